@@ -1,0 +1,134 @@
+/*
+ * pyglm_hip.h -- C ABI of the MI355X (gfx950) population-GLM likelihood library.
+ *
+ * The reference (slinderman/theano_pyglm) has no FFI: its operator boundary is
+ *   seval(expr, syms, vals)            pyglm/utils/theano_func_wrapper.py:12-51
+ * evaluated on Theano shared variables filled by
+ *   Glm.set_data / Population.set_data pyglm/glm.py:99-110, pyglm/population.py:223-231
+ * Each entry point below names the reference expression(s) it replaces.  All
+ * pointers are plain host pointers unless the name ends in `_dev`; the caller
+ * owns host buffers, the library owns device buffers.  Every function returns
+ * 0 on success and a negative code on failure; pgl_last_error() gives the text.
+ * A handle is bound to one GPU; calls on one handle must be serialised by the
+ * caller (like the reference's module-global _func_cache / shared variables).
+ *
+ * Flat feature-weight layout ("theta", one row per post-synaptic neuron):
+ *     theta[0]                      bias                     (bias.py:32)
+ *     theta[1 .. 1+Dstim)           stimulus feature weights (bkgd.py:81 / 227: w_stim,
+ *                                   for SpatiotemporalStimulus vec(w_t (x) w_x), bkgd.py:214-220)
+ *     theta[1+Dstim .. 1+Dstim+N*B) impulse weights w[n_pre*B + b]
+ *                                   (impulse.py:58 w_ir; for DirichletImpulses beta, impulse.py:286-308)
+ *   P = 1 + Dstim + N*B.  Gradients come back in the same layout (chain rules
+ *   through w_t (x) w_x or |g|/sum|g| are applied by the host mirror).
+ * Weff is the (N x N) row-major matrix A[n_pre,n_post]*W[n_pre,n_post] (glm.py:31-37).
+ */
+#ifndef PYGLM_HIP_H
+#define PYGLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgl_context* pgl_handle;
+
+#define PGL_OK 0
+#define PGL_ERR_ARG (-1)       /* bad argument */
+#define PGL_ERR_HIP (-2)       /* HIP runtime error (no device, OOM, launch failure) */
+#define PGL_ERR_STATE (-3)     /* call order (e.g. ll before set_spikes) */
+#define PGL_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
+
+#define PGL_NLIN_EXP 0         /* nlin.py:25 */
+#define PGL_NLIN_EXPLINEAR 1   /* nlin.py:43 */
+
+/* flags for pgl_set_option */
+#define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
+#define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
+
+const char* pgl_last_error(void);
+int pgl_version(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int pgl_device_count(void);
+
+/* Context for a population of N neurons observed for nT bins of width dt, with
+ * B impulse basis functions of R taps (impulse.py:92-112).  Mirrors
+ * Population.__init__/Glm.__init__ (population.py:12-32, glm.py:8-63). */
+int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
+               pgl_handle* out);
+int pgl_destroy(pgl_handle h);
+int pgl_set_option(pgl_handle h, int option, int value);
+
+/* Glm.set_data: S.set_value(data["S"]) (glm.py:99-103).  Spike counts (nT,N)
+ * row-major.  The f64 form checks that every count is an integer in 0..255
+ * (population.py:345-349 caps at 10) and stores uint8. */
+int pgl_set_spikes_u8(pgl_handle h, const uint8_t* S);
+int pgl_set_spikes_f64(pgl_handle h, const double* S);
+
+/* The interpolated impulse basis `ibasis` (R,B) row-major (impulse.py:92-112, 359-376). */
+int pgl_set_basis(pgl_handle h, const double* ibasis);
+
+/* bkgd_model.set_data: stim.set_value(data['fstim']) (bkgd.py:156-157, 342-345).
+ * fstim is (nT, Dstim) row-major; Dstim = 0 / NULL = NoStimulus (bkgd.py:29-43). */
+int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim);
+
+/* seval(glm.ll) and seval(g_glm_ll) for every post-synaptic neuron n in
+ * [n_lo, n_hi) in one fused pass (glm.py:39-52; coord_descent.py:27-30, 52-57, 73-78;
+ * population.py:71-86).  theta is ((n_hi-n_lo), P), Weff is (N,N).
+ * ll_out[(n_hi-n_lo)], grad_out[(n_hi-n_lo)*P] (grad_out may be NULL: ll only). */
+int pgl_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* theta,
+                const double* Weff, double* ll_out, double* grad_out);
+
+/* Same with device pointers, asynchronous on the handle's stream; pair with pgl_sync. */
+int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
+                    const double* d_Weff, double* d_ll, double* d_grad);
+int pgl_sync(pgl_handle h);
+
+/* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
+ * fS_out (nT,N,B) row-major, float64. */
+int pgl_features(pgl_handle h, double* fS_out);
+
+/* seval(imp_model.I_imp) (impulse.py:58 / 308; gibbs.py:812-833):
+ * I_imp_out (nT,N) row-major for impulse weights w (N,B). */
+int pgl_impulse_currents(pgl_handle h, const double* w, double* I_imp_out);
+
+/* Glm.get_state lam / I_net / I_bkgd for neuron n (glm.py:75-91, population.py:88-120).
+ * theta_n is one row (P); Weff_col is column n of Weff (N).  Outputs (nT) or NULL. */
+int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col,
+              double* lam_out, double* I_net_out, double* I_stim_out);
+
+/* CollapsedGibbsNetworkColumnUpdate._glm_ll (gibbs.py:910-937): for each w[k],
+ * ll_k = sum_t(-dt*lam + log(lam)*S[t,n_post]), lam = nlin(I_bias + I_stim[t] +
+ * I_other[t] + w[k]*I_col[t]).  I_stim may be NULL.  Host arrays of nT. */
+int pgl_ll_from_current(pgl_handle h, int n_post, double I_bias, const double* I_stim,
+                        const double* I_other, const double* I_col, const double* w,
+                        int K, double* ll_out);
+
+/* Device-resident form of _precompute_vars + _precompute_other_current + _glm_ll
+ * (gibbs.py:812-864, 910-937).  prepare: computes I_imp (all presynaptic columns)
+ * and the total I_net for neuron n_post once.  ll: for presynaptic n_pre, removes
+ * the current contribution aw_cur*I_imp[:,n_pre] (rank-1 downdate instead of the
+ * reference's full gemv per pair) and evaluates ll at the K candidate weights. */
+int pgl_gibbs_prepare(pgl_handle h, int n_post, const double* theta_n,
+                      const double* Weff_col);
+int pgl_gibbs_ll(pgl_handle h, int n_pre, double aw_cur, const double* w, int K,
+                 double* ll_out);
+/* After A[n_pre,n_post]*W[n_pre,n_post] changed by `delta` (gibbs.py:1044-1066 writes the
+ * new sample into the state dict): I_net += delta * I_imp[:,n_pre] on the device. */
+int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
+
+/* Timing of the most recent pgl_ll_grad[_dev] call, measured with HIP events on the
+ * handle's stream: ms of the fused kernel alone and of the whole call (prep +
+ * fused + finalize).  For the _dev form call after pgl_sync. */
+int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms);
+
+/* Launch geometry and algorithmic work of the fused kernel for [n_lo,n_hi):
+ * info[0]=blocks, [1]=threads/block, [2]=time chunks, [3]=k-tiles(16 rows),
+ * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),
+ * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins). */
+int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+"""
+GPU parity tests: the HIP path (through the C ABI, theano_pyglm_amd._lib) against
+the CPU oracle on the same seeded inputs.  Tolerances (north_star): ll rtol 1e-5,
+gradient 1e-4 of max|g|; the f64 path is held to far tighter bounds here.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import glm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-10      # f64 path (north_star asks 1e-5)
+G_RTOL = 1e-9        # relative to max|g| (north_star asks 1e-4)
+
+
+def _check(prob, n_lo=0, n_hi=None, f32=False, nchunks=0, ll_rtol=LL_RTOL, g_rtol=G_RTOL):
+    dev = prob.device(f32=f32, nchunks=nchunks)
+    n_hi = prob.N if n_hi is None else n_hi
+    ll, g = dev.ll_grad(prob.theta[n_lo:n_hi], prob.Weff, n_lo, n_hi)
+    ll0, g0 = prob.oracle_ll_grad(n_lo, n_hi)
+    assert np.all(np.isfinite(ll)) and np.all(np.isfinite(g))
+    assert np.allclose(ll, ll0, rtol=ll_rtol, atol=0), (ll, ll0)
+    assert H.rel_err(g, g0) < g_rtol, H.rel_err(g, g0)
+    # ll-only call gives the same ll
+    ll2, _ = dev.ll_grad(prob.theta[n_lo:n_hi], prob.Weff, n_lo, n_hi, want_grad=False)
+    assert np.array_equal(ll, ll2)
+    dev.close()
+    return ll, g
+
+
+def test_features_golden(golden):
+    """pgl_features == reference convolve_with_basis (basis.py:201-236) golden vectors."""
+    from theano_pyglm_amd import _lib
+    for key_s, key_f in (('conv_S', 'conv_fS'), ('conv_short_S', 'conv_short_fS'),
+                         ('conv_one_S', 'conv_one_fS')):
+        S = golden[key_s]
+        ib = golden['conv_ibasis']
+        d = _lib.DeviceGlm(S.shape[1], S.shape[0], ib.shape[1], ib.shape[0], 'explinear', 0.001)
+        d.set_spikes(S)
+        d.set_basis(ib)
+        f = d.features()
+        assert np.max(np.abs(f - golden[key_f])) < 1e-12
+        d.close()
+
+
+def test_ll_grad_c1_like():
+    """standard_glm shape N=4 (KT=2 padded), ragged nT."""
+    _check(H.Problem(4, 3001, H.std_ibasis(), seed=1))
+
+
+def test_ll_grad_n32():
+    """C2 shape N=32 (KT=10), 2 post tiles."""
+    _check(H.Problem(32, 4096, H.std_ibasis(), seed=2))
+
+
+def test_ll_grad_ragged_n20_weighted():
+    """N=20: second post tile is ragged; Weff = A*W (sparse_weighted-like)."""
+    _check(H.Problem(20, 2500, H.std_ibasis(), seed=3, weighted=True))
+
+
+def test_ll_grad_n128():
+    """C3 shape N=128 (KT=40, 8 post tiles, 2 post blocks)."""
+    _check(H.Problem(128, 1536, H.std_ibasis(), seed=4, w_scale=0.5))
+
+
+def test_ll_grad_subrange():
+    """Neuron shard [n_lo,n_hi) as used by the multi-GPU split."""
+    p = H.Problem(40, 2000, H.std_ibasis(), seed=5)
+    _check(p, 16, 32)
+    _check(p, 7, 40)
+
+
+def test_ll_grad_exp_stim():
+    """spatiotemporal_glm shape: exp nonlinearity, B=3, R=300, 9 dense stimulus columns."""
+    _check(H.Problem(8, 2200, H.st_ibasis(), kind='exp', Dstim=9, seed=6))
+
+
+def test_ll_grad_n64_b3_stim_kt13():
+    """C5 shape N=64, B=3 + 9 stimulus columns -> 201 feature columns (KT=13)."""
+    _check(H.Problem(64, 1200, H.st_ibasis(), kind='exp', Dstim=9, seed=7, w_scale=0.02))
+
+
+def test_chunking_invariance():
+    """Different time-chunk decompositions agree to reduction round-off."""
+    p = H.Problem(16, 5000, H.std_ibasis(), seed=8)
+    a, ga = _check(p, nchunks=1)
+    b, gb = _check(p, nchunks=7)
+    c, gc = _check(p, nchunks=313)
+    assert np.allclose(a, b, rtol=1e-12) and np.allclose(a, c, rtol=1e-12)
+    assert H.rel_err(ga, gc) < 1e-12
+
+
+def test_f32_feature_staging():
+    """Optional f32 LDS staging of the feature tile: still far inside rtol 1e-5."""
+    p = H.Problem(32, 4096, H.std_ibasis(), seed=9)
+    _check(p, f32=True, ll_rtol=1e-8, g_rtol=1e-6)
+
+
+def test_high_rate_overflows_staging():
+    """> 16 events per neuron per window: the global-memory fallback of the event staging."""
+    p = H.Problem(8, 1500, H.std_ibasis(), seed=10, rate_hz=400.0, bias_mu=3.0, w_scale=0.05)
+    _check(p)
+
+
+def test_empty_spikes():
+    p = H.Problem(4, 500, H.std_ibasis(), seed=11)
+    p.S[:] = 0
+    p._fS = None
+    _check(p)
+
+
+def test_impulse_currents_and_state():
+    p = H.Problem(6, 1800, H.std_ibasis(), seed=12, weighted=True)
+    dev = p.device()
+    n = 3
+    w = p.theta[n, 1:].reshape(p.N, p.B)
+    I = dev.impulse_currents(w)
+    I0 = O.impulse_currents(p.fS, w)
+    assert np.max(np.abs(I - I0)) < 1e-11
+    lam, inet, istim = dev.state(n, p.theta[n], p.Weff[:, n])
+    x0, inet0, _ = O.glm_currents(n, p.fS, w, p.Weff[:, n], p.theta[n, 0])
+    assert np.max(np.abs(inet - inet0)) < 1e-10
+    assert np.allclose(lam, O.nlin(x0, p.kind), rtol=1e-12)
+    assert np.all(istim == 0)
+    # reference invariant lam_true == lam_sim (generate_synth_data.py:125-129): the
+    # feature path equals the simulator's time-domain superposition
+    imps = O.impulse_responses(p.ibasis, w)
+    xd = O.direct_currents(p.S.astype(float), imps, p.Weff[:, n], p.theta[n, 0])
+    assert np.allclose(lam, O.nlin(xd, p.kind))
+    dev.close()
+
+
+def test_mcmc_inner_ll():
+    """gibbs.py:910-937 at the 10 Gauss-Hermite nodes + w=0 (gibbs.py:1002-1032)."""
+    p = H.Problem(5, 2600, H.std_ibasis(), seed=13, weighted=True)
+    dev = p.device()
+    n_post, n_pre = 2, 4
+    w = p.theta[n_post, 1:].reshape(p.N, p.B)
+    I_imp = O.impulse_currents(p.fS, w)
+    A = (p.Weff != 0).astype(float)
+    I_other = O.other_current(I_imp, A, p.Weff, n_pre, n_post)
+    ws, _ = O.gauss_hermite_nodes(0.0, 1.0)
+    ws = np.concatenate((ws, [0.0]))
+    ref = O.mcmc_inner_ll(ws, p.theta[n_post, 0], 0.0, I_other, I_imp[:, n_pre],
+                          p.S[:, n_post].astype(float), p.dt, p.kind)
+    got = dev.ll_from_current(n_post, p.theta[n_post, 0], None, I_other, I_imp[:, n_pre], ws)
+    assert np.allclose(got, ref, rtol=1e-11)
+    # device-resident form with the rank-1 downdate
+    dev.gibbs_prepare(n_post, p.theta[n_post], p.Weff[:, n_post])
+    got2 = dev.gibbs_ll(n_pre, p.Weff[n_pre, n_post], ws)
+    assert np.allclose(got2, ref, rtol=1e-10)
+    # 23 candidate weights (> one launch of 16)
+    ws3 = np.linspace(-2, 2, 23)
+    ref3 = O.mcmc_inner_ll(ws3, p.theta[n_post, 0], 0.0, I_other, I_imp[:, n_pre],
+                           p.S[:, n_post].astype(float), p.dt, p.kind)
+    assert np.allclose(dev.gibbs_ll(n_pre, p.Weff[n_pre, n_post], ws3), ref3, rtol=1e-10)
+    # update: set the pair's weight to 0.7 and look at another presynaptic neuron
+    dev.gibbs_update(n_pre, 0.7 - p.Weff[n_pre, n_post])
+    W2 = p.Weff.copy()
+    W2[n_pre, n_post] = 0.7
+    I_other2 = O.other_current(I_imp, (W2 != 0).astype(float), W2, 1, n_post)
+    ref4 = O.mcmc_inner_ll(ws, p.theta[n_post, 0], 0.0, I_other2, I_imp[:, 1],
+                           p.S[:, n_post].astype(float), p.dt, p.kind)
+    assert np.allclose(dev.gibbs_ll(1, W2[1, n_post], ws), ref4, rtol=1e-10)
+    dev.close()
+
+
+def test_errors():
+    from theano_pyglm_amd import _lib
+    d = _lib.DeviceGlm(4, 100, 5, 200, 'explinear', 0.001)
+    with pytest.raises(_lib.PglError):
+        d.ll_grad(np.zeros((4, 21)), np.ones((4, 4)))      # no data yet
+    with pytest.raises(_lib.PglError):
+        d.set_spikes(np.full((100, 4), 0.5))               # non-integer counts
+    d.close()
+    with pytest.raises(_lib.PglError):
+        _lib.DeviceGlm(4, 100, 9, 200, 'explinear', 0.001)  # B > 8

@@ -1,0 +1,244 @@
+"""
+ctypes binding of the C ABI declared in include/pyglm_hip.h (libpyglm_hip.so,
+built from theano_pyglm_amd/csrc by __graft_entry__.build()).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is
+visible, every compute entry point raises PglError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpyglm_hip.so')
+
+NLIN_EXP = 0
+NLIN_EXPLINEAR = 1
+OPT_FEATURE_F32 = 1
+OPT_NCHUNKS = 2
+
+# every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    'pgl_last_error', 'pgl_version', 'pgl_device_count', 'pgl_create', 'pgl_destroy',
+    'pgl_set_option', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
+    'pgl_set_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
+    'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
+    'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info',
+]
+
+
+class PglError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libpyglm_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PglError("HIP library %s not found: run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+                       % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    lib.pgl_last_error.restype = C.c_char_p
+    lib.pgl_last_error.argtypes = []
+    lib.pgl_version.restype = C.c_int
+    lib.pgl_device_count.restype = C.c_int
+    lib.pgl_create.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                               C.POINTER(vp)]
+    lib.pgl_destroy.argtypes = [vp]
+    lib.pgl_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.pgl_set_spikes_u8.argtypes = [vp, vp]
+    lib.pgl_set_spikes_f64.argtypes = [vp, vp]
+    lib.pgl_set_basis.argtypes = [vp, vp]
+    lib.pgl_set_stim_features.argtypes = [vp, vp, C.c_int]
+    lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pgl_sync.argtypes = [vp]
+    lib.pgl_features.argtypes = [vp, vp]
+    lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
+    lib.pgl_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.pgl_ll_from_current.argtypes = [vp, C.c_int, C.c_double, vp, vp, vp, vp, C.c_int, vp]
+    lib.pgl_gibbs_prepare.argtypes = [vp, C.c_int, vp, vp]
+    lib.pgl_gibbs_ll.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int, vp]
+    lib.pgl_gibbs_update.argtypes = [vp, C.c_int, C.c_double]
+    lib.pgl_last_timing.argtypes = [vp, dp, dp]
+    lib.pgl_info.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ('pgl_last_error',):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return load().pgl_device_count()
+
+
+def _chk(rc):
+    if rc != 0:
+        raise PglError("libpyglm_hip error %d: %s" % (rc, load().pgl_last_error().decode()))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceGlm(object):
+    """One pgl_handle: the device-resident data of one data sequence
+    (the Theano shared variables S / ir / stim of glm.py:17-18, impulse.py:41-42,
+    bkgd.py:70-71) plus the kernels that evaluate glm.ll and its gradient on it."""
+
+    def __init__(self, N, nT, B, R, nlin, dt, device=0):
+        self.lib = load()
+        self.N, self.nT, self.B, self.R, self.dt = int(N), int(nT), int(B), int(R), float(dt)
+        self.nlin = {'exp': NLIN_EXP, 'explinear': NLIN_EXPLINEAR}.get(nlin, nlin)
+        self.Dstim = 0
+        h = C.c_void_p()
+        _chk(self.lib.pgl_create(self.N, self.nT, self.B, self.R, int(self.nlin), self.dt,
+                                 int(device), C.byref(h)))
+        self.h = h
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h.value:
+            self.lib.pgl_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def P(self):
+        return 1 + self.Dstim + self.N * self.B
+
+    # -- data ---------------------------------------------------------------
+    def set_option(self, opt, value):
+        _chk(self.lib.pgl_set_option(self.h, int(opt), int(value)))
+
+    def set_spikes(self, S):
+        S = np.asarray(S)
+        if S.shape != (self.nT, self.N):
+            raise ValueError("S must be (nT,N)=(%d,%d), got %s" % (self.nT, self.N, S.shape))
+        if S.dtype == np.uint8:
+            S = np.ascontiguousarray(S)
+            _chk(self.lib.pgl_set_spikes_u8(self.h, _ptr(S)))
+        else:
+            S = _f64(S)
+            _chk(self.lib.pgl_set_spikes_f64(self.h, _ptr(S)))
+
+    def set_basis(self, ibasis):
+        ib = _f64(ibasis, (self.R, self.B))
+        _chk(self.lib.pgl_set_basis(self.h, _ptr(ib)))
+
+    def set_stim_features(self, fstim):
+        if fstim is None:
+            _chk(self.lib.pgl_set_stim_features(self.h, None, 0))
+            self.Dstim = 0
+            return
+        f = _f64(fstim)
+        if f.ndim != 2 or f.shape[0] != self.nT:
+            raise ValueError("fstim must be (nT,Dstim)")
+        _chk(self.lib.pgl_set_stim_features(self.h, _ptr(f), int(f.shape[1])))
+        self.Dstim = int(f.shape[1])
+
+    # -- hot path -------------------------------------------------------------
+    def ll_grad(self, theta, Weff, n_lo=0, n_hi=None, want_grad=True):
+        n_hi = self.N if n_hi is None else n_hi
+        npost = n_hi - n_lo
+        th = _f64(theta, (npost, self.P))
+        We = _f64(Weff, (self.N, self.N))
+        ll = np.empty(npost)
+        g = np.empty((npost, self.P)) if want_grad else None
+        _chk(self.lib.pgl_ll_grad(self.h, int(n_lo), int(n_hi), _ptr(th), _ptr(We), _ptr(ll),
+                                  _ptr(g)))
+        return ll, g
+
+    def ll_grad_dev(self, d_theta, d_Weff, d_ll, d_grad, n_lo=0, n_hi=None):
+        """Device-pointer form (integers, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        n_hi = self.N if n_hi is None else n_hi
+        _chk(self.lib.pgl_ll_grad_dev(self.h, int(n_lo), int(n_hi), C.c_void_p(d_theta),
+                                      C.c_void_p(d_Weff), C.c_void_p(d_ll),
+                                      C.c_void_p(d_grad) if d_grad else None))
+
+    def sync(self):
+        _chk(self.lib.pgl_sync(self.h))
+
+    def last_timing(self):
+        a, b = C.c_double(), C.c_double()
+        _chk(self.lib.pgl_last_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self, n_lo=0, n_hi=None):
+        n_hi = self.N if n_hi is None else n_hi
+        v = np.zeros(9)
+        _chk(self.lib.pgl_info(self.h, int(n_lo), int(n_hi), _ptr(v), 9))
+        keys = ['blocks', 'threads', 'chunks', 'ktiles', 'lds_bytes', 'tile_rows', 'flops',
+                'bytes', 'events']
+        return dict(zip(keys, v.tolist()))
+
+    # -- direct-form helpers --------------------------------------------------
+    def features(self):
+        out = np.empty((self.nT, self.N, self.B))
+        _chk(self.lib.pgl_features(self.h, _ptr(out)))
+        return out
+
+    def impulse_currents(self, w):
+        w = _f64(w, (self.N, self.B))
+        out = np.empty((self.nT, self.N))
+        _chk(self.lib.pgl_impulse_currents(self.h, _ptr(w), _ptr(out)))
+        return out
+
+    def state(self, n, theta_n, Weff_col):
+        th = _f64(theta_n, (self.P,))
+        wc = _f64(Weff_col, (self.N,))
+        lam = np.empty(self.nT)
+        inet = np.empty(self.nT)
+        istim = np.empty(self.nT)
+        _chk(self.lib.pgl_state(self.h, int(n), _ptr(th), _ptr(wc), _ptr(lam), _ptr(inet),
+                                _ptr(istim)))
+        return lam, inet, istim
+
+    def ll_from_current(self, n_post, I_bias, I_stim, I_other, I_col, ws):
+        ws = _f64(np.atleast_1d(ws))
+        I_other = _f64(I_other, (self.nT,))
+        I_col = _f64(I_col, (self.nT,))
+        I_stim = None if I_stim is None else _f64(I_stim, (self.nT,))
+        out = np.empty(len(ws))
+        _chk(self.lib.pgl_ll_from_current(self.h, int(n_post), float(I_bias), _ptr(I_stim),
+                                          _ptr(I_other), _ptr(I_col), _ptr(ws), len(ws),
+                                          _ptr(out)))
+        return out
+
+    def gibbs_prepare(self, n_post, theta_n, Weff_col):
+        th = _f64(theta_n, (self.P,))
+        wc = _f64(Weff_col, (self.N,))
+        _chk(self.lib.pgl_gibbs_prepare(self.h, int(n_post), _ptr(th), _ptr(wc)))
+
+    def gibbs_ll(self, n_pre, aw_cur, ws):
+        ws = _f64(np.atleast_1d(ws))
+        out = np.empty(len(ws))
+        _chk(self.lib.pgl_gibbs_ll(self.h, int(n_pre), float(aw_cur), _ptr(ws), len(ws),
+                                   _ptr(out)))
+        return out
+
+    def gibbs_update(self, n_pre, delta):
+        _chk(self.lib.pgl_gibbs_update(self.h, int(n_pre), float(delta)))

@@ -1,0 +1,638 @@
+// C ABI (include/pyglm_hip.h) over the gfx950 kernels in pglm_kernels.hip.h.
+// Host side: context, device buffers, spike-event (CSR) index, launch plans, timing.
+#include "pglm_kernels.hip.h"
+#include "../../include/pyglm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(PGL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct pgl_context {
+    int N = 0, B = 0, R = 0, nlin = 0, device = 0;
+    int64_t nT = 0;
+    double dt = 0;
+    int Dstim = 0, Kimp = 0, Ktot = 0, nT16 = 0;
+    int numCU = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_spikes = false, have_basis = false;
+    int64_t nnz = 0;
+    DevBuf S, ST, spk, wlo, whi, phi, fstim;
+    DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart;
+    DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
+    int gibbs_npost = -1;
+    double gibbs_bias = 0;
+    int opt_f32 = 0, opt_nchunks = 0;
+    bool timing_valid = false;
+};
+
+static int ensure(DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return PGL_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return PGL_OK;
+}
+static void release(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+#define ENSURE(buf, bytes)                       \
+    do {                                         \
+        int rc_ = ensure(buf, bytes);            \
+        if (rc_ != PGL_OK) return rc_;           \
+    } while (0)
+
+struct Plan {
+    int npost, nPT, wpb, nPB, KT, KS, rsf, nTiles, nChunks, tilesPerChunk, blocks, threads;
+    size_t lds;
+    bool f32;
+};
+
+static const int kKT[] = {2, 4, 10, 13, 20, 40};
+
+static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
+{
+    if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
+    pl.npost = n_hi - n_lo;
+    pl.nPT = (pl.npost + 15) / 16;
+    pl.wpb = std::min(4, pl.nPT);
+    pl.nPB = (pl.nPT + pl.wpb - 1) / pl.wpb;
+    const int need = (h->Ktot + 15) / 16;
+    pl.KT = 0;
+    for (int kt : kKT)
+        if (kt >= need) {
+            pl.KT = kt;
+            break;
+        }
+    if (pl.KT == 0)
+        return fail(PGL_ERR_UNSUPPORTED,
+                    "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
+    pl.KS = pl.KT * 4;
+    pl.f32 = h->opt_f32 != 0;
+    const int kpad = pl.KT * 16;
+    pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
+    pl.nTiles = h->nT16;
+    int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, h->numCU / pl.nPB);
+    target = std::min(target, pl.nTiles);
+    pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
+    pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
+    pl.blocks = pl.nChunks * pl.nPB;
+    pl.threads = 64 * pl.wpb;
+    size_t off = ((size_t)16 * pl.rsf * (pl.f32 ? 4 : 8) + 15) & ~(size_t)15;
+    off += (((size_t)h->B * h->R * 8) + 15) & ~(size_t)15;
+    off += (size_t)h->N * PGL_CAP * 8;
+    off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
+    off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
+    pl.lds = off;
+    if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
+    return PGL_OK;
+}
+
+template <int KT, typename FT>
+static hipError_t launch_fused_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    auto kern = k_fused_ll_grad<KT, FT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(pl.threads), pl.lds, s, fp);
+    return hipGetLastError();
+}
+
+template <typename FT>
+static hipError_t launch_fused_kt(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KT) {
+    case 2: return launch_fused_t<2, FT>(pl, fp, s);
+    case 4: return launch_fused_t<4, FT>(pl, fp, s);
+    case 10: return launch_fused_t<10, FT>(pl, fp, s);
+    case 13: return launch_fused_t<13, FT>(pl, fp, s);
+    case 20: return launch_fused_t<20, FT>(pl, fp, s);
+    case 40: return launch_fused_t<40, FT>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" {
+
+const char* pgl_last_error(void) { return g_err.c_str(); }
+int pgl_version(void) { return 100; }
+
+int pgl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device, pgl_handle* out)
+{
+    if (!out) return fail(PGL_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (N <= 0 || nT <= 0 || B <= 0 || R <= 0) return fail(PGL_ERR_ARG, "N, nT, B, R must be positive");
+    if (B > PGL_MAXB) return fail(PGL_ERR_UNSUPPORTED, "B > 8 basis functions");
+    if (nlin != PGL_NLIN_EXP && nlin != PGL_NLIN_EXPLINEAR) return fail(PGL_ERR_ARG, "unknown nonlinearity");
+    if (nT > (int64_t)1 << 30) return fail(PGL_ERR_UNSUPPORTED, "nT > 2^30 bins");
+    if (!(dt > 0)) return fail(PGL_ERR_ARG, "dt must be positive");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(PGL_ERR_HIP, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(PGL_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    pgl_context* h = new pgl_context();
+    h->N = N; h->nT = nT; h->B = B; h->R = R; h->nlin = nlin; h->dt = dt; h->device = device;
+    h->Kimp = N * B; h->Ktot = h->Kimp; h->nT16 = (int)((nT + 15) / 16);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->numCU = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
+    for (int i = 0; i < 4; ++i) {
+        e = hipEventCreate(&h->ev[i]);
+        if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
+    }
+    *out = h;
+    return PGL_OK;
+}
+
+int pgl_destroy(pgl_handle h)
+{
+    if (!h) return PGL_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
+                      &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
+                      &h->gbpart, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
+                      &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan};
+    for (DevBuf* b : bufs) release(*b);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PGL_OK;
+}
+
+int pgl_set_option(pgl_handle h, int option, int value)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    switch (option) {
+    case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
+    case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
+    }
+    return fail(PGL_ERR_ARG, "unknown option");
+}
+
+// Build the spike-event index from the dense count matrix and upload everything.
+static int upload_spikes(pgl_handle h, const uint8_t* S)
+{
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->N;
+    const int64_t nT = h->nT;
+    std::vector<int> cnt(N + 1, 0);
+    for (int64_t t = 0; t < nT; ++t) {
+        const uint8_t* row = S + t * N;
+        for (int n = 0; n < N; ++n) cnt[n + 1] += row[n] != 0;
+    }
+    for (int n = 0; n < N; ++n) cnt[n + 1] += cnt[n];
+    const int64_t nnz = cnt[N];
+    std::vector<int2> ev((size_t)std::max<int64_t>(nnz, 1));
+    {
+        std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t t = 0; t < nT; ++t) {
+            const uint8_t* row = S + t * N;
+            for (int n = 0; n < N; ++n)
+                if (row[n]) ev[(size_t)cur[n]++] = make_int2((int)t, (int)row[n]);
+        }
+    }
+    // per 16-row tile event windows: lo = first s >= 16*tile - R, hi = first s >= 16*tile + 15
+    const int nT16 = h->nT16;
+    std::vector<int> wlo((size_t)nT16 * N), whi((size_t)nT16 * N);
+    for (int n = 0; n < N; ++n) {
+        int lo = cnt[n], hi = cnt[n];
+        const int end = cnt[n + 1];
+        for (int tile = 0; tile < nT16; ++tile) {
+            const int64_t klo = (int64_t)16 * tile - h->R;
+            const int64_t khi = (int64_t)16 * tile + 15;
+            while (lo < end && ev[(size_t)lo].x < klo) ++lo;
+            while (hi < end && ev[(size_t)hi].x < khi) ++hi;
+            wlo[(size_t)tile * N + n] = lo;
+            whi[(size_t)tile * N + n] = hi;
+        }
+    }
+    ENSURE(h->S, (size_t)nT * N);
+    ENSURE(h->ST, (size_t)nT * N);
+    ENSURE(h->spk, ev.size() * sizeof(int2));
+    ENSURE(h->wlo, wlo.size() * 4);
+    ENSURE(h->whi, whi.size() * 4);
+    HIPCHK(hipMemcpyAsync(h->S.p, S, (size_t)nT * N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->spk.p, ev.data(), ev.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), wlo.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), whi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    dim3 grid((unsigned)((nT + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(k_transpose_u8, grid, dim3(256), 0, h->stream, (const uint8_t*)h->S.p,
+                       (uint8_t*)h->ST.p, (long long)nT, N);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->nnz = nnz;
+    h->have_spikes = true;
+    h->gibbs_npost = -1;
+    return PGL_OK;
+}
+
+int pgl_set_spikes_u8(pgl_handle h, const uint8_t* S)
+{
+    if (!h || !S) return fail(PGL_ERR_ARG, "null argument");
+    return upload_spikes(h, S);
+}
+
+int pgl_set_spikes_f64(pgl_handle h, const double* S)
+{
+    if (!h || !S) return fail(PGL_ERR_ARG, "null argument");
+    const size_t n = (size_t)h->nT * h->N;
+    std::vector<uint8_t> u(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double v = S[i];
+        if (!(v >= 0.0 && v <= 255.0) || v != std::floor(v))
+            return fail(PGL_ERR_ARG, "spike counts must be integers in 0..255");
+        u[i] = (uint8_t)v;
+    }
+    return upload_spikes(h, u.data());
+}
+
+int pgl_set_basis(pgl_handle h, const double* ibasis)
+{
+    if (!h || !ibasis) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> ph((size_t)h->B * h->R);
+    for (int d = 0; d < h->R; ++d)
+        for (int b = 0; b < h->B; ++b) ph[(size_t)b * h->R + d] = ibasis[(size_t)d * h->B + b];
+    ENSURE(h->phi, ph.size() * 8);
+    HIPCHK(hipMemcpyAsync(h->phi.p, ph.data(), ph.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_basis = true;
+    h->gibbs_npost = -1;
+    return PGL_OK;
+}
+
+int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    if (Dstim < 0 || (Dstim > 0 && !fstim)) return fail(PGL_ERR_ARG, "bad stimulus features");
+    HIPCHK(hipSetDevice(h->device));
+    if ((h->Kimp + Dstim + 15) / 16 > 40)
+        return fail(PGL_ERR_UNSUPPORTED, "N*B + Dstim exceeds 640 feature columns");
+    h->Dstim = Dstim;
+    h->Ktot = h->Kimp + Dstim;
+    h->gibbs_npost = -1;
+    if (Dstim > 0) {
+        const size_t bytes = (size_t)h->nT * Dstim * 8;
+        ENSURE(h->fstim, bytes);
+        HIPCHK(hipMemcpyAsync(h->fstim.p, fstim, bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return PGL_OK;
+}
+
+static int check_ready(pgl_handle h)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    if (!h->have_spikes) return fail(PGL_ERR_STATE, "pgl_set_spikes_* has not been called");
+    if (!h->have_basis) return fail(PGL_ERR_STATE, "pgl_set_basis has not been called");
+    return PGL_OK;
+}
+
+// Enqueue prep + fused + finalize on the handle's stream.  All pointers are device pointers.
+static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double* d_theta,
+                           const double* d_Weff, double* d_ll, double* d_grad)
+{
+    const int P = 1 + h->Dstim + h->Kimp;
+    (void)P;
+    ENSURE(h->Wfrag, (size_t)pl.nPT * pl.KS * 64 * 8);
+    ENSURE(h->bias, (size_t)pl.nPT * 16 * 8);
+    ENSURE(h->llpart, (size_t)pl.nChunks * pl.nPT * 64 * 8);
+    ENSURE(h->gbpart, (size_t)pl.nChunks * pl.nPT * 64 * 8);
+    if (d_grad) ENSURE(h->Gpart, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
+
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    {
+        const long long total = (long long)pl.nPT * pl.KS * 64;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
+                           (double*)h->Wfrag.p, (double*)h->bias.p, h->N, h->B, h->Dstim, h->Kimp,
+                           h->Ktot, pl.KS, n_lo, pl.npost, pl.nPT);
+        HIPCHK(hipGetLastError());
+    }
+    FusedParams fp;
+    fp.nT = h->nT; fp.N = h->N; fp.B = h->B; fp.R = h->R; fp.nlin = h->nlin;
+    fp.Dstim = h->Dstim; fp.Kimp = h->Kimp; fp.Ktot = h->Ktot; fp.dt = h->dt;
+    fp.spk = (const int2*)h->spk.p; fp.wlo = (const int*)h->wlo.p; fp.whi = (const int*)h->whi.p;
+    fp.S = (const uint8_t*)h->S.p; fp.fstim = (const double*)h->fstim.p; fp.phi = (const double*)h->phi.p;
+    fp.Wfrag = (const double*)h->Wfrag.p; fp.bias = (const double*)h->bias.p;
+    fp.n_lo = n_lo; fp.npost = pl.npost; fp.nPT = pl.nPT;
+    fp.nT16 = h->nT16; fp.tilesPerChunk = pl.tilesPerChunk; fp.nChunks = pl.nChunks; fp.nTiles = pl.nTiles;
+    fp.rsf = pl.rsf;
+    fp.Gpart = (double*)h->Gpart.p; fp.llpart = (double*)h->llpart.p; fp.gbpart = (double*)h->gbpart.p;
+    fp.want_grad = d_grad ? 1 : 0;
+
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    hipError_t e = pl.f32 ? launch_fused_kt<float>(pl, fp, h->stream)
+                          : launch_fused_kt<double>(pl, fp, h->stream);
+    if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
+    HIPCHK(hipEventRecord(h->ev[2], h->stream));
+    {
+        const long long nfrag = d_grad ? (long long)pl.nPT * pl.KT * 256 : 0;
+        const long long nthreads = std::max<long long>(nfrag, pl.npost);
+        const int blocks = (int)((nthreads + 255) / 256);
+        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream,
+                           (const double*)h->Gpart.p, (const double*)h->llpart.p,
+                           (const double*)h->gbpart.p, d_Weff, d_ll, d_grad, h->N, h->B, h->Dstim,
+                           h->Kimp, h->Ktot, pl.KT, n_lo, pl.npost, pl.nPT, pl.nChunks);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    h->timing_valid = true;
+    return PGL_OK;
+}
+
+int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta, const double* d_Weff,
+                    double* d_ll, double* d_grad)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!d_theta || !d_Weff || !d_ll) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    Plan pl;
+    rc = make_plan(h, n_lo, n_hi, pl);
+    if (rc) return rc;
+    return enqueue_ll_grad(h, pl, n_lo, d_theta, d_Weff, d_ll, d_grad);
+}
+
+int pgl_sync(pgl_handle h)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PGL_OK;
+}
+
+int pgl_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* theta, const double* Weff,
+                double* ll_out, double* grad_out)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!theta || !Weff || !ll_out) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    Plan pl;
+    rc = make_plan(h, n_lo, n_hi, pl);
+    if (rc) return rc;
+    const size_t P = 1 + (size_t)h->Dstim + h->Kimp;
+    const size_t np = (size_t)pl.npost;
+    ENSURE(h->theta, np * P * 8);
+    ENSURE(h->Weff, (size_t)h->N * h->N * 8);
+    ENSURE(h->ll, np * 8);
+    if (grad_out) ENSURE(h->grad, np * P * 8);
+    HIPCHK(hipMemcpyAsync(h->theta.p, theta, np * P * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->Weff.p, Weff, (size_t)h->N * h->N * 8, hipMemcpyHostToDevice, h->stream));
+    rc = enqueue_ll_grad(h, pl, n_lo, (const double*)h->theta.p, (const double*)h->Weff.p,
+                         (double*)h->ll.p, grad_out ? (double*)h->grad.p : nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ll_out, h->ll.p, np * 8, hipMemcpyDeviceToHost, h->stream));
+    if (grad_out)
+        HIPCHK(hipMemcpyAsync(grad_out, h->grad.p, np * P * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PGL_OK;
+}
+
+int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    if (!h->timing_valid) return fail(PGL_ERR_STATE, "no pgl_ll_grad call to time yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev[3]));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, h->ev[1], h->ev[2]));
+    HIPCHK(hipEventElapsedTime(&b, h->ev[0], h->ev[3]));
+    if (fused_ms) *fused_ms = a;
+    if (total_ms) *total_ms = b;
+    return PGL_OK;
+}
+
+int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
+{
+    if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
+    Plan pl;
+    int rc = make_plan(h, n_lo, n_hi, pl);
+    if (rc) return rc;
+    const double P = 1.0 + h->Dstim + h->Kimp;
+    double v[9];
+    v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
+    v[5] = 16;
+    v[6] = 4.0 * (double)h->nT * (double)h->Ktot * (double)pl.npost;
+    // nT*N*1 (u8 counts) + nT*Dstim*8 + params in + (ll+grad) out
+    v[7] = (double)h->nT * h->N + (double)h->nT * h->Dstim * 8.0 + 8.0 * pl.npost * P +
+           8.0 * pl.npost * (1.0 + P);
+    v[8] = (double)h->nnz;
+    for (int i = 0; i < n_info && i < 9; ++i) info[i] = v[i];
+    return PGL_OK;
+}
+
+int pgl_features(pgl_handle h, double* fS_out)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!fS_out) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->nT * h->Kimp * 8;
+    ENSURE(h->tmpA, bytes);
+    hipLaunchKernelGGL(k_features, dim3(h->nT16), dim3(256), (size_t)h->B * h->R * 8, h->stream,
+                       (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
+                       (const double*)h->phi.p, (double*)h->tmpA.p, (long long)h->nT, h->N, h->B, h->R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(fS_out, h->tmpA.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PGL_OK;
+}
+
+// I_impT (N,nT) on device for impulse weights d_w (N,B)
+static int enqueue_impulse_T(pgl_handle h, const double* d_w)
+{
+    ENSURE(h->IimpT, (size_t)h->N * h->nT * 8);
+    const int blocks = (int)((h->nT + 63) / 64);
+    const size_t lds = ((size_t)h->B * h->R + (size_t)h->N * h->B) * 8;
+    hipLaunchKernelGGL(k_impulse_T, dim3(blocks), dim3(256), lds, h->stream, (const int2*)h->spk.p,
+                       (const int*)h->wlo.p, (const int*)h->whi.p, (const double*)h->phi.p, d_w,
+                       (double*)h->IimpT.p, (long long)h->nT, h->nT16, h->N, h->B, h->R);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_impulse_currents(pgl_handle h, const double* w, double* I_imp_out)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!w || !I_imp_out) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    ENSURE(h->wsmall, (size_t)h->Kimp * 8);
+    HIPCHK(hipMemcpyAsync(h->wsmall.p, w, (size_t)h->Kimp * 8, hipMemcpyHostToDevice, h->stream));
+    rc = enqueue_impulse_T(h, (const double*)h->wsmall.p);
+    if (rc) return rc;
+    h->gibbs_npost = -1;
+    std::vector<double> T((size_t)h->N * h->nT);
+    HIPCHK(hipMemcpyAsync(T.data(), h->IimpT.p, T.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int n = 0; n < h->N; ++n)
+        for (int64_t t = 0; t < h->nT; ++t) I_imp_out[(size_t)t * h->N + n] = T[(size_t)n * h->nT + t];
+    return PGL_OK;
+}
+
+int pgl_gibbs_prepare(pgl_handle h, int n_post, const double* theta_n, const double* Weff_col)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!theta_n || !Weff_col) return fail(PGL_ERR_ARG, "null argument");
+    if (n_post < 0 || n_post >= h->N) return fail(PGL_ERR_ARG, "n_post out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t P = 1 + (size_t)h->Dstim + h->Kimp;
+    ENSURE(h->thetan, P * 8);
+    ENSURE(h->wcol, (size_t)h->N * 8);
+    ENSURE(h->Inet, (size_t)h->nT * 8);
+    ENSURE(h->Istim, (size_t)h->nT * 8);
+    HIPCHK(hipMemcpyAsync(h->thetan.p, theta_n, P * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->wcol.p, Weff_col, (size_t)h->N * 8, hipMemcpyHostToDevice, h->stream));
+    const double* d_th = (const double*)h->thetan.p;
+    rc = enqueue_impulse_T(h, d_th + 1 + h->Dstim);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_inet, dim3(1024), dim3(256), 0, h->stream, (const double*)h->IimpT.p,
+                       (const double*)h->wcol.p, (const double*)h->fstim.p, d_th + 1,
+                       (double*)h->Inet.p, (double*)h->Istim.p, (long long)h->nT, h->N, h->Dstim);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->gibbs_npost = n_post;
+    h->gibbs_bias = theta_n[0];
+    return PGL_OK;
+}
+
+static int run_ll_current(pgl_handle h, const double* d_base, const double* d_stim,
+                          const double* d_col, int n_post, double bias, double aw_cur,
+                          const double* w, int K, double* ll_out)
+{
+    const int nblocks = 1024;
+    ENSURE(h->part, (size_t)nblocks * PGL_KMAX * 8);
+    ENSURE(h->outK, PGL_KMAX * 8);
+    ENSURE(h->wsmall, std::max<size_t>((size_t)h->Kimp, PGL_KMAX) * 8);
+    const uint8_t* Sn = (const uint8_t*)h->ST.p + (size_t)n_post * h->nT;
+    for (int k0 = 0; k0 < K; k0 += PGL_KMAX) {
+        const int kk = std::min(PGL_KMAX, K - k0);
+        HIPCHK(hipMemcpyAsync(h->wsmall.p, w + k0, (size_t)kk * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_ll_current, dim3(nblocks), dim3(256), 0, h->stream, d_base, d_stim,
+                           d_col, Sn, bias, aw_cur, (const double*)h->wsmall.p, kk, h->nlin, h->dt,
+                           (long long)h->nT, (double*)h->part.p);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(64), 0, h->stream, (const double*)h->part.p,
+                           nblocks, kk, (double*)h->outK.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ll_out + k0, h->outK.p, (size_t)kk * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return PGL_OK;
+}
+
+int pgl_gibbs_ll(pgl_handle h, int n_pre, double aw_cur, const double* w, int K, double* ll_out)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->gibbs_npost < 0) return fail(PGL_ERR_STATE, "pgl_gibbs_prepare has not been called");
+    if (!w || !ll_out || K <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if (n_pre < 0 || n_pre >= h->N) return fail(PGL_ERR_ARG, "n_pre out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const double* col = (const double*)h->IimpT.p + (size_t)n_pre * h->nT;
+    return run_ll_current(h, (const double*)h->Inet.p, (const double*)h->Istim.p, col,
+                          h->gibbs_npost, h->gibbs_bias, aw_cur, w, K, ll_out);
+}
+
+int pgl_gibbs_update(pgl_handle h, int n_pre, double delta)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->gibbs_npost < 0) return fail(PGL_ERR_STATE, "pgl_gibbs_prepare has not been called");
+    if (n_pre < 0 || n_pre >= h->N) return fail(PGL_ERR_ARG, "n_pre out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const double* col = (const double*)h->IimpT.p + (size_t)n_pre * h->nT;
+    hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, h->stream, (double*)h->Inet.p, col, delta,
+                       (long long)h->nT);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_ll_from_current(pgl_handle h, int n_post, double I_bias, const double* I_stim,
+                        const double* I_other, const double* I_col, const double* w, int K,
+                        double* ll_out)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    if (!h->have_spikes) return fail(PGL_ERR_STATE, "pgl_set_spikes_* has not been called");
+    if (!I_other || !I_col || !w || !ll_out || K <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if (n_post < 0 || n_post >= h->N) return fail(PGL_ERR_ARG, "n_post out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->nT * 8;
+    ENSURE(h->tmpA, bytes);
+    ENSURE(h->tmpB, bytes);
+    HIPCHK(hipMemcpyAsync(h->tmpA.p, I_other, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tmpB.p, I_col, bytes, hipMemcpyHostToDevice, h->stream));
+    const double* d_stim = nullptr;
+    if (I_stim) {
+        ENSURE(h->tmpC, bytes);
+        HIPCHK(hipMemcpyAsync(h->tmpC.p, I_stim, bytes, hipMemcpyHostToDevice, h->stream));
+        d_stim = (const double*)h->tmpC.p;
+    }
+    return run_ll_current(h, (const double*)h->tmpA.p, d_stim, (const double*)h->tmpB.p, n_post,
+                          I_bias, 0.0, w, K, ll_out);
+}
+
+int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col, double* lam_out,
+              double* I_net_out, double* I_stim_out)
+{
+    int rc = pgl_gibbs_prepare(h, n, theta_n, Weff_col);
+    if (rc) return rc;
+    const size_t bytes = (size_t)h->nT * 8;
+    if (lam_out) {
+        ENSURE(h->lam, bytes);
+        hipLaunchKernelGGL(k_lam, dim3(1024), dim3(256), 0, h->stream, (const double*)h->Inet.p,
+                           (const double*)h->Istim.p, theta_n[0], h->nlin, (double*)h->lam.p,
+                           (long long)h->nT);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(lam_out, h->lam.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (I_net_out) HIPCHK(hipMemcpyAsync(I_net_out, h->Inet.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (I_stim_out) HIPCHK(hipMemcpyAsync(I_stim_out, h->Istim.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PGL_OK;
+}
+
+}  // extern "C"
