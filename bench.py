@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""
+bench.py -- population GLM ll+grad evals/s on MI355X (BASELINE.json metric).
+
+One "step" = one population log-likelihood + gradient evaluation: for every
+post-synaptic neuron n, ll_n and d ll_n / d theta_n (theta_n = bias + N*B impulse
+weights) on a spike matrix already resident in HBM.  Workload at
+every GPU count: standard_glm, N=128 neurons, T=600 s at 1 ms bins (C3, the
+configuration the north-star target is quoted on), synthetic Poisson spikes.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: the post-synaptic neurons are block-partitioned over the ranks (the reference's own
+parallel pattern, parallel_coord_descent.py:137-147); S is replicated; each step ends with an
+RCCL all-gather of the per-neuron ll (1 KB) so every rank holds the population ll.  Total work
+is fixed -> "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (BASELINE.md §4 / SURVEY.md §8d)
+
+
+def make_workload(N, T, dt, seed):
+    """C2-C5 synthetic inputs: S ~ Poisson(20 Hz * dt) clipped to 10, uint8;
+    bias ~ N(20, 0.1) (standard_glm.py:16-21); w_ir ~ N(0, 0.5)."""
+    rng = np.random.default_rng(seed)
+    nT = int(round(T / dt))
+    S = np.minimum(rng.poisson(20.0 * dt, size=(nT, N)), 10).astype(np.uint8)
+    return S
+
+
+def standard_ibasis(R=200):
+    """standard_glm impulse basis: the committed 100-point orthonormal cosine basis
+    (tests/golden, produced by the reference's create_basis) interpolated to R taps
+    (impulse.py:92-103)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'basis_golden.npz'))
+    basis = g['std_imp_basis']
+    L, B = basis.shape
+    ib = np.zeros((R, B))
+    for b in range(B):
+        ib[:, b] = np.interp(np.linspace(0, 1, R), np.linspace(0, 1, L), basis[:, b])
+    return ib
+
+
+def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
+    """Oracle C port (oracle/glm_oracle.c: the reference's per-neuron dataflow on
+    materialised features) timed single-threaded on a bounded sample: the first
+    `sample_bins` bins of the same spike matrix, all neurons; cost is linear in nT."""
+    from oracle import c_oracle as CO
+    nT, N = S.shape
+    Ss = np.ascontiguousarray(S[:sample_bins])
+    fS = CO.features(Ss, ibasis)
+    n_sub = min(N, 16)                      # single-thread leg: 16 neurons, scaled to N
+    t0 = time.time()
+    CO.ll_grad(Ss, fS, theta[:n_sub], Weff, 'explinear', dt, 0, n_sub, threads=1)
+    t1 = time.time() - t0
+    per_eval_1 = t1 * (N / float(n_sub)) * (nT / float(sample_bins))
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    CO.ll_grad(Ss, fS, theta, Weff, 'explinear', dt, threads=cores)
+    tm = time.time() - t0
+    per_eval_m = tm * (nT / float(sample_bins))
+    return {
+        "value": 1.0 / per_eval_1, "unit": "evals/s", "cores": 1, "kind": "port",
+        "sample": "first %d of %d bins, %d of %d neurons, scaled linearly; C restatement of the "
+                  "reference per-neuron dataflow on materialised fS (oracle/glm_oracle.c)"
+                  % (sample_bins, nT, n_sub, N),
+        "all_cores": {"value": 1.0 / per_eval_m, "cores": cores,
+                      "sample": "first %d bins, all neurons, OpenMP over neurons" % sample_bins},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--neurons', type=int, default=128)
+    ap.add_argument('--seconds', type=float, default=600.0)
+    ap.add_argument('--f32-features', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n"
+                             % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_hip()
+    if world > 1:
+        dist.barrier()
+    from theano_pyglm_amd import _lib
+
+    N, dt = args.neurons, 0.001
+    S = make_workload(N, args.seconds, dt, seed=1234 + 3)
+    nT = S.shape[0]
+    ib = standard_ibasis()
+    R, B = ib.shape
+    P = 1 + N * B
+    rng = np.random.default_rng(99)
+    theta = np.zeros((N, P))
+    theta[:, 0] = 20.0 + 0.1 * rng.standard_normal(N)
+    theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
+    Weff = np.ones((N, N))
+
+    # neuron shard of this rank
+    n_lo = (N * rank) // world
+    n_hi = (N * (rank + 1)) // world
+    dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt, device=local_rank)
+    dev.set_spikes(S)
+    dev.set_basis(ib)
+    if args.f32_features:
+        dev.set_option(_lib.OPT_FEATURE_F32, 1)
+
+    d_theta = torch.from_numpy(theta[n_lo:n_hi].copy()).cuda()
+    d_Weff = torch.from_numpy(Weff).cuda()
+    d_ll = torch.zeros(n_hi - n_lo, dtype=torch.float64, device='cuda')
+    d_grad = torch.zeros((n_hi - n_lo, P), dtype=torch.float64, device='cuda')
+    if world > 1:
+        sizes = [(N * (r + 1)) // world - (N * r) // world for r in range(world)]
+        gather = [torch.zeros(s, dtype=torch.float64, device='cuda') for s in sizes]
+    torch.cuda.synchronize()
+
+    fused_ms = []
+
+    def step(record):
+        dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr(),
+                        n_lo, n_hi)
+        dev.sync()
+        if record:
+            fused_ms.append(dev.last_timing()[0])
+        if world > 1:
+            dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB over xGMI)
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = dev.info(n_lo, n_hi)
+    kern_ms = float(np.mean(fused_ms))
+    achieved = info['flops'] / (kern_ms * 1e-3) / 1e12
+    ll_host = d_ll.cpu().numpy()
+    assert np.all(np.isfinite(ll_host)), "non-finite ll"
+
+    if rank == 0:
+        out = {
+            "metric": "population ll+grad evals/sec (N neurons x T bins)",
+            "value": args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "standard_glm N=%d T=%gs dt=1ms (nT=%d), B=%d R=%d, explinear, "
+                            "Poisson 20 Hz spikes, ll+grad of all N neurons per step"
+                            % (N, args.seconds, nT, B, R),
+                "sharding": "post-synaptic neurons block-partitioned over %d rank(s); S replicated; "
+                            "all-gather of ll per step" % world,
+                "feature_staging": "f32" if args.f32_features else "f64",
+                "spike_events": int(info['events']),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "k_fused_ll_grad (rank 0 shard: %d neurons)" % (n_hi - n_lo),
+                "achieved": achieved,
+                "peak": F64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / F64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "kernel_ms": kern_ms,
+                "algorithmic_flops_per_launch": info['flops'],
+                "algorithmic_bytes_per_launch": info['bytes'],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 30000))
+        print(json.dumps(out))
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

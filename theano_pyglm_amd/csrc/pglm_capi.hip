@@ -43,7 +43,7 @@ struct pgl_context {
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
-    int opt_f32 = 0, opt_nchunks = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0;
     bool timing_valid = false;
 };
 
@@ -71,7 +71,7 @@ static void release(DevBuf& b)
     } while (0)
 
 struct Plan {
-    int npost, nPT, wpb, nPB, KT, KS, rsf, nTiles, nChunks, tilesPerChunk, blocks, threads;
+    int npost, nPT, wpb, nPB, KT, KS, rsf, RP, nTiles, nChunks, tilesPerChunk, blocks, threads;
     size_t lds;
     bool f32;
 };
@@ -107,7 +107,9 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.blocks = pl.nChunks * pl.nPB;
     pl.threads = 64 * pl.wpb;
     size_t off = ((size_t)16 * pl.rsf * (pl.f32 ? 4 : 8) + 15) & ~(size_t)15;
-    off += (((size_t)h->B * h->R * 8) + 15) & ~(size_t)15;
+    pl.RP = h->R + 32;
+    while (pl.RP % 32 != 6) ++pl.RP;      // bank spread of the per-basis rows for ds_read_b128
+    off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;
     off += (size_t)h->N * PGL_CAP * 8;
     off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
     off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
@@ -204,6 +206,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     if (!h) return fail(PGL_ERR_ARG, "null handle");
     switch (option) {
     case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
+    case 99: h->opt_dbg = value; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -358,8 +361,10 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
     fp.n_lo = n_lo; fp.npost = pl.npost; fp.nPT = pl.nPT;
     fp.nT16 = h->nT16; fp.tilesPerChunk = pl.tilesPerChunk; fp.nChunks = pl.nChunks; fp.nTiles = pl.nTiles;
     fp.rsf = pl.rsf;
+    fp.RP = pl.RP;
     fp.Gpart = (double*)h->Gpart.p; fp.llpart = (double*)h->llpart.p; fp.gbpart = (double*)h->gbpart.p;
     fp.want_grad = d_grad ? 1 : 0;
+    fp.dbg = h->opt_dbg;
 
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
     hipError_t e = pl.f32 ? launch_fused_kt<float>(pl, fp, h->stream)

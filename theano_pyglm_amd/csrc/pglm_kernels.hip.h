@@ -43,10 +43,12 @@ struct FusedParams {
     int n_lo, npost, nPT;
     int nT16, tilesPerChunk, nChunks, nTiles;
     int rsf;                             // F row stride in elements
+    int RP;                              // padded basis-table length (>= R+32, RP % 32 == 6)
     double* __restrict__ Gpart;          // [nChunks][nPT][KT][4][64]
     double* __restrict__ llpart;         // [nChunks][nPT][64]
     double* __restrict__ gbpart;         // [nChunks][nPT][64]
     int want_grad;
+    int dbg;                             // timing ablation bits (results invalid when != 0)
 };
 
 __device__ __forceinline__ double pgl_softplus_parts(double x, double& sig, double& loglam)
@@ -61,51 +63,64 @@ __device__ __forceinline__ double pgl_softplus_parts(double x, double& sig, doub
 }
 
 // ---------------------------------------------------------------------------
-// Feature generation for one time tile: F[t][n'*B+b] for t in [t0,t0+TT)
+// Feature generation for one 16-row time tile: F[t][n'*B+b], t in [t0,t0+16).
+// One thread owns a feature column (n',b) and keeps its 16 rows in registers; every
+// event (s,c) of n' in the tile's window adds c*phi_b[t0+t-s-1] to row t.  The basis
+// table is zero-padded by 16 taps on both sides, so no per-row validity test is
+// needed (the window table only admits events with s in [t0-R, t0+14]); an even- and
+// an odd-shifted copy keep every 16-tap slice 16-byte aligned for ds_read_b128.
 // ---------------------------------------------------------------------------
-template <int BB, int TT, typename FT>
-__device__ __forceinline__ void gen_pairs(FT* __restrict__ Fs, const int rsf,
-                                          const double* __restrict__ phiS,
-                                          const int2* __restrict__ s_spk,
-                                          const int* __restrict__ s_lo,
-                                          const int* __restrict__ s_cnt,
-                                          const int2* __restrict__ spk, const int t0,
-                                          const int N, const int B, const int R,
-                                          const int tid, const int nthr)
+__device__ __forceinline__ void gen_accum16(double (&acc)[16], const int2 e, const int t0,
+                                            const double* __restrict__ phiE,
+                                            const double* __restrict__ phiO, const int boff)
 {
-    const int npairs = TT * N;
-    for (int id = tid; id < npairs; id += nthr) {
-        const int t = id & (TT - 1);
-        const int np = id / TT;
+    const int base = t0 - e.x - 1 + 16;               // padded index of row 0's lag, >= 1
+    const double c = (double)e.y;
+    const double* tab = (base & 1) ? (phiO + boff + base - 1) : (phiE + boff + base);
+    const double2* t2 = reinterpret_cast<const double2*>(tab);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double2 v = t2[q];
+        acc[2 * q] = fma(c, v.x, acc[2 * q]);
+        acc[2 * q + 1] = fma(c, v.y, acc[2 * q + 1]);
+    }
+}
+
+template <typename FT>
+__device__ __forceinline__ void gen_cols(FT* __restrict__ Fs, const int rsf,
+                                         const double* __restrict__ phiE,
+                                         const double* __restrict__ phiO, const int RP,
+                                         const int2* __restrict__ s_spk,
+                                         const int* __restrict__ s_lo,
+                                         const int* __restrict__ s_cnt,
+                                         const int2* __restrict__ spk, const int t0, const int B,
+                                         const int Kimp, const int tid, const int nthr)
+{
+    for (int col = tid; col < Kimp; col += nthr) {
+        const int np = col / B;
+        const int b = col - np * B;
         const int cnt = s_cnt[np];
-        const int tg = t0 + t;
-        const int2* sp = (cnt <= PGL_CAP) ? (s_spk + np * PGL_CAP) : (spk + s_lo[np]);
-        if (BB > 0) {
-            double acc[BB > 0 ? BB : 1];
+        const int boff = b * RP;
+        double acc[16];
 #pragma unroll
-            for (int b = 0; b < BB; ++b) acc[b] = 0.0;
-            for (int j = 0; j < cnt; ++j) {
-                const int2 e = sp[j];
-                const int d = tg - e.x - 1;
-                if (d >= 0 && d < R) {
-                    const double c = (double)e.y;
-#pragma unroll
-                    for (int b = 0; b < BB; ++b) acc[b] = fma(c, phiS[b * R + d], acc[b]);
-                }
+        for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+        // two events per trip (the second is a zero-weight dummy when cnt is odd) so that
+        // 16 independent ds_read_b128 are in flight before the FMAs
+        const int2 dummy = make_int2(t0, 0);
+        if (cnt <= PGL_CAP) {
+            const int2* sp = s_spk + np * PGL_CAP;
+            for (int j = 0; j < cnt; j += 2) {
+                const int2 e0 = sp[j];
+                const int2 e1 = (j + 1 < cnt) ? sp[j + 1] : dummy;
+                gen_accum16(acc, e0, t0, phiE, phiO, boff);
+                gen_accum16(acc, e1, t0, phiE, phiO, boff);
             }
-#pragma unroll
-            for (int b = 0; b < BB; ++b) Fs[t * rsf + np * BB + b] = (FT)acc[b];
         } else {
-            for (int b = 0; b < B; ++b) {
-                double a = 0.0;
-                for (int j = 0; j < cnt; ++j) {
-                    const int2 e = sp[j];
-                    const int d = tg - e.x - 1;
-                    if (d >= 0 && d < R) a = fma((double)e.y, phiS[b * R + d], a);
-                }
-                Fs[t * rsf + np * B + b] = (FT)a;
-            }
+            const int2* sp = spk + s_lo[np];
+            for (int j = 0; j < cnt; ++j) gen_accum16(acc, sp[j], t0, phiE, phiO, boff);
         }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Fs[t * rsf + col] = (FT)acc[t];
     }
 }
 
@@ -134,8 +149,10 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
     // LDS carve (all offsets multiples of 16)
     FT* Fs = reinterpret_cast<FT*>(smem);
     size_t off = ((size_t)TT * rsf * sizeof(FT) + 15) & ~(size_t)15;
-    double* phiS = reinterpret_cast<double*>(smem + off);
-    off += (((size_t)B * R * 8) + 15) & ~(size_t)15;
+    const int RP = p.RP;
+    double* phiE = reinterpret_cast<double*>(smem + off);
+    double* phiO = phiE + (size_t)B * RP;
+    off += (((size_t)2 * B * RP * 8) + 15) & ~(size_t)15;
     int2* s_spk = reinterpret_cast<int2*>(smem + off);
     off += (size_t)N * PGL_CAP * 8;
     int* s_lo = reinterpret_cast<int*>(smem + off);
@@ -143,7 +160,11 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
     int* s_cnt = reinterpret_cast<int*>(smem + off);
 
     // one-time: basis table, zero the F tile (padding columns stay zero forever)
-    for (int i = tid; i < B * R; i += nthr) phiS[i] = p.phi[i];
+    for (int i = tid; i < B * RP; i += nthr) {
+        const int b = i / RP, k = i - b * RP;
+        phiE[i] = (k >= 16 && k < 16 + R) ? p.phi[b * R + k - 16] : 0.0;
+        phiO[i] = (k + 1 >= 16 && k + 1 < 16 + R) ? p.phi[b * R + k + 1 - 16] : 0.0;
+    }
     for (int i = tid; i < TT * rsf; i += nthr) Fs[i] = (FT)0;
 
     d4_t G[KT];
@@ -169,13 +190,14 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         const int t0 = tile * TT;
         // ---- phase A: event window of every presynaptic neuron, staged to LDS ----
-        if (tid < N) {
+        if (tid < N && !(p.dbg & 32)) {
             const int lo = p.wlo[(size_t)tile * N + tid];
             const int hi = p.whi[(size_t)tile * N + tid];
             s_lo[tid] = lo;
             s_cnt[tid] = hi - lo;
         }
         __syncthreads();
+        if (!(p.dbg & 2))
         for (int id = tid; id < N * PGL_CAP; id += nthr) {
             const int np = id / PGL_CAP;
             const int sl = id % PGL_CAP;
@@ -193,12 +215,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
         }
         __syncthreads();
         // ---- phase B: F tile from events ----
-        if (B == 5)
-            gen_pairs<5, TT, FT>(Fs, rsf, phiS, s_spk, s_lo, s_cnt, p.spk, t0, N, B, R, tid, nthr);
-        else if (B == 3)
-            gen_pairs<3, TT, FT>(Fs, rsf, phiS, s_spk, s_lo, s_cnt, p.spk, t0, N, B, R, tid, nthr);
-        else
-            gen_pairs<0, TT, FT>(Fs, rsf, phiS, s_spk, s_lo, s_cnt, p.spk, t0, N, B, R, tid, nthr);
+        if (!(p.dbg & 1))
+            gen_cols<FT>(Fs, rsf, phiE, phiO, RP, s_spk, s_lo, s_cnt, p.spk, t0, B, p.Kimp, tid, nthr);
         __syncthreads();
 
         if (active) {
@@ -209,7 +227,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
             for (int r = 0; r < 4; ++r) {
                 const long long tg = (long long)t0 + grp + 4 * r;
                 vt[r] = valid_n && (tg < p.nT);
-                sc[r] = vt[r] ? (double)p.S[tg * N + nglob] : 0.0;
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);      // clamped: branch-free load
+                sc[r] = (double)p.S[tc * N + nglob];
             }
             // ---- forward: X(16x16) = F(16xK) . Wmat(Kx16) ----
             // Flat list of KS MFMAs.  The Wmat fragments (L2 -> VGPR) are fetched PW steps
@@ -232,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
                 for (int s = 0; s < PW; ++s) wr[s] = wr_s[s * 64 + lane];
 #pragma unroll
                 for (int s = 0; s < PA; ++s) ar[s] = (double)fa[4 * s];
+                if (!(p.dbg & 8))
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const double a = ar[s % PA];
@@ -251,7 +271,10 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
             for (int r = 0; r < 4; ++r) {
                 const double x = acc0[r] + acc1[r] + bias_l;
                 double term, res;
-                if (p.nlin == 1) {
+                if (p.dbg & 4) {
+                    term = x * sc[r];
+                    res = x - sc[r];
+                } else if (p.nlin == 1) {
                     double sig, loglam;
                     const double lam = pgl_softplus_parts(x, sig, loglam);
                     term = -p.dt * lam + loglam * sc[r];
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
             // ---- backward: G(Kx16) += F^T(Kx16) . r(16x16);  B operand of k-step j is rr[j] ----
             // Flat list of 4*KT MFMAs (step s: time k-step j = s / KT, feature tile kt = s % KT),
             // F^T fragments fetched from LDS PD steps ahead.
-            if (p.want_grad) {
+            if (p.want_grad && !(p.dbg & 16)) {
                 const FT* fb = Fs + grp * rsf + col;  // A[i=k=lane&15][kk=lane>>4] = F[4j+kk][16kt+i]
                 constexpr int PD = 4;
                 constexpr int NS = 4 * KT;
