@@ -60,7 +60,7 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     nT, N = S.shape
     Ss = np.ascontiguousarray(S[:sample_bins])
     fS = CO.features(Ss, ibasis)
-    n_sub = min(N, 16)                      # single-thread leg: 16 neurons, scaled to N
+    n_sub = N                               # single-thread leg: every neuron
     t0 = time.time()
     CO.ll_grad(Ss, fS, theta[:n_sub], Weff, 'explinear', dt, 0, n_sub, threads=1)
     t1 = time.time() - t0
@@ -214,7 +214,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 30000))
+            out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         print(json.dumps(out))
     dev.close()
     if world > 1:
