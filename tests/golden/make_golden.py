@@ -87,6 +87,12 @@ def main():
     out['shift_fstim'] = rb.convolve_with_basis(st, one)
 
     np.savez_compressed(os.path.join(here, 'basis_golden.npz'), **out)
+
+    # --- the three template dicts (hyper-parameters only: data, not code) -------------
+    import json
+    with open(os.path.join(here, 'templates_golden.json'), 'w') as f:
+        json.dump({'standard_glm': StandardGlm, 'sparse_weighted_model': SparseWeightedModel,
+                   'spatiotemporal_glm': SpatiotemporalGlm}, f, indent=1, sort_keys=True)
     for k, v in out.items():
         print(k, v.shape)
 

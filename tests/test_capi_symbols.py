@@ -1,0 +1,54 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol that
+include/pyglm_hip.h declares, and fails loudly (no CPU fallback) when asked to compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'pyglm_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(pgl_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported():
+    import __graft_entry__ as ge
+    ge.build_hip()
+    from theano_pyglm_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libpyglm_hip.so does not export %s" % n
+    assert sorted(_lib.SYMBOLS) == names
+    _lib.load()
+    assert _lib.load().pgl_version() >= 100
+
+
+def test_no_cpu_fallback():
+    from theano_pyglm_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.PglError, match="device"):
+        _lib.DeviceGlm(4, 100, 5, 200, 'explinear', 0.001)
+    from theano_pyglm_amd.models.model_factory import make_model
+    from theano_pyglm_amd.population import Population
+    p = Population(make_model('standard_glm', N=2, dt=0.001))
+    with pytest.raises(_lib.PglError):
+        p.add_data({'S': np.zeros((50, 2)), 'N': 2, 'dt': 0.001, 'T': 0.05})
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through oracle/ (checker only)."""
+    pkg = os.path.join(ROOT, 'theano_pyglm_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), os.path.join(dp, f)
+                assert '/root/reference' not in txt

@@ -1,0 +1,170 @@
+"""CPU tests of the host-side mirror (no compute on the device)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import glm_oracle as O
+from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity, check_stability
+from theano_pyglm_amd.models import templates as T
+from theano_pyglm_amd.population import Population
+from theano_pyglm_amd.utils import basis as B
+from theano_pyglm_amd.utils import packvec as PV
+from theano_pyglm_amd.utils.syms import flatten
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_templates_equal_reference():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'templates_golden.json')) as f:
+        g = json.load(f)
+    assert T.standard_glm() == g['standard_glm']
+    assert T.sparse_weighted_model() == g['sparse_weighted_model']
+    assert T.spatiotemporal_glm() == g['spatiotemporal_glm']
+
+
+def test_make_model_and_sparsity():
+    m = make_model('standard_glm', N=7, dt=0.001)
+    assert m['N'] == 7 and m['dt'] == 0.001 and T.standard_glm()['N'] == 2
+    with pytest.raises(Exception):
+        make_model('no_such_model')
+    s = make_model('sparse_weighted_model', N=128, dt=0.001)
+    stabilize_sparsity(s)
+    assert abs(s['network']['graph']['rho'] - min(1.0, (0.7 + 0.2) ** 2 / 128.0)) < 1e-15   # model_factory.py:87-102
+    assert make_model('network_glm', N=3)['impulse']['type'] == 'dirichlet'
+    with pytest.raises(KeyError):
+        Population(make_model('standard_glm', N=2))          # no dt -> glm.py:16 KeyError
+
+
+def test_basis_module_matches_golden(golden):
+    std = T.standard_glm()['impulse']['basis']
+    assert np.allclose(B.create_basis(std), golden['std_imp_basis'], atol=1e-13)
+    assert np.allclose(B.create_basis(T.sparse_weighted_model()['impulse']['basis']), golden['swm_imp_basis'], atol=1e-13)
+    assert np.allclose(B.convolve_with_basis(golden['conv_S'], golden['conv_ibasis']), golden['conv_fS'], atol=1e-12)
+    assert np.allclose(B.convolve_with_low_rank_2d_basis(golden['lr2d_stim'], golden['lr2d_ibasis_x'],
+                                                         golden['lr2d_ibasis_t']), golden['lr2d_fstim'], atol=1e-12)
+    f = np.sin(np.linspace(0, 3, 200))
+    beta = B.project_onto_basis(f, golden['conv_ibasis'])
+    assert beta.shape == (5, 1)
+    assert np.allclose(golden['conv_ibasis'].T.dot(golden['conv_ibasis'].dot(beta)[:, 0] - f), 0, atol=1e-9)
+
+
+def test_component_bases_match_oracle(golden):
+    p = Population(make_model('standard_glm', N=3, dt=0.001))
+    assert np.allclose(p.glm.imp_model.ibasis, O.linear_impulse_ibasis(golden['std_imp_basis'], 0.001, 0.2, False))
+    q = Population(make_model('sparse_weighted_model', N=3, dt=0.001))
+    assert np.allclose(q.glm.imp_model.ibasis, O.dirichlet_impulse_ibasis(golden['swm_imp_basis'], 0.001, 0.2, True))
+    r = Population(make_model('spatiotemporal_glm', N=3, dt=0.001))
+    assert np.allclose(r.glm.imp_model.ibasis, O.linear_impulse_ibasis(golden['st_imp_basis'], 0.001, 0.3, True))
+    assert np.allclose(r.glm.bkgd_model.ibasis_t, O.stim_temporal_ibasis(golden['st_temporal_basis'], 0.001, 0.3, True))
+    assert np.allclose(r.glm.bkgd_model.ibasis_x, np.eye(3))
+
+
+def test_state_dict_schema_and_packing():
+    """population.py:149-162 / SURVEY Appendix A; packed layout SURVEY §8a A7."""
+    rng = np.random.RandomState(0)
+    p = Population(make_model('standard_glm', N=4, dt=0.001))
+    x = p.sample(rng)
+    assert sorted(x.keys()) == ['glms', 'latent', 'net'] and x['net'] == {'graph': {}, 'weights': {}}
+    assert [g['n'] for g in x['glms']] == [0, 1, 2, 3]
+    assert x['glms'][0]['imp']['w_ir'].shape == (20,) and x['glms'][0]['bias']['bias'].shape == (1,)
+    syms = p.glm_syms()
+    v, shapes = PV.packdict(PV.get_vars(syms, x['glms'][1]))
+    assert v.size == 21 and v[0] == x['glms'][1]['bias']['bias'][0]
+    assert np.array_equal(v[1:], x['glms'][1]['imp']['w_ir'])
+    back = PV.unpackdict(v, shapes)
+    assert np.array_equal(back['imp']['w_ir'], x['glms'][1]['imp']['w_ir'])
+    assert [s.name for s in flatten(syms)] == ['bias', 'w_ir']
+    nv = p.extract_vars(x, 2)
+    assert sorted(nv.keys()) == ['glm', 'latent', 'net'] and nv['glm']['n'] == 2
+    # missing key -> the seval binding error (theano_func_wrapper.py:92-93)
+    bad = p.sample(rng)
+    del bad['glms'][0]['imp']['w_ir']
+    with pytest.raises(Exception, match="not found"):
+        p.compute_log_prior(bad)
+    # sparse model: A int8, W flat, Dirichlet g_n
+    q = Population(stabilize_sparsity(make_model('sparse_weighted_model', N=3, dt=0.001)))
+    y = q.sample(rng)
+    assert y['net']['graph']['A'].dtype == np.int8 and y['net']['weights']['W'].shape == (9,)
+    assert sorted(y['glms'][0]['imp'].keys()) == ['g_0', 'g_1', 'g_2']
+    assert check_stability(q.model, y, 3) in (True, False)
+    st = Population(make_model('spatiotemporal_glm', N=2, dt=0.001))
+    z = st.sample(rng)
+    v, _ = PV.packdict(PV.get_vars(st.glm_syms(), z['glms'][0]))
+    assert v.size == 1 + 3 + 3 + 6
+    assert np.array_equal(v[1:4], z['glms'][0]['bkgd']['w_t']) and np.array_equal(v[4:7], z['glms'][0]['bkgd']['w_x'])
+
+
+def test_log_prior_matches_oracle():
+    rng = np.random.RandomState(1)
+    p = Population(make_model('standard_glm', N=3, dt=0.001))
+    x = p.sample(rng)
+    ref = sum(O.bias_log_p(g['bias']['bias'][0], 20, 0.1) +
+              O.group_lasso_log_p(g['imp']['w_ir'].reshape(3, 5), 1.0, 0.0, 10.0) for g in x['glms'])
+    assert np.isclose(p.compute_log_prior(x), ref)
+    q = Population(stabilize_sparsity(make_model('sparse_weighted_model', N=3, dt=0.001)))
+    y = q.sample(rng)
+    W = y['net']['weights']['W'].reshape(3, 3)
+    ref = O.erdos_renyi_log_p(y['net']['graph']['A'].astype(float), q.network.graph.rho) + \
+        O.gaussian_weight_log_p(W, 0.0, 1.0, -0.2, 0.5)
+    for g in y['glms']:
+        ref += O.bias_log_p(g['bias']['bias'][0], 20.0, 0.25) + \
+            O.dirichlet_log_p([g['imp']['g_%d' % k] for k in range(3)], 1)
+    assert np.isclose(q.compute_log_prior(y), ref)
+
+
+def test_flat_weights_and_chain_rules():
+    rng = np.random.RandomState(2)
+    q = Population(stabilize_sparsity(make_model('sparse_weighted_model', N=3, dt=0.001)))
+    y = q.sample(rng)
+    xn = y['glms'][1]
+    xn['imp']['g_1'] = xn['imp']['g_1'] * np.array([1, -1, 1, 1, -1])
+    th = q.glm.theta_row(xn)
+    assert th.size == 16 and np.allclose(th[1:].reshape(3, 5).sum(1), 1.0)
+    gth = rng.randn(16)
+    gd = q.glm.chain_grad(xn, gth)
+    for k in range(3):
+        assert np.allclose(gd['imp']['g_%d' % k], O.dirichlet_chain(gth[1 + 5 * k:6 + 5 * k], xn['imp']['g_%d' % k]))
+    st = Population(make_model('spatiotemporal_glm', N=2, dt=0.001))
+    z = st.sample(rng)['glms'][0]
+    th = st.glm.theta_row(z)
+    assert np.allclose(th[1:10], O.spatiotemporal_w_stim(z['bkgd']['w_t'], z['bkgd']['w_x']))
+    gth = rng.randn(th.size)
+    gd = st.glm.chain_grad(z, gth)
+    gt, gx = O.spatiotemporal_chain(gth[1:10], z['bkgd']['w_t'], z['bkgd']['w_x'])
+    assert np.allclose(gd['bkgd']['w_t'], gt) and np.allclose(gd['bkgd']['w_x'], gx)
+    # W_eff orientation [n_pre, n_post] = A*W (glm.py:31-37)
+    assert np.allclose(q.W_eff(y), y['net']['graph']['A'] * y['net']['weights']['W'].reshape(3, 3))
+
+
+def test_stimulus_preprocessing_matches_oracle():
+    rng = np.random.RandomState(3)
+    st = Population(make_model('spatiotemporal_glm', N=2, dt=0.001))
+    stim = rng.randn(20, 3)
+    data = {'S': np.zeros((2000, 2)), 'stim': stim, 'dt_stim': 0.1, 'T': 2.0, 'dt': 0.001, 'N': 2}
+    st.preprocess_data(data)
+    ref = O.spatiotemporal_stim_features(stim, 0.1, 0.001, 2000, st.glm.bkgd_model.ibasis_x,
+                                         st.glm.bkgd_model.ibasis_t)
+    assert data['fstim'].shape == (2000, 9) and np.allclose(data['fstim'], ref, atol=1e-12)
+    m = make_model('standard_glm', N=2, dt=0.001)
+    m['bkgd']['type'] = 'basis'
+    bs = Population(m)
+    d2 = {'S': np.zeros((2000, 2)), 'stim': stim[:, :1], 'dt_stim': 0.1, 'T': 2.0, 'dt': 0.001, 'N': 2}
+    bs.preprocess_data(d2)
+    ref = O.basis_stim_features(stim[:, :1], 0.1, 0.001, 2000, bs.glm.bkgd_model.ibasis)
+    assert np.allclose(d2['fstim'], ref, atol=1e-12)
+
+
+def test_simulate_consistency_host():
+    """Population.simulate reproduces the superposition the oracle restates
+    (population.py:351-353): X equals direct_currents of the spikes it emitted."""
+    rng = np.random.RandomState(4)
+    p = Population(make_model('standard_glm', N=3, dt=0.001))
+    x = p.sample(rng)
+    S, X = p.simulate(x, (0, 1.5), 0.001, None, 0.1, rng=rng)
+    assert S.shape == (1500, 3) and S.max() <= 10
+    for n in range(3):
+        imps = p.glm.imp_model.impulse(x['glms'][n]['imp'])
+        xd = O.direct_currents(S, imps, np.ones(3), x['glms'][n]['bias']['bias'][0])
+        assert np.allclose(X[:, n], xd)

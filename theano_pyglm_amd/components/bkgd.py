@@ -1,0 +1,174 @@
+"""
+Stimulus (background) models -- counterpart of pyglm/components/bkgd.py:29-345.
+
+Each model turns the raw stimulus into dense feature columns `data['fstim']` once per
+data set (host side), exposes the flat feature weights the device kernel multiplies
+them with, and maps the device's flat-weight gradient back onto its own variables.
+"""
+import numpy as np
+
+from theano_pyglm_amd.components.component import Component
+from theano_pyglm_amd.components.priors import _rng
+from theano_pyglm_amd.utils import basis as bs
+
+
+def create_bkgd_component(model, glm, latent):
+    typ = model['bkgd']['type'].lower()
+    if typ in ('no_stimulus', 'none', 'nostimulus'):
+        return NoStimulus(model)
+    if typ == 'basis':
+        return BasisStimulus(model)
+    if typ == 'spatiotemporal':
+        return SpatiotemporalStimulus(model)
+    raise Exception("Unrecognized backgound model: %s" % typ)
+
+
+class NoStimulus(Component):
+    """bkgd.py:29-43: I_stim = 0."""
+    n_features = 0
+
+    def __init__(self, model):
+        pass
+
+    def flat_weights(self, vars):
+        return np.zeros((0,))
+
+    def chain_grad(self, vars, g_flat):
+        return {}
+
+    def preprocess_data(self, data):
+        data['fstim'] = None
+
+
+def _interp_stim(stim, dt_stim, t):
+    t_stim = dt_stim * np.arange(stim.shape[0])
+    return bs.interpolate_columns(stim, t, t_stim)
+
+
+class BasisStimulus(Component):
+    """bkgd.py:45-169: I_stim = fstim . w_stim, fstim[:, d*B+b] = causal conv of stimulus
+    dimension d with temporal basis b; prior -0.5/0.01^2 sum w^2 (sigma hard-coded, :76)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.bkgd_model = model['bkgd']
+        self.basis = bs.create_basis(self.bkgd_model['basis'])
+        R = bs.n_taps(self.bkgd_model['dt_max'], model['dt'])
+        ib = bs.interpolate_columns(self.basis, np.linspace(0, 1, R),
+                                    np.linspace(0, 1, self.basis.shape[0]))
+        if self.bkgd_model['basis']['norm']:
+            ib = ib / ib.sum(axis=0, keepdims=True)            # bkgd.py:115-116
+        self.ibasis = ib
+        self.B = ib.shape[1]
+        self.n_vars = self.B * self.bkgd_model['D_stim']
+        self.n_features = self.n_vars
+
+    def get_variables(self):
+        return {'w_stim': (self.n_vars,)}
+
+    def flat_weights(self, vars):
+        return np.asarray(vars['w_stim'], dtype=float).reshape(-1)
+
+    def chain_grad(self, vars, g_flat):
+        return {'w_stim': np.array(g_flat, dtype=float)}
+
+    def log_p(self, vars):
+        return np.sum(-0.5 / (0.01 ** 2) * (self.flat_weights(vars) - 0.0) ** 2)
+
+    def grad_log_p(self, vars):
+        return {'w_stim': -self.flat_weights(vars) / (0.01 ** 2)}
+
+    def get_state(self, vars=None):
+        st = {'basis': self.ibasis}
+        if vars is not None:                                    # bkgd.py:85 (D_stim = 1 form)
+            st['stim_response'] = np.dot(self.ibasis, self.flat_weights(vars)[:self.B])
+        return st
+
+    def preprocess_data(self, data):
+        """bkgd.py:122-154."""
+        if not abs(data['stim'].shape[0] * data['dt_stim'] - data['T']) < data['dt_stim']:
+            raise Exception('Stimulus length is not the same as data time length!')
+        D = self.bkgd_model['D_stim']
+        if not D == data['stim'].shape[1]:
+            raise Exception("Stim dimension (%d) is not equal to that specified by model (%d)"
+                            % (data['stim'].shape[1], D))
+        t = self.model['dt'] * np.arange(data['S'].shape[0])
+        dt_stim = self.bkgd_model.get('dt_stim', data['dt_stim'])
+        stim = _interp_stim(np.asarray(data['stim'], dtype=float), dt_stim, t)
+        c = bs.convolve_with_basis(stim, self.ibasis)           # (nT,D,B)
+        data['fstim'] = np.ascontiguousarray(c.reshape(c.shape[0], -1))
+
+    def sample(self, acc, rng=None):
+        return {'w_stim': 0.01 * _rng(rng).standard_normal(self.n_vars)}
+
+
+class SpatiotemporalStimulus(Component):
+    """bkgd.py:172-345: rank-1 filter, w_stim = vec(w_t (x) w_x) (index bt*Bx+bx, :214-220),
+    I_stim = fstim . w_stim (:227), Gaussian(mu, sigma) prior on both factors (:223-224)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.bkgd_model = model['bkgd']
+        self.mu = self.bkgd_model['mu']
+        self.sigma = self.bkgd_model['sigma']
+        self.spatial_basis = bs.create_basis(self.bkgd_model['spatial_basis'])
+        self.temporal_basis = bs.create_basis(self.bkgd_model['temporal_basis'])
+        R = bs.n_taps(self.bkgd_model['dt_max'], model['dt'])
+        ibt = bs.interpolate_columns(self.temporal_basis, np.linspace(0, 1, R),
+                                     np.linspace(0, 1, self.temporal_basis.shape[0]))
+        D = self.bkgd_model['D_stim']
+        ibx = bs.interpolate_columns(self.spatial_basis, np.linspace(0, 1, D),
+                                     np.linspace(0, 1, self.spatial_basis.shape[0]))
+        if self.bkgd_model['temporal_basis']['norm']:
+            ibt = ibt / ibt.sum(axis=0, keepdims=True)          # bkgd.py:294-296
+        self.ibasis_t, self.ibasis_x = ibt, ibx
+        self.Bt, self.Bx = ibt.shape[1], ibx.shape[1]
+        self.n_vars = self.Bx + self.Bt
+        self.n_features = self.Bt * self.Bx
+
+    def get_variables(self):
+        return {'w_x': (self.Bx,), 'w_t': (self.Bt,)}
+
+    def flat_weights(self, vars):
+        return np.outer(np.asarray(vars['w_t'], float), np.asarray(vars['w_x'], float)).reshape(-1)
+
+    def chain_grad(self, vars, g_flat):
+        G = np.asarray(g_flat, dtype=float).reshape(self.Bt, self.Bx)
+        return {'w_t': G.dot(np.asarray(vars['w_x'], float)),
+                'w_x': G.T.dot(np.asarray(vars['w_t'], float))}
+
+    def log_p(self, vars):
+        return (-0.5 / self.sigma ** 2 * np.sum((np.asarray(vars['w_x']) - self.mu) ** 2)
+                - 0.5 / self.sigma ** 2 * np.sum((np.asarray(vars['w_t']) - self.mu) ** 2))
+
+    def grad_log_p(self, vars):
+        return {'w_x': -(np.asarray(vars['w_x'], float) - self.mu) / self.sigma ** 2,
+                'w_t': -(np.asarray(vars['w_t'], float) - self.mu) / self.sigma ** 2}
+
+    def get_state(self, vars=None):
+        st = {'basis_t': self.ibasis_t}
+        if vars is not None:                                    # bkgd.py:250-272
+            rt = np.dot(self.ibasis_t, np.asarray(vars['w_t'], float))
+            rx = np.dot(self.ibasis_x, np.asarray(vars['w_x'], float))
+            sign = np.sign(np.sum(rt))
+            Z = np.linalg.norm(rt)
+            st['stim_response_t'] = sign * (1.0 / Z) * rt
+            rx = sign * Z * rx
+            if 'shape' in self.bkgd_model:
+                rx = rx.reshape(self.bkgd_model['shape'])
+            st['stim_response_x'] = rx
+        return st
+
+    def preprocess_data(self, data):
+        """bkgd.py:303-340: interpolate, low-rank convolution, (nT, Bt*Bx) with column bt*Bx+bx."""
+        dt = self.model['dt']
+        t = np.arange(0, data['T'], dt)
+        stim = _interp_stim(np.asarray(data['stim'], dtype=float), data['dt_stim'], t)
+        f = bs.convolve_with_low_rank_2d_basis(stim, self.ibasis_x, self.ibasis_t)   # (nt,Bx,Bt)
+        f = np.transpose(f, axes=[0, 2, 1])
+        data['fstim'] = np.ascontiguousarray(f.reshape(len(t), self.Bt * self.Bx))
+
+    def sample(self, acc, rng=None):
+        r = _rng(rng)
+        return {'w_x': self.mu + self.sigma * r.standard_normal(self.Bx),
+                'w_t': self.mu + self.sigma * r.standard_normal(self.Bt)}

@@ -1,0 +1,104 @@
+"""
+Glm -- one generalized linear model shared by all neurons (counterpart of pyglm/glm.py).
+
+    x_t   = I_bias + I_stim[t] + sum_n' W_eff[n',n] * I_imp[t,n']      glm.py:39-45
+    ll_n  = sum_t( -dt*nlin(x_t) + log(nlin(x_t)) * S[t,n] )           glm.py:52
+    log_p = lkhd_scale * ll + log_prior                                  glm.py:55-63
+
+The reference builds these as Theano expressions; here the data-dependent part (ll and
+its gradient) is evaluated by the HIP kernels on the flat feature-weight row `theta_row`
+and everything that only touches <= N*B numbers (priors, chain rules) is numpy.
+"""
+import numpy as np
+
+from theano_pyglm_amd.components.component import Component
+from theano_pyglm_amd.components.bias import create_bias_component
+from theano_pyglm_amd.components.bkgd import create_bkgd_component
+from theano_pyglm_amd.components.impulse import create_impulse_component
+from theano_pyglm_amd.components.nlin import create_nlin_component
+from theano_pyglm_amd.utils.syms import Sym, from_shapes
+
+_PARTS = ('bias', 'bkgd', 'imp', 'nlin')
+
+
+class Glm(Component):
+    def __init__(self, model, network, latent):
+        self.model = model
+        self.network = network
+        self.dt = model['dt']                      # glm.py:16 (KeyError without dt, like the reference)
+        self.N = model['N']
+        self.bias_model = create_bias_component(model, self, latent)
+        self.bkgd_model = create_bkgd_component(model, self, latent)
+        self.imp_model = create_impulse_component(model, self, latent)
+        self.nlin_model = create_nlin_component(model)
+        self.lkhd_scale = 1.0
+
+    def _part(self, key):
+        return {'bias': self.bias_model, 'bkgd': self.bkgd_model, 'imp': self.imp_model,
+                'nlin': self.nlin_model}[key]
+
+    # -- variables ----------------------------------------------------------
+    def get_variables(self):
+        """glm.py:65-73."""
+        v = {'n': Sym('n', (), 'int64')}
+        for k in _PARTS:
+            v[k] = from_shapes(self._part(k).get_variables())
+        return v
+
+    def sample(self, acc, rng=None):
+        """glm.py:119-129."""
+        v = {'n': -1}
+        for k in _PARTS:
+            v[k] = self._part(k).sample(acc, rng=rng)
+        return v
+
+    def set_hyperparameters(self, model):
+        """glm.py:112-117."""
+        self.bkgd_model.set_hyperparameters(model['bkgd'])
+        self.imp_model.set_hyperparameters(model['impulse'])
+        self.bias_model.set_hyperparameters(model['bias'])
+
+    def preprocess_data(self, data):
+        for k in _PARTS:
+            self._part(k).preprocess_data(data)
+
+    # -- host-side pieces ---------------------------------------------------
+    def log_prior(self, xn):
+        """glm.py:55-59 on the per-neuron dict xn = {'bias':..,'bkgd':..,'imp':..,'nlin':..}."""
+        return (self.bias_model.log_p(xn['bias']) + self.bkgd_model.log_p(xn['bkgd']) +
+                self.imp_model.log_p(xn['imp']) + self.nlin_model.log_p(xn.get('nlin', {})))
+
+    def grad_log_prior(self, xn):
+        return {'n': {}, 'bias': self.bias_model.grad_log_p(xn['bias']),
+                'bkgd': self.bkgd_model.grad_log_p(xn['bkgd']),
+                'imp': self.imp_model.grad_log_p(xn['imp']), 'nlin': {}}
+
+    @property
+    def Dstim(self):
+        return self.bkgd_model.n_features
+
+    @property
+    def P(self):
+        return 1 + self.Dstim + self.N * self.imp_model.B
+
+    def theta_row(self, xn):
+        """Flat feature weights [bias, w_stim, w_imp] consumed by the device (pyglm_hip.h)."""
+        return np.concatenate(([self.bias_model.I_bias(xn['bias'])],
+                               self.bkgd_model.flat_weights(xn['bkgd']),
+                               self.imp_model.flat_weights(xn['imp'])))
+
+    def chain_grad(self, xn, g_theta):
+        """Flat-weight gradient of ll (from the device) -> gradient w.r.t. the model's own
+        variables, as a nested dict shaped like the differentiable part of xn."""
+        D = self.Dstim
+        return {'n': {}, 'bias': {'bias': np.array([g_theta[0]])},
+                'bkgd': self.bkgd_model.chain_grad(xn['bkgd'], g_theta[1:1 + D]),
+                'imp': self.imp_model.chain_grad(xn['imp'], g_theta[1 + D:]),
+                'nlin': {}}
+
+    def get_state(self, xn=None):
+        """glm.py:75-91 (the time series lam / I_net / I_bkgd are filled in by Population)."""
+        return {'bias': self.bias_model.get_state(None if xn is None else xn['bias']),
+                'bkgd': self.bkgd_model.get_state(None if xn is None else xn['bkgd']),
+                'imp': self.imp_model.get_state(None if xn is None else xn['imp']),
+                'nlin': {}}

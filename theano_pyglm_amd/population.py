@@ -1,0 +1,290 @@
+"""
+Population -- connected GLMs (counterpart of pyglm/population.py).
+
+Same construction and method surface as the reference (`Population(model)`, `add_data`,
+`set_data`, `sample`, `extract_vars`, `compute_log_p`, `compute_log_prior`, `compute_ll`,
+`eval_state`, `simulate`) plus the gradient entry points the reference builds with
+T.grad inside its inference code (coord_descent.py:27-30): `compute_ll_grad` (all
+neurons in one fused device pass) and `compute_grad(vars, n)`.
+
+Every data sequence is uploaded to the GPU once (spike counts as uint8 + the
+spike-event index, the interpolated impulse basis, dense stimulus features) and stays
+resident; `set_data` only switches the current handle -- the reference re-copies the
+whole feature tensor into Theano shared variables on every evaluation
+(coord_descent.py:52-57, glm.py:99-110).  There is no CPU fallback.
+"""
+import os
+
+import numpy as np
+
+from theano_pyglm_amd import _lib
+from theano_pyglm_amd.components.latent import LatentVariables
+from theano_pyglm_amd.components.network import Network
+from theano_pyglm_amd.glm import Glm
+from theano_pyglm_amd.utils.packvec import packdict, get_vars
+from theano_pyglm_amd.utils.syms import from_shapes, differentiable, check_bound
+
+
+class Population(object):
+    def __init__(self, model, device=None):
+        """population.py:12-32."""
+        self.model = model
+        self.N = model['N']
+        self.data_sequences = []
+        self.latent = LatentVariables(model)
+        self.network = Network(model, self.latent)
+        self.glm = Glm(model, self.network, self.latent)
+        self.device = int(os.environ.get('PYGLM_DEVICE', '0')) if device is None else int(device)
+        self._handles = {}        # id(data dict) -> _lib.DeviceGlm
+        self._current = None      # data dict conditioned on (set_data)
+
+    # -- variables ------------------------------------------------------------
+    def get_variables(self):
+        """population.py:133-140."""
+        return {'latent': {},
+                'net': from_shapes(self.network.get_variables(), int_keys=('A',)),
+                'glm': self.glm.get_variables()}
+
+    def set_hyperparameters(self, model):
+        """population.py:142-147."""
+        self.network.set_hyperparameters(model)
+        self.glm.set_hyperparameters(model)
+
+    def sample(self, rng=None):
+        """population.py:149-162: latent -> net -> glms[0..N-1]."""
+        v = {'latent': {}}
+        v['net'] = self.network.sample(v, rng=rng)
+        v['glms'] = []
+        for n in range(self.N):
+            xn = self.glm.sample(v, rng=rng)
+            xn['n'] = n
+            v['glms'].append(xn)
+        return v
+
+    def extract_vars(self, vals, n):
+        """population.py:164-175."""
+        out = {}
+        for k, v in vals.items():
+            if k == 'glms':
+                out['glm'] = v[n]
+            else:
+                out[k] = v
+        return out
+
+    # -- data -------------------------------------------------------------------
+    def preprocess_data(self, data):
+        """population.py:187-196 (the impulse features fS are NOT materialised)."""
+        assert isinstance(data, dict), 'Data must be a dictionary'
+        self.glm.preprocess_data(data)
+        data['preprocessed'] = True
+        return data
+
+    def add_data(self, data, set_as_current_data=True):
+        """population.py:198-221."""
+        assert isinstance(data, dict), 'Data must be a dictionary'
+        assert 'S' in data, 'Data must contain an array of spike times'
+        assert isinstance(data['S'], np.ndarray), 'Spike times must be a numpy array'
+        if 'preprocessed' not in data or not data['preprocessed']:
+            data = self.preprocess_data(data)
+        self.data_sequences.append(data)
+        if set_as_current_data:
+            self.set_data(data)
+
+    def _handle(self, data):
+        h = self._handles.get(id(data))
+        if h is None:
+            S = np.asarray(data['S'])
+            nT, N = S.shape
+            assert N == self.N, "ERROR: Spike train must be (TxN) dimensional where N=%d" % self.N
+            imp = self.glm.imp_model
+            h = _lib.DeviceGlm(N, nT, imp.B, imp.ibasis.shape[0], self.glm.nlin_model.kind,
+                               self.glm.dt, device=self.device)
+            h.set_spikes(S)
+            h.set_basis(imp.ibasis)
+            if self.glm.Dstim > 0:
+                h.set_stim_features(data['fstim'])
+            self._handles[id(data)] = h
+            data['_device_handle'] = h        # keeps the handle alive as long as the data dict
+        return h
+
+    def set_data(self, data):
+        """population.py:223-231: condition on `data` (switches the device-resident handle)."""
+        assert 'preprocessed' in data and data['preprocessed'] == True, \
+            'Data must be preprocessed before it can be set'
+        self._handle(data)
+        self._current = data
+
+    def release_data(self):
+        """Free the device buffers of every data sequence."""
+        for h in self._handles.values():
+            h.close()
+        self._handles = {}
+
+    # -- parameters -> device layout ----------------------------------------------
+    def theta_matrix(self, vars, n_lo=0, n_hi=None):
+        n_hi = self.N if n_hi is None else n_hi
+        return np.array([self.glm.theta_row(vars['glms'][n]) for n in range(n_lo, n_hi)])
+
+    def W_eff(self, vars):
+        return self.network.W_eff(vars['net'])
+
+    def _check_vars(self, vars, n):
+        """Mirror of seval's binding check (theano_func_wrapper.py:69-105)."""
+        syms = self.get_variables()
+        nv = self.extract_vars(vars, n)
+        check_bound({'net': syms['net']}, nv)
+        glm_syms = dict((k, v) for k, v in syms['glm'].items() if k != 'n')
+        check_bound(glm_syms, nv['glm'])
+
+    # -- log probability ---------------------------------------------------------------
+    def compute_log_prior(self, vars):
+        """population.py:47-69: latent + network + sum_n glm.log_prior."""
+        lp = 0.0
+        lp += self.latent.log_p(vars.get('latent', {}))
+        lp += self.network.log_p(vars['net'])
+        for n in range(self.N):
+            self._check_vars(vars, n)
+            lp += self.glm.log_prior(vars['glms'][n])
+        return lp
+
+    def compute_ll_vector(self, vars, n_lo=0, n_hi=None):
+        """Per-neuron ll of the CURRENT data sequence for neurons [n_lo, n_hi)."""
+        n_hi = self.N if n_hi is None else n_hi
+        if self._current is None:
+            raise Exception("No data sequence has been set")
+        h = self._handle(self._current)
+        ll, _ = h.ll_grad(self.theta_matrix(vars, n_lo, n_hi), self.W_eff(vars), n_lo, n_hi,
+                          want_grad=False)
+        return ll
+
+    def compute_ll(self, vars):
+        """population.py:71-86: sum over neurons of glm.ll on the current data."""
+        for n in range(self.N):
+            self._check_vars(vars, n)
+        return float(np.sum(self.compute_ll_vector(vars)))
+
+    def compute_log_p(self, vars):
+        """population.py:34-45 (lkhd_scale is not applied here, like the reference)."""
+        lp = 0.0
+        lp += self.compute_log_prior(vars)
+        for data in self.data_sequences:
+            self.set_data(data)
+            lp += self.compute_ll(vars)
+        return lp
+
+    # -- gradients (the reference: T.grad in coord_descent.py:27-30) --------------------
+    def compute_ll_grad(self, vars, n_lo=0, n_hi=None):
+        """ll_n and d ll_n / d(flat feature weights) for n in [n_lo,n_hi) on the current data:
+        returns (ll (npost,), g_theta (npost,P)) straight from the fused device pass."""
+        n_hi = self.N if n_hi is None else n_hi
+        h = self._handle(self._current)
+        return h.ll_grad(self.theta_matrix(vars, n_lo, n_hi), self.W_eff(vars), n_lo, n_hi)
+
+    def glm_syms(self):
+        """differentiable(syms['glm']) (coord_descent.py:24)."""
+        return differentiable(self.get_variables()['glm'])
+
+    def compute_lp_grad_packed(self, vars, n_lo=0, n_hi=None, include_prior=True):
+        """For every neuron n in [n_lo,n_hi): log posterior of its GLM parameters
+        (log_prior_n + sum_data ll_n) and the gradient w.r.t. the packed per-neuron vector
+        (layout = packdict of the differentiable GLM variables).
+        Returns (lp (npost,), grads (npost, P_packed))."""
+        n_hi = self.N if n_hi is None else n_hi
+        syms = self.glm_syms()
+        lps = np.zeros(n_hi - n_lo)
+        grads = None
+        for data in self.data_sequences:
+            self.set_data(data)
+            ll, g_theta = self.compute_ll_grad(vars, n_lo, n_hi)
+            lps += ll
+            for i, n in enumerate(range(n_lo, n_hi)):
+                xn = vars['glms'][n]
+                gd = self.glm.chain_grad(xn, g_theta[i])
+                gv, _ = packdict(get_vars(syms, gd))
+                if grads is None:
+                    grads = np.zeros((n_hi - n_lo, gv.size))
+                grads[i] += gv
+        if include_prior:
+            for i, n in enumerate(range(n_lo, n_hi)):
+                xn = vars['glms'][n]
+                lps[i] += self.glm.log_prior(xn)
+                gv, _ = packdict(get_vars(syms, self.glm.grad_log_prior(xn)))
+                grads[i] += gv
+        return lps, grads
+
+    def compute_grad(self, vars, n):
+        """Gradient of (glm.log_prior + sum_data glm.ll) of neuron n w.r.t. its packed
+        parameter vector -- minus coord_descent.grad_nlp (coord_descent.py:61-80)."""
+        return self.compute_lp_grad_packed(vars, n, n + 1)[1][0]
+
+    # -- state ---------------------------------------------------------------------------
+    def eval_state(self, vars):
+        """population.py:88-120: rates, currents and component state of every neuron."""
+        state = {'latent': {}, 'net': self.network.get_state(vars['net'])}
+        h = self._handle(self._current)
+        W = self.W_eff(vars)
+        glm_states = []
+        for n in range(self.N):
+            xn = vars['glms'][n]
+            st = self.glm.get_state(xn)
+            lam, inet, istim = h.state(n, self.glm.theta_row(xn), W[:, n])
+            st['lam'] = lam
+            st['I_bias'] = self.glm.bias_model.I_bias(xn['bias'])
+            st['I_bkgd'] = istim if self.glm.Dstim > 0 else 0.0
+            st['I_net'] = inet
+            glm_states.append(st)
+        state['glms'] = glm_states
+        state['logprior'] = self.compute_log_prior(vars)
+        state['ll'] = self.compute_ll(vars)
+        state['logp'] = state['ll'] + state['logprior']
+        return state
+
+    # -- simulation ------------------------------------------------------------------------
+    def simulate(self, vars, T_range, dt, stim, dt_stim, rng=None, verbose=False):
+        """population.py:233-389: integrate-and-fire thinning with exponential thresholds;
+        every spike adds A*W*impulse to X[t+1 : t+R+1] (351-353); <= 10 spikes per bin.
+        Host-side restatement (seeded; the reference uses the global np.random)."""
+        from theano_pyglm_amd.components.priors import _rng
+        r = _rng(rng)
+        T_start, T_stop = T_range
+        N = self.N
+        nT = len(np.arange(T_start, T_stop, dt))
+        X = np.zeros((nT, N))
+        for n in range(N):
+            X[:, n] = self.glm.bias_model.I_bias(vars['glms'][n]['bias'])
+        if self.glm.Dstim > 0:
+            tmp = {'S': np.zeros((nT, N)), 'stim': stim, 'dt_stim': dt_stim, 'T': float(T_stop - T_start),
+                   'dt': dt}
+            self.glm.bkgd_model.preprocess_data(tmp)
+            for n in range(N):
+                X[:, n] += tmp['fstim'].dot(self.glm.bkgd_model.flat_weights(vars['glms'][n]['bkgd']))
+        # imps[n_pre, n_post, :] (population.py:275-282)
+        imps = np.array([self.glm.imp_model.impulse(vars['glms'][n]['imp']) for n in range(N)])
+        imps = np.transpose(imps, axes=[1, 0, 2])
+        T_imp = imps.shape[2]
+        AW = self.W_eff(vars)[:, :, None] * imps              # (n_pre, n_post, R)
+        f_nlin = self.glm.nlin_model.f_nlin
+        S = np.zeros((nT, N))
+        acc = np.zeros(N)
+        thr = -np.log(r.random_sample(N))
+        n_exceptions = 0
+        for t in range(nT):
+            acc = acc + f_nlin(X[t, :]) * dt
+            i_spk = acc > thr
+            S[t, i_spk] += 1
+            n_spk = int(np.sum(i_spk))
+            t_imp = min(nT - t - 1, T_imp)
+            while n_spk > 0:
+                if np.any(S[t, :] >= 10):
+                    n_exceptions += 1
+                    break
+                X[t + 1:t + t_imp + 1, :] += np.sum(AW[i_spk, :, :t_imp], 0).T
+                acc -= thr * i_spk
+                acc[acc < 0] = 0
+                thr[i_spk] = -np.log(r.random_sample(n_spk))
+                i_spk = acc > thr
+                S[t, i_spk] += 1
+                n_spk = int(np.sum(i_spk))
+        if verbose:
+            print("Number of exceptions arising from multiple spikes per bin: %d" % n_exceptions)
+        return S, X
