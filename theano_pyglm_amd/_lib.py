@@ -17,6 +17,7 @@ NLIN_EXP = 0
 NLIN_EXPLINEAR = 1
 OPT_FEATURE_F32 = 1
 OPT_NCHUNKS = 2
+OPT_KERNEL = 3
 
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [

@@ -43,7 +43,7 @@ struct pgl_context {
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0;
     bool timing_valid = false;
 };
 
@@ -72,31 +72,55 @@ static void release(DevBuf& b)
 
 struct Plan {
     int npost, nPT, wpb, nPB, KT, KS, rsf, RP, nTiles, nChunks, tilesPerChunk, blocks, threads;
+    int version, PTW, KTW, KSPLIT;      // version 2: 8 waves, K split over KSPLIT waves per post tile
     size_t lds;
     bool f32;
 };
 
 static const int kKT[] = {2, 4, 10, 13, 20, 40};
+static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
 {
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
     pl.nPT = (pl.npost + 15) / 16;
-    pl.wpb = std::min(4, pl.nPT);
-    pl.nPB = (pl.nPT + pl.wpb - 1) / pl.wpb;
     const int need = (h->Ktot + 15) / 16;
-    pl.KT = 0;
-    for (int kt : kKT)
-        if (kt >= need) {
-            pl.KT = kt;
-            break;
-        }
-    if (pl.KT == 0)
-        return fail(PGL_ERR_UNSUPPORTED,
-                    "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
-    pl.KS = pl.KT * 4;
     pl.f32 = h->opt_f32 != 0;
+    pl.version = (h->opt_kernel == 1 || pl.f32) ? 1 : 2;
+    pl.RP = h->R + 32;
+    while (pl.RP % 32 != 6) ++pl.RP;      // bank spread of the per-basis rows for ds_read_b128
+    if (pl.version == 2) {
+        pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
+        pl.KSPLIT = 8 / pl.PTW;
+        const int needw = (need + pl.KSPLIT - 1) / pl.KSPLIT;
+        pl.KTW = 0;
+        for (int k : kKTW)
+            if (k >= needw) {
+                pl.KTW = k;
+                break;
+            }
+        if (pl.KTW == 0 || pl.KTW * pl.KSPLIT > 40)
+            return fail(PGL_ERR_UNSUPPORTED,
+                        "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
+        pl.KT = pl.KTW * pl.KSPLIT;
+        pl.wpb = 8;
+        pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
+    } else {
+        pl.PTW = 0; pl.KTW = 0; pl.KSPLIT = 1;
+        pl.wpb = std::min(4, pl.nPT);
+        pl.nPB = (pl.nPT + pl.wpb - 1) / pl.wpb;
+        pl.KT = 0;
+        for (int kt : kKT)
+            if (kt >= need) {
+                pl.KT = kt;
+                break;
+            }
+        if (pl.KT == 0)
+            return fail(PGL_ERR_UNSUPPORTED,
+                        "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
+    }
+    pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
     pl.nTiles = h->nT16;
@@ -107,12 +131,15 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.blocks = pl.nChunks * pl.nPB;
     pl.threads = 64 * pl.wpb;
     size_t off = ((size_t)16 * pl.rsf * (pl.f32 ? 4 : 8) + 15) & ~(size_t)15;
-    pl.RP = h->R + 32;
-    while (pl.RP % 32 != 6) ++pl.RP;      // bank spread of the per-basis rows for ds_read_b128
     off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;
     off += (size_t)h->N * PGL_CAP * 8;
-    off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
-    off += (((size_t)h->N * 4) + 15) & ~(size_t)15;
+    if (pl.version == 2) {
+        off += 2 * ((((size_t)2 * h->N * 4) + 15) & ~(size_t)15);
+        off += (size_t)8 * 256 * 8 + (size_t)pl.PTW * 256 * 8;
+        if (h->N * PGL_CAP > 4 * 512) return fail(PGL_ERR_UNSUPPORTED, "N > 128 neurons");
+    } else {
+        off += 2 * ((((size_t)h->N * 4) + 15) & ~(size_t)15);
+    }
     pl.lds = off;
     if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
     return PGL_OK;
@@ -139,6 +166,42 @@ static hipError_t launch_fused_kt(const Plan& pl, const FusedParams& fp, hipStre
     case 13: return launch_fused_t<13, FT>(pl, fp, s);
     case 20: return launch_fused_t<20, FT>(pl, fp, s);
     case 40: return launch_fused_t<40, FT>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int KTW, int PTW>
+static hipError_t launch_fused2_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    auto kern = k_fused2<KTW, PTW, double>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    return hipGetLastError();
+}
+
+template <int PTW>
+static hipError_t launch_fused2_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KTW) {
+    case 1: return launch_fused2_t<1, PTW>(pl, fp, s);
+    case 2: return launch_fused2_t<2, PTW>(pl, fp, s);
+    case 3: return launch_fused2_t<3, PTW>(pl, fp, s);
+    case 5: return launch_fused2_t<5, PTW>(pl, fp, s);
+    case 7: if constexpr (PTW >= 2) return launch_fused2_t<7, PTW>(pl, fp, s); break;
+    case 10: if constexpr (PTW >= 2) return launch_fused2_t<10, PTW>(pl, fp, s); break;
+    case 20: if constexpr (PTW >= 4) return launch_fused2_t<20, PTW>(pl, fp, s); break;
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.PTW) {
+    case 1: return launch_fused2_k<1>(pl, fp, s);
+    case 2: return launch_fused2_k<2>(pl, fp, s);
+    case 4: return launch_fused2_k<4>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -207,6 +270,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     switch (option) {
     case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
     case 99: h->opt_dbg = value; return PGL_OK;
+    case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -339,8 +403,8 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
     (void)P;
     ENSURE(h->Wfrag, (size_t)pl.nPT * pl.KS * 64 * 8);
     ENSURE(h->bias, (size_t)pl.nPT * 16 * 8);
-    ENSURE(h->llpart, (size_t)pl.nChunks * pl.nPT * 64 * 8);
-    ENSURE(h->gbpart, (size_t)pl.nChunks * pl.nPT * 64 * 8);
+    ENSURE(h->llpart, (size_t)pl.nChunks * pl.nPT * pl.KSPLIT * 64 * 8);
+    ENSURE(h->gbpart, (size_t)pl.nChunks * pl.nPT * pl.KSPLIT * 64 * 8);
     if (d_grad) ENSURE(h->Gpart, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
 
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
@@ -367,18 +431,24 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
     fp.dbg = h->opt_dbg;
 
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
-    hipError_t e = pl.f32 ? launch_fused_kt<float>(pl, fp, h->stream)
-                          : launch_fused_kt<double>(pl, fp, h->stream);
+    hipError_t e = (pl.version == 2) ? launch_fused2(pl, fp, h->stream)
+                   : pl.f32        ? launch_fused_kt<float>(pl, fp, h->stream)
+                                   : launch_fused_kt<double>(pl, fp, h->stream);
     if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(h->ev[2], h->stream));
     {
-        const long long nfrag = d_grad ? (long long)pl.nPT * pl.KT * 256 : 0;
-        const long long nthreads = std::max<long long>(nfrag, pl.npost);
-        const int blocks = (int)((nthreads + 255) / 256);
-        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream,
-                           (const double*)h->Gpart.p, (const double*)h->llpart.p,
-                           (const double*)h->gbpart.p, d_Weff, d_ll, d_grad, h->N, h->B, h->Dstim,
-                           h->Kimp, h->Ktot, pl.KT, n_lo, pl.npost, pl.nPT, pl.nChunks);
+        if (d_grad) {
+            const long long nfrag = (long long)pl.nPT * pl.KT * 256;
+            const int blocks = (int)((nfrag + 255) / 256);
+            hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream,
+                               (const double*)h->Gpart.p, (const double*)h->llpart.p,
+                               (const double*)h->gbpart.p, d_Weff, d_ll, d_grad, h->N, h->B,
+                               h->Dstim, h->Kimp, h->Ktot, pl.KT, n_lo, pl.npost, pl.nPT, pl.nChunks);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(64), 0, h->stream,
+                           (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad,
+                           1 + h->Dstim + h->Kimp, pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(h->ev[3], h->stream));

@@ -51,9 +51,136 @@ struct FusedParams {
     int dbg;                             // timing ablation bits (results invalid when != 0)
 };
 
+// ---------------------------------------------------------------------------
+// f64 elementary functions of the epilogue.  Hand-rolled (instead of the ocml calls)
+// because on gfx950 every f64 VALU instruction competes with the f64 MFMA for the same
+// DP pipeline (tools/ubench): the rate epilogue is pure overhead on the MFMA roofline, so
+// its instruction count matters.  Accuracy ~1 ulp (prototype: tools/ubench/proto_math.py).
+// ---------------------------------------------------------------------------
+// polynomial / reduction constants, read with scalar loads (SGPRs): as f64 literals they would
+// be hoisted into ~50 loop-invariant VGPRs and spilled around the MFMA accumulators
+__constant__ double PGL_C[32] = {
+    1.4426950408889634,            //  0 log2(e)
+    6.93147180369123816490e-01,    //  1 ln2 hi
+    1.90821492927058770002e-10,    //  2 ln2 lo
+    1.6059043836821613e-10,        //  3 1/13!
+    2.08767569878681e-09,          //  4 1/12!
+    2.505210838544172e-08,         //  5 1/11!
+    2.755731922398589e-07,         //  6 1/10!
+    2.7557319223985893e-06,        //  7 1/9!
+    2.48015873015873e-05,          //  8 1/8!
+    0.0001984126984126984,         //  9 1/7!
+    0.001388888888888889,          // 10 1/6!
+    0.008333333333333333,          // 11 1/5!
+    0.041666666666666664,          // 12 1/4!
+    0.16666666666666666,           // 13 1/3!
+    1.479819860511658591e-01,      // 14 Lg7
+    1.531383769920937332e-01,      // 15 Lg6
+    1.818357216161805012e-01,      // 16 Lg5
+    2.222219843214978396e-01,      // 17 Lg4
+    2.857142874366239149e-01,      // 18 Lg3
+    3.999999999940941908e-01,      // 19 Lg2
+    6.666666666666735130e-01,      // 20 Lg1
+    0.70710678118654752440,        // 21 sqrt(1/2)
+    1.0 / 3.0,                     // 22
+    9.6e-5,                        // 23 series threshold on exp(-|x|)
+    0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ double pgl_rcp(const double b)
+{
+    double r = __builtin_amdgcn_rcp(b);           // v_rcp_f64 seed + two Newton steps
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+
+// exp(y): k = rint(y/ln2), r = y - k ln2 (hi/lo split), degree-13 Taylor in |r| <= 0.347, ldexp
+__device__ __forceinline__ double pgl_exp(const double y)
+{
+    const double* __restrict__ C = PGL_C;
+    const double k = rint(y * C[0]);
+    double r = fma(-k, C[1], y);
+    r = fma(-k, C[2], r);
+    double p = C[3];
+#pragma unroll
+    for (int i = 4; i <= 13; ++i) p = fma(p, r, C[i]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double kc = fmin(fmax(k, -2200.0), 2200.0);
+    return ldexp(p, (int)kc);
+}
+
+// log(v) for v >= 0 (fdlibm e_log.c scheme: v = 2^e m, m in [sqrt(1/2), sqrt 2),
+// s = f/(2+f), 7-term polynomial in s^2); log(0) = -inf, inf/NaN pass through
+__device__ __forceinline__ double pgl_log(const double v)
+{
+    double m = __builtin_amdgcn_frexp_mant(v);    // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(v);
+    const double* __restrict__ C = PGL_C;
+    const bool lt = m < C[21];
+    m = lt ? m + m : m;
+    e = lt ? e - 1 : e;
+    const double f = m - 1.0;
+    const double den = 2.0 + f;
+    const double rc = pgl_rcp(den);
+    double s = f * rc;
+    s = fma(fma(-den, s, f), rc, s);
+    const double z = s * s;
+    double R = C[14];
+#pragma unroll
+    for (int i = 15; i <= 20; ++i) R = fma(R, z, C[i]);
+    R = R * z;
+    const double hfsq = 0.5 * f * f;
+    const double de = (double)e;
+    double res = de * C[1] - ((hfsq - (s * (hfsq + R) + de * C[2])) - f);
+    res = (v == 0.0) ? -__builtin_huge_val() : res;
+    res = (v < __builtin_huge_val()) ? res : v;
+    return res;
+}
+
+// One element of the rate epilogue (glm.py:43-52 and its derivative w.r.t. x):
+//   explinear: lam = log(1+exp(x)) in the overflow-safe form max(x,0) + log1p(exp(-|x|)),
+//              term = -dt*lam + s*log(lam),  r = (-dt + s/lam) * sigmoid(x)
+//   exp:       lam = exp(x), term = -dt*lam + s*x, r = -dt*lam + s
+// log(lam) and 1/lam are only evaluated in waves where some lane has a spike (s > 0);
+// when every lane of the wave has exp(-|x|) < 9.6e-5 (|x| > 9.25, the operating regime of
+// standard_glm's bias ~ 20) log1p and 1/(1+e) come from their alternating series (error < e^6).
+__device__ __forceinline__ void pgl_rate_terms(const double x, const double s, const int nlin,
+                                               const double dt, double& term, double& res)
+{
+    if (nlin == 1) {
+        const double e = pgl_exp(-fabs(x));
+        double l1p, inv;
+        if (__all(e < PGL_C[23])) {
+            l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), PGL_C[22]), 0.5), 1.0);
+            inv = fma(-e, fma(-e, fma(-e, fma(-e, fma(-e, 1.0, 1.0), 1.0), 1.0), 1.0), 1.0);
+        } else {
+            const double u = 1.0 + e;
+            inv = pgl_rcp(u);
+            l1p = pgl_log(u) + (e - (u - 1.0)) * inv;
+        }
+        const double lam = fmax(x, 0.0) + l1p;
+        const double sig = (x >= 0.0) ? inv : e * inv;
+        term = -dt * lam;
+        res = -dt * sig;
+        if (s > 0.0) {
+            term = fma(pgl_log(lam), s, term);
+            res = (-dt + s * pgl_rcp(lam)) * sig;
+        }
+        // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52)
+        term = (lam == 0.0) ? __builtin_nan("") : term;
+        res = (x != x) ? x : res;
+    } else {
+        const double lam = pgl_exp(x);
+        term = fma(x, s, -dt * lam);
+        res = fma(-dt, lam, s);
+    }
+}
+
 __device__ __forceinline__ double pgl_softplus_parts(double x, double& sig, double& loglam)
 {
-    // stable log(1+exp(x)) (nlin.py:43); sigmoid and log(lam) share the exp
+    // stable log(1+exp(x)) (nlin.py:43); ocml form, used by the non-hot helper kernels
     const double e = exp(-fabs(x));
     const double lam = fmax(x, 0.0) + log1p(e);
     const double inv = 1.0 / (1.0 + e);
@@ -274,15 +401,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
                 if (p.dbg & 4) {
                     term = x * sc[r];
                     res = x - sc[r];
-                } else if (p.nlin == 1) {
-                    double sig, loglam;
-                    const double lam = pgl_softplus_parts(x, sig, loglam);
-                    term = -p.dt * lam + loglam * sc[r];
-                    res = (-p.dt + sc[r] / lam) * sig;
                 } else {
-                    const double lam = exp(x);
-                    term = -p.dt * lam + x * sc[r];
-                    res = -p.dt * lam + sc[r];
+                    pgl_rate_terms(x, sc[r], p.nlin, p.dt, term, res);
                 }
                 ll_acc += vt[r] ? term : 0.0;
                 rr[r] = vt[r] ? res : 0.0;
@@ -319,6 +439,369 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
             double* gp = p.Gpart + slot * (size_t)KT * 256 + lane;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Feature generation, version 2 kernel: work item = (feature column, block of ROWS rows)
+// so that all 512 threads are busy (640 columns x 4 row blocks = 5 items per thread at C3)
+// and a wave spans few presynaptic neurons (less trip-count divergence).  Events are
+// staged in LDS already decoded for this tile: {byte offset of row 0's 16-tap slice in the
+// even/odd basis table, count as float} -- the even/odd select and lag arithmetic are done
+// once per event at staging time instead of once per (event, column, row block).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int2 pgl_decode_event(const int2 e, const int t0, const int oddoff)
+{
+    const int base = t0 - e.x - 1 + 16;                       // >= 1, < R + 16
+    const int off = (base & 1) ? (oddoff + (base - 1) * 8) : base * 8;
+    return make_int2(off, __float_as_int((float)e.y));
+}
+
+template <int BB, int ROWS, typename FT>
+__device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
+                                          const unsigned char* __restrict__ phiBytes,
+                                          const int RP, const int2* __restrict__ s_dec,
+                                          const int* __restrict__ s_lo,
+                                          const int* __restrict__ s_cnt,
+                                          const int2* __restrict__ spk, const int t0, const int B,
+                                          const int Kimp, const int tid, const int nthr)
+{
+    constexpr int QN = 16 / ROWS;
+    const int nitems = Kimp * QN;
+    const int oddoff = B * RP * 8;
+    for (int item = tid; item < nitems; item += nthr) {
+        const int q = item % QN;
+        const int colx = item / QN;
+        const int np = (BB > 0) ? colx / BB : colx / B;
+        const int b = colx - np * ((BB > 0) ? BB : B);
+        const int cnt = s_cnt[np];
+        const unsigned char* tb = phiBytes + (b * RP + q * ROWS) * 8;
+        double acc[ROWS];
+#pragma unroll
+        for (int t = 0; t < ROWS; ++t) acc[t] = 0.0;
+        if (cnt <= PGL_CAP) {
+            const int2* sp = s_dec + np * PGL_CAP;
+            for (int j = 0; j < cnt; j += 2) {
+                const int2 e0 = sp[j];
+                int2 e1 = sp[j + 1 < PGL_CAP ? j + 1 : j];
+                if (j + 1 >= cnt) e1 = make_int2(0, 0);       // zero-weight dummy, valid offset
+                const double c0 = (double)__int_as_float(e0.y);
+                const double c1 = (double)__int_as_float(e1.y);
+                const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
+                const double2* p1 = reinterpret_cast<const double2*>(tb + e1.x);
+#pragma unroll
+                for (int h = 0; h < ROWS / 2; ++h) {
+                    const double2 v0 = p0[h];
+                    const double2 v1 = p1[h];
+                    acc[2 * h] = fma(c0, v0.x, acc[2 * h]);
+                    acc[2 * h + 1] = fma(c0, v0.y, acc[2 * h + 1]);
+                    acc[2 * h] = fma(c1, v1.x, acc[2 * h]);
+                    acc[2 * h + 1] = fma(c1, v1.y, acc[2 * h + 1]);
+                }
+            }
+        } else {                                              // window overflowed the staging
+            const int2* sp = spk + s_lo[np];
+            for (int j = 0; j < cnt; ++j) {
+                const int2 e0 = pgl_decode_event(sp[j], t0, oddoff);
+                const double c0 = (double)__int_as_float(e0.y);
+                const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
+#pragma unroll
+                for (int h = 0; h < ROWS / 2; ++h) {
+                    const double2 v0 = p0[h];
+                    acc[2 * h] = fma(c0, v0.x, acc[2 * h]);
+                    acc[2 * h + 1] = fma(c0, v0.y, acc[2 * h + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < ROWS; ++t) Fs[(q * ROWS + t) * rsf + colx] = (FT)acc[t];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused ll + grad kernel, version 2: 8 waves per workgroup (two per SIMD, <= 256
+// registers each, VGPR-form MFMA).  A workgroup owns PTW post-synaptic tiles; the
+// feature dimension K is split over KSPLIT = 8/PTW waves per tile, so a wave keeps
+// only KTW = KT/KSPLIT accumulator tiles of G (<= 160 registers) and streams only its
+// own slice of Wmat.  Per time tile:
+//   gen F (all 512 threads) | forward partial X over the wave's K slice | partial X
+//   -> LDS | the tile's 256 elements are split over its KSPLIT waves: sum of partials,
+//   epilogue, r -> LDS | every wave re-reads r (MFMA B layout) | backward on its K slice.
+// The two waves of a SIMD hide each other's LDS / L2 latencies; the event windows of
+// the next tile are prefetched into registers during the MFMA phases.
+// (f64 VALU work cannot hide under f64 MFMA on gfx950: both issue to the same DP
+// pipeline -- tools/ubench -- so the win is latency hiding, not FP overlap.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pgl_epilogue(const double x, const double s, const bool valid,
+                                             const int nlin, const double dt, double& ll_acc,
+                                             double& gb_acc, double& res_out)
+{
+    double term, res;
+    pgl_rate_terms(x, s, nlin, dt, term, res);
+    ll_acc += valid ? term : 0.0;
+    res_out = valid ? res : 0.0;
+    gb_acc += res_out;
+}
+
+template <int KTW, int PTW, typename FT>
+__global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
+{
+    constexpr int TT = 16;
+    constexpr int NW = 8;
+    constexpr int KSPLIT = NW / PTW;
+    constexpr int KSW = KTW * 4;                 // forward k-steps of this wave
+    constexpr int KS_ALL = KSW * KSPLIT;         // k-steps of the whole padded K
+    constexpr int KT_ALL = KTW * KSPLIT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int nthr = NW * 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptl = wave % PTW;                  // post tile inside the workgroup
+    const int ksl = wave / PTW;                  // K slice of this wave
+    const int nPB = (p.nPT + PTW - 1) / PTW;
+    const int pb = blockIdx.x % nPB;
+    const int chunk = blockIdx.x / nPB;
+    const int pt = pb * PTW + ptl;
+    const bool active = pt < p.nPT;
+
+    const int N = p.N, B = p.B, R = p.R, rsf = p.rsf, RP = p.RP;
+    // LDS carve (offsets multiples of 16)
+    FT* Fs = reinterpret_cast<FT*>(smem);
+    size_t off = ((size_t)TT * rsf * sizeof(FT) + 15) & ~(size_t)15;
+    double* phiE = reinterpret_cast<double*>(smem + off);
+    double* phiO = phiE + (size_t)B * RP;
+    off += (((size_t)2 * B * RP * 8) + 15) & ~(size_t)15;
+    int2* s_spk = reinterpret_cast<int2*>(smem + off);
+    off += (size_t)N * PGL_CAP * 8;
+    int* s_lo = reinterpret_cast<int*>(smem + off);           // [2][N]
+    off += (((size_t)2 * N * 4) + 15) & ~(size_t)15;
+    int* s_cnt = reinterpret_cast<int*>(smem + off);          // [2][N]
+    off += (((size_t)2 * N * 4) + 15) & ~(size_t)15;
+    double* Xp = reinterpret_cast<double*>(smem + off);       // [NW][4][64] partial X
+    off += (size_t)NW * 256 * 8;
+    double* Rb = reinterpret_cast<double*>(smem + off);       // [PTW][4][64] residuals r
+
+    for (int i = tid; i < B * RP; i += nthr) {
+        const int b = i / RP, k = i - b * RP;
+        phiE[i] = (k >= 16 && k < 16 + R) ? p.phi[b * R + k - 16] : 0.0;
+        phiO[i] = (k + 1 >= 16 && k + 1 < 16 + R) ? p.phi[b * R + k + 1 - 16] : 0.0;
+    }
+    for (int i = tid; i < TT * rsf; i += nthr) Fs[i] = (FT)0;
+
+    d4_t G[KTW];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double ll_acc = 0.0, gb_acc = 0.0;
+
+    const int col = lane & 15;
+    const int grp = lane >> 4;
+    const int nloc = pt * 16 + col;
+    const bool valid_n = active && (nloc < p.npost);
+    const int nglob = p.n_lo + (valid_n ? nloc : 0);
+    const double bias_l = valid_n ? p.bias[nloc] : 0.0;
+    const double* __restrict__ wrow =
+        p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
+    const int kcol0 = ksl * KTW * 16;            // first feature column of this wave's slice
+
+    const int tile_beg = chunk * p.tilesPerChunk;
+    int tile_end = tile_beg + p.tilesPerChunk;
+    if (tile_end > p.nTiles) tile_end = p.nTiles;
+
+    // prologue: windows of the first two tiles, events of the first tile
+    if (tid < N) {
+        for (int q = 0; q < 2; ++q) {
+            const int tl = tile_beg + q;
+            int lo = 0, cnt = 0;
+            if (tl < tile_end) {
+                lo = p.wlo[(size_t)tl * N + tid];
+                cnt = p.whi[(size_t)tl * N + tid] - lo;
+            }
+            s_lo[(tl & 1) * N + tid] = lo;
+            s_cnt[(tl & 1) * N + tid] = cnt;
+        }
+    }
+    __syncthreads();
+    {
+        const int pb0 = (tile_beg & 1) * N;
+        for (int id = tid; id < N * PGL_CAP; id += nthr) {
+            const int np = id / PGL_CAP, sl = id % PGL_CAP;
+            const int cnt = s_cnt[pb0 + np];
+            if (cnt <= PGL_CAP && sl < cnt)
+                s_spk[id] = pgl_decode_event(p.spk[s_lo[pb0 + np] + sl], tile_beg * TT, B * RP * 8);
+        }
+    }
+    __syncthreads();
+
+    constexpr int NPF = 4;                        // prefetched event slots per thread (N*CAP <= 2048)
+    for (int tile = tile_beg; tile < tile_end; ++tile) {
+        const int t0 = tile * TT;
+        const int cur = (tile & 1) * N;
+        const int nxt = ((tile + 1) & 1) * N;
+        // ---- prefetch (registers): events of tile+1, windows of tile+2 ----
+        int2 pf[NPF];
+        bool pfv[NPF];
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int id = tid + q * nthr;
+            pfv[q] = false;
+            pf[q] = make_int2(0, 0);
+            if (id < N * PGL_CAP && tile + 1 < tile_end) {
+                const int np = id / PGL_CAP, sl = id % PGL_CAP;
+                const int cnt = s_cnt[nxt + np];
+                if (cnt <= PGL_CAP && sl < cnt) {
+                    pf[q] = p.spk[s_lo[nxt + np] + sl];
+                    pfv[q] = true;
+                }
+            }
+        }
+        int w2lo = 0, w2cnt = 0;
+        if (tid < N && tile + 2 < tile_end) {
+            w2lo = p.wlo[(size_t)(tile + 2) * N + tid];
+            w2cnt = p.whi[(size_t)(tile + 2) * N + tid] - w2lo;
+        }
+        // dense stimulus feature columns of this tile
+        if (p.Dstim > 0) {
+            for (int id = tid; id < TT * p.Dstim; id += nthr) {
+                const int t = id / p.Dstim;
+                const int j = id % p.Dstim;
+                const long long tg = (long long)t0 + t;
+                Fs[t * rsf + p.Kimp + j] = (FT)((tg < p.nT) ? p.fstim[tg * p.Dstim + j] : 0.0);
+            }
+        }
+        // ---- F tile from the staged events ----
+        if (!(p.dbg & 1)) {
+            const unsigned char* phiBytes = reinterpret_cast<const unsigned char*>(phiE);
+            if (B == 5)
+                gen_items<5, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                                    p.Kimp, tid, nthr);
+            else if (B == 3)
+                gen_items<3, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                                    p.Kimp, tid, nthr);
+            else
+                gen_items<0, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                                    p.Kimp, tid, nthr);
+        }
+        __syncthreads();
+
+        // ---- forward over this wave's K slice ----
+        d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
+        d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+        if (active && !(p.dbg & 8)) {
+            const FT* fa = Fs + col * rsf + kcol0 + grp;
+            const double* wr_s = wrow;
+            asm volatile("" : "+s"(wr_s));
+            constexpr int PW = (KSW < 8) ? KSW : 8;
+            constexpr int PA = (KSW < 4) ? KSW : 4;
+            double wr[PW], ar[PA];
+#pragma unroll
+            for (int s = 0; s < PW; ++s) wr[s] = wr_s[s * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < PA; ++s) ar[s] = (double)fa[4 * s];
+#pragma unroll
+            for (int s = 0; s < KSW; ++s) {
+                const double a = ar[s % PA];
+                const double b = wr[s % PW];
+                if (s + PA < KSW) ar[s % PA] = (double)fa[4 * (s + PA)];
+                if (s + PW < KSW) wr[s % PW] = wr_s[(s + PW) * 64 + lane];
+                if (s & 1)
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                else
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            double* xw = Xp + (size_t)wave * 256 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xw[r * 64] = acc0[r] + acc1[r];
+        }
+        // ---- commit the prefetched staging for the next tile: the event slots and the
+        // window buffer of `tile` were last read by gen(tile), i.e. before the barrier above;
+        // committing here keeps the prefetch registers dead during epilogue and backward ----
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int id = tid + q * nthr;
+            if (pfv[q]) s_spk[id] = pgl_decode_event(pf[q], t0 + TT, B * RP * 8);
+        }
+        if (tid < N) {                            // windows of tile+2 go to the buffer of `tile`
+            s_lo[cur + tid] = w2lo;
+            s_cnt[cur + tid] = w2cnt;
+        }
+        __syncthreads();
+
+        // ---- epilogue: the tile's 256 elements are split over its KSPLIT waves ----
+        if (active) {
+            constexpr int EPW = (KSPLIT >= 4) ? 1 : 4 / KSPLIT;      // regs handled per wave
+#pragma unroll
+            for (int e = 0; e < EPW; ++e) {
+                int r;
+                bool mine = true;
+                if (KSPLIT == 8) {
+                    r = ksl >> 1;
+                    mine = ((lane >> 5) == (ksl & 1));
+                } else if (KSPLIT == 4) {
+                    r = ksl;
+                } else {
+                    r = ksl * EPW + e;
+                }
+                double x = bias_l;
+#pragma unroll
+                for (int k2 = 0; k2 < KSPLIT; ++k2)
+                    x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
+                const long long tg = (long long)t0 + grp + 4 * r;
+                const bool vt = valid_n && (tg < p.nT) && mine;
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+                const double sc = (double)p.S[tc * N + nglob];
+                double res;
+                if (p.dbg & 4) {
+                    ll_acc += x * sc;
+                    res = vt ? x - sc : 0.0;
+                    gb_acc += res;
+                } else {
+                    pgl_epilogue(x, sc, vt, p.nlin, p.dt, ll_acc, gb_acc, res);
+                }
+                if (mine) Rb[(size_t)ptl * 256 + r * 64 + lane] = res;
+            }
+        }
+        __syncthreads();
+
+        // ---- backward on this wave's K slice ----
+        if (active && p.want_grad && !(p.dbg & 16)) {
+            double rr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr[r] = Rb[(size_t)ptl * 256 + r * 64 + lane];
+            const FT* fb = Fs + grp * rsf + kcol0 + col;
+            constexpr int NS = 4 * KTW;
+            constexpr int PD = (NS < 4) ? NS : 4;
+            double ar[PD];
+#pragma unroll
+            for (int s = 0; s < PD; ++s) ar[s] = (double)fb[(4 * (s / KTW)) * rsf + 16 * (s % KTW)];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double a = ar[s % PD];
+                if (s + PD < NS)
+                    ar[s % PD] = (double)fb[(4 * ((s + PD) / KTW)) * rsf + 16 * ((s + PD) % KTW)];
+                G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KTW], G[s % KTW], 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (active) {
+        const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
+        p.llpart[slot * 64 + lane] = ll_acc;
+        p.gbpart[slot * 64 + lane] = gb_acc;
+        if (p.want_grad) {
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + (size_t)ksl * KTW) * 256 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
             }
@@ -390,17 +873,33 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
             }
         }
     }
-    if (gid < npost) {
-        const int n = (int)gid;
-        const int pt = n >> 4, col = n & 15;
-        double sl = 0.0, sg = 0.0;
-        for (int c = 0; c < nChunks; ++c) {
-            const size_t base = ((size_t)c * nPT + pt) * 64;
-            for (int g = 0; g < 4; ++g) {
-                sl += llpart[base + g * 16 + col];
-                sg += gbpart[base + g * 16 + col];
-            }
-        }
+}
+
+// ll_n and d ll_n / d bias: one wave per neuron, lanes stride over the (chunk, lane-group)
+// partials, fixed-order butterfly -> deterministic for a given launch geometry
+__global__ __launch_bounds__(64) void k_finalize_ll(const double* __restrict__ llpart,
+                                                    const double* __restrict__ gbpart,
+                                                    double* __restrict__ ll_out,
+                                                    double* __restrict__ grad_out, int P, int npost,
+                                                    int nPT, int nChunks, int nsub)
+{
+    const int n = blockIdx.x;
+    if (n >= npost) return;
+    const int pt = n >> 4, col = n & 15;
+    const int per = 4 * nsub;
+    const int total = nChunks * per;
+    double sl = 0.0, sg = 0.0;
+    for (int i = threadIdx.x; i < total; i += 64) {
+        const int c = i / per, g = i - c * per;
+        const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
+        sl += llpart[idx];
+        sg += gbpart[idx];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o, 64);
+        sg += __shfl_xor(sg, o, 64);
+    }
+    if (threadIdx.x == 0) {
         ll_out[n] = sl;
         if (grad_out != nullptr) grad_out[(size_t)n * P] = sg;
     }
