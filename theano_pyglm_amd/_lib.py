@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpyglm_hip.so')
+LIB_PATH = os.environ.get('PYGLM_HIP_LIB', os.path.join(_HERE, 'libpyglm_hip.so'))   # env: dev A/B builds
 
 NLIN_EXP = 0
 NLIN_EXPLINEAR = 1

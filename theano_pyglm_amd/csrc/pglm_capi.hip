@@ -43,7 +43,7 @@ struct pgl_context {
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0;
     bool timing_valid = false;
 };
 
@@ -89,9 +89,12 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.f32 = h->opt_f32 != 0;
     pl.version = (h->opt_kernel == 1 || pl.f32) ? 1 : 2;
     pl.RP = h->R + 32;
-    while (pl.RP % 32 != 6) ++pl.RP;      // bank spread of the per-basis rows for ds_read_b128
+    // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
+    // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
+    while (pl.RP % 32 != (pl.version == 2 ? 8 : 6)) ++pl.RP;
     if (pl.version == 2) {
         pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
+        if (h->opt_ptw == 1 || h->opt_ptw == 2 || h->opt_ptw == 4) pl.PTW = std::min(h->opt_ptw, pl.PTW);
         pl.KSPLIT = 8 / pl.PTW;
         const int needw = (need + pl.KSPLIT - 1) / pl.KSPLIT;
         pl.KTW = 0;
@@ -270,6 +273,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     switch (option) {
     case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
     case 99: h->opt_dbg = value; return PGL_OK;
+    case 98: h->opt_ptw = value; return PGL_OK;
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }

@@ -22,6 +22,15 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 #define PGL_CAP 16          // staged spike events per presynaptic neuron and tile
+#ifndef PGL_GEN_ROWS
+#define PGL_GEN_ROWS 4       // rows per feature-generation work item (V2 kernel)
+#endif
+#ifndef PGL_GEN_NIG
+#define PGL_GEN_NIG 1        // work items a thread advances in lock-step (A/B: >1 only adds register pressure; the loop is LDS-bandwidth bound)
+#endif
+#ifndef PGL_PW
+#define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) in the V2 forward pass
+#endif
 #define PGL_MAXB 8
 
 struct FusedParams {
@@ -461,7 +470,7 @@ __device__ __forceinline__ int2 pgl_decode_event(const int2 e, const int t0, con
     return make_int2(off, __float_as_int((float)e.y));
 }
 
-template <int BB, int ROWS, typename FT>
+template <int BB, typename FT>
 __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                                           const unsigned char* __restrict__ phiBytes,
                                           const int RP, const int2* __restrict__ s_dec,
@@ -470,19 +479,21 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                                           const int2* __restrict__ spk, const int t0, const int B,
                                           const int Kimp, const int tid, const int nthr)
 {
-    constexpr int QN = 16 / ROWS;
-    const int nitems = Kimp * QN;
+    // item = (feature column, q): rows {2q, 2q+1, 8+2q, 9+2q}.  With this interleave the four
+    // q-lanes of a column read one contiguous 64-byte span of the 16-tap slice per
+    // ds_read_b128 (taps 2q,2q+1 first, taps 8+2q,9+2q second), and with RP % 32 == 8 the
+    // basis rows b = 0..3 of a neuron sit 4 slots apart: a 16-lane LDS group of one neuron
+    // covers 16 distinct 16-byte slots.  The loop is LDS-bandwidth bound.
+    const int nitems = Kimp * 4;
     const int oddoff = B * RP * 8;
     for (int item = tid; item < nitems; item += nthr) {
-        const int q = item % QN;
-        const int colx = item / QN;
+        const int q = item & 3;
+        const int colx = item >> 2;
         const int np = (BB > 0) ? colx / BB : colx / B;
         const int b = colx - np * ((BB > 0) ? BB : B);
         const int cnt = s_cnt[np];
-        const unsigned char* tb = phiBytes + (b * RP + q * ROWS) * 8;
-        double acc[ROWS];
-#pragma unroll
-        for (int t = 0; t < ROWS; ++t) acc[t] = 0.0;
+        const unsigned char* tb = phiBytes + b * RP * 8 + q * 16;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         if (cnt <= PGL_CAP) {
             const int2* sp = s_dec + np * PGL_CAP;
             for (int j = 0; j < cnt; j += 2) {
@@ -493,15 +504,15 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                 const double c1 = (double)__int_as_float(e1.y);
                 const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
                 const double2* p1 = reinterpret_cast<const double2*>(tb + e1.x);
-#pragma unroll
-                for (int h = 0; h < ROWS / 2; ++h) {
-                    const double2 v0 = p0[h];
-                    const double2 v1 = p1[h];
-                    acc[2 * h] = fma(c0, v0.x, acc[2 * h]);
-                    acc[2 * h + 1] = fma(c0, v0.y, acc[2 * h + 1]);
-                    acc[2 * h] = fma(c1, v1.x, acc[2 * h]);
-                    acc[2 * h + 1] = fma(c1, v1.y, acc[2 * h + 1]);
-                }
+                const double2 u0 = p0[0], u1 = p0[4], w0 = p1[0], w1 = p1[4];
+                a0 = fma(c0, u0.x, a0);
+                a1 = fma(c0, u0.y, a1);
+                a2 = fma(c0, u1.x, a2);
+                a3 = fma(c0, u1.y, a3);
+                a0 = fma(c1, w0.x, a0);
+                a1 = fma(c1, w0.y, a1);
+                a2 = fma(c1, w1.x, a2);
+                a3 = fma(c1, w1.y, a3);
             }
         } else {                                              // window overflowed the staging
             const int2* sp = spk + s_lo[np];
@@ -509,16 +520,18 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                 const int2 e0 = pgl_decode_event(sp[j], t0, oddoff);
                 const double c0 = (double)__int_as_float(e0.y);
                 const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
-#pragma unroll
-                for (int h = 0; h < ROWS / 2; ++h) {
-                    const double2 v0 = p0[h];
-                    acc[2 * h] = fma(c0, v0.x, acc[2 * h]);
-                    acc[2 * h + 1] = fma(c0, v0.y, acc[2 * h + 1]);
-                }
+                const double2 u0 = p0[0], u1 = p0[4];
+                a0 = fma(c0, u0.x, a0);
+                a1 = fma(c0, u0.y, a1);
+                a2 = fma(c0, u1.x, a2);
+                a3 = fma(c0, u1.y, a3);
             }
         }
-#pragma unroll
-        for (int t = 0; t < ROWS; ++t) Fs[(q * ROWS + t) * rsf + colx] = (FT)acc[t];
+        FT* fr = Fs + (2 * q) * rsf + colx;
+        fr[0] = (FT)a0;
+        fr[rsf] = (FT)a1;
+        fr[8 * rsf] = (FT)a2;
+        fr[9 * rsf] = (FT)a3;
     }
 }
 
@@ -678,13 +691,13 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
         if (!(p.dbg & 1)) {
             const unsigned char* phiBytes = reinterpret_cast<const unsigned char*>(phiE);
             if (B == 5)
-                gen_items<5, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<5, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
             else if (B == 3)
-                gen_items<3, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<3, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
             else
-                gen_items<0, 4, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<0, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
         }
         __syncthreads();
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
             const FT* fa = Fs + col * rsf + kcol0 + grp;
             const double* wr_s = wrow;
             asm volatile("" : "+s"(wr_s));
-            constexpr int PW = (KSW < 8) ? KSW : 8;
+            constexpr int PW = (KSW < PGL_PW) ? KSW : PGL_PW;
             constexpr int PA = (KSW < 4) ? KSW : 4;
             double wr[PW], ar[PA];
 #pragma unroll

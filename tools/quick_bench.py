@@ -15,6 +15,8 @@ t0 = time.time()
 p = H.Problem(N, nT, H.std_ibasis(), seed=1234, w_scale=0.5)
 print("gen %.1fs" % (time.time() - t0)); t0 = time.time()
 dev = p.device(f32=bool(f32), nchunks=nch)
+import os
+if os.environ.get('PTW'): dev.set_option(98, int(os.environ['PTW']))
 print("upload %.1fs" % (time.time() - t0), dev.info())
 for dbg in dbgs:
   dev.set_option(99, dbg)
