@@ -11,10 +11,15 @@ configuration the north-star target is quoted on), synthetic Poisson spikes.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: the post-synaptic neurons are block-partitioned over the ranks (the reference's own
-parallel pattern, parallel_coord_descent.py:137-147); S is replicated; each step ends with an
-RCCL all-gather of the per-neuron ll (1 KB) so every rank holds the population ll.  Total work
-is fixed -> "scaling": "strong".
+N>1 (total work fixed -> "scaling": "strong"), two shardings of the same evaluation:
+  --shard time (default): every rank evaluates all N neurons on its own range of time bins
+      (the likelihood is additive over time segments, population.py:41-43; features reach R bins
+      back, so the 77 MB spike matrix is replicated) and one RCCL all-reduce sums the packed
+      (ll, grad) block (N x (1+P) doubles = 657 KB).  This is the time x neuron split SURVEY
+      §8(e) prescribes when neuron sharding alone scales < 6x: feature generation is divided
+      too, whereas with neurons sharded every GPU regenerates all features.
+  --shard neurons: post-synaptic neurons block-partitioned (the reference's own pattern,
+      parallel_coord_descent.py:137-147), all-gather of the per-neuron ll (1 KB) per step.
 """
 import argparse
 import json
@@ -89,6 +94,9 @@ def main():
     ap.add_argument('--seconds', type=float, default=600.0)
     ap.add_argument('--f32-features', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', choices=['time', 'neurons'], default='time')
+    # dev-only: exercise the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo collectives)
+    ap.add_argument('--debug-single-device', action='store_true')
     args = ap.parse_args()
 
     import torch
@@ -101,10 +109,13 @@ def main():
         if rank == 0:
             sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n"
                              % (args.gpus, world))
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if args.debug_single_device else 'nccl', rank=rank,
+                                world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -125,21 +136,29 @@ def main():
     theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
     Weff = np.ones((N, N))
 
-    # neuron shard of this rank
-    n_lo = (N * rank) // world
-    n_hi = (N * (rank + 1)) // world
+    from theano_pyglm_amd import parallel as PL
     dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt, device=local_rank)
     dev.set_spikes(S)
     dev.set_basis(ib)
     if args.f32_features:
         dev.set_option(_lib.OPT_FEATURE_F32, 1)
+    if args.shard == 'time' or world == 1:
+        n_lo, n_hi = 0, N
+        t_lo, t_hi = PL.time_shard_bounds(nT, rank, world)
+        dev.set_time_range(t_lo, t_hi)
+    else:
+        n_lo, n_hi = PL.shard_bounds(N, rank, world)
+        t_lo, t_hi = 0, nT
 
     d_theta = torch.from_numpy(theta[n_lo:n_hi].copy()).cuda()
     d_Weff = torch.from_numpy(Weff).cuda()
-    d_ll = torch.zeros(n_hi - n_lo, dtype=torch.float64, device='cuda')
-    d_grad = torch.zeros((n_hi - n_lo, P), dtype=torch.float64, device='cuda')
-    if world > 1:
-        sizes = [(N * (r + 1)) // world - (N * r) // world for r in range(world)]
+    # one contiguous block [ll | grad] so that a single all-reduce moves both
+    npost = n_hi - n_lo
+    d_out = torch.zeros(npost * (1 + P), dtype=torch.float64, device='cuda')
+    d_ll = d_out[:npost]
+    d_grad = d_out[npost:].view(npost, P)
+    if world > 1 and args.shard == 'neurons':
+        sizes = [b - a for a, b in PL.all_shard_bounds(N, world)]
         gather = [torch.zeros(s, dtype=torch.float64, device='cuda') for s in sizes]
     torch.cuda.synchronize()
 
@@ -152,7 +171,18 @@ def main():
         if record:
             fused_ms.append(dev.last_timing()[0])
         if world > 1:
-            dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB over xGMI)
+            if args.debug_single_device:         # gloo: collectives on host copies
+                if args.shard == 'time':
+                    h = d_out.cpu()
+                    dist.all_reduce(h)
+                    d_out.copy_(h)
+                else:
+                    hl = [g.cpu() for g in gather]
+                    dist.all_gather(hl, d_ll.cpu())
+            elif args.shard == 'time':
+                dist.all_reduce(d_out)               # population (ll, grad) on every rank
+            else:
+                dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB)
 
     for _ in range(args.warmup):
         step(False)
@@ -167,7 +197,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if args.debug_single_device else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -195,14 +226,17 @@ def main():
                 "workload": "standard_glm N=%d T=%gs dt=1ms (nT=%d), B=%d R=%d, explinear, "
                             "Poisson 20 Hz spikes, ll+grad of all N neurons per step"
                             % (N, args.seconds, nT, B, R),
-                "sharding": "post-synaptic neurons block-partitioned over %d rank(s); S replicated; "
-                            "all-gather of ll per step" % world,
+                "sharding": ("time bins split over %d rank(s), all neurons per rank, S replicated, "
+                             "all-reduce of the packed (ll, grad) block per step" % world)
+                if (args.shard == 'time' or world == 1) else
+                            ("post-synaptic neurons block-partitioned over %d rank(s); S replicated; "
+                             "all-gather of ll per step" % world),
                 "feature_staging": "f32" if args.f32_features else "f64",
                 "spike_events": int(info['events']),
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_fused_ll_grad (rank 0 shard: %d neurons)" % (n_hi - n_lo),
+                "kernel": "k_fused2 (rank 0 shard: %d neurons x %d bins)" % (n_hi - n_lo, t_hi - t_lo),
                 "achieved": achieved,
                 "peak": F64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

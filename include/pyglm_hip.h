@@ -73,6 +73,12 @@ int pgl_set_basis(pgl_handle h, const double* ibasis);
  * fstim is (nT, Dstim) row-major; Dstim = 0 / NULL = NoStimulus (bkgd.py:29-43). */
 int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim);
 
+/* Restrict pgl_ll_grad to the bins [t_lo, t_hi) (t_lo a multiple of 16): ll and gradient
+ * become the partial sums over that range, while features still see the spikes before t_lo.
+ * The likelihood is a sum over data segments (population.py:41-43), so a time range per GPU
+ * plus an all-reduce of (ll, grad) shards one evaluation over GPUs.  Default: [0, nT). */
+int pgl_set_time_range(pgl_handle h, int64_t t_lo, int64_t t_hi);
+
 /* seval(glm.ll) and seval(g_glm_ll) for every post-synaptic neuron n in
  * [n_lo, n_hi) in one fused pass (glm.py:39-52; coord_descent.py:27-30, 52-57, 73-78;
  * population.py:71-86).  theta is ((n_hi-n_lo), P), Weff is (N,N).

@@ -177,3 +177,25 @@ def test_errors():
     d.close()
     with pytest.raises(_lib.PglError):
         _lib.DeviceGlm(4, 100, 9, 200, 'explinear', 0.001)  # B > 8
+
+
+def test_time_range_partial_sums():
+    """pgl_set_time_range: partial ll/grad over time shards add up to the full evaluation
+    (the time-sharded multi-GPU split; shards see the spikes before their range)."""
+    p = H.Problem(24, 5000, H.std_ibasis(), seed=14, weighted=True)
+    dev = p.device()
+    ll_full, g_full = dev.ll_grad(p.theta, p.Weff)
+    cuts = [0, 1616, 1632, 3200, 5000]
+    ll_sum, g_sum = 0.0, 0.0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dev.set_time_range(a, b)
+        ll, g = dev.ll_grad(p.theta, p.Weff)
+        ll_sum, g_sum = ll_sum + ll, g_sum + g
+    assert np.allclose(ll_sum, ll_full, rtol=1e-12)
+    assert H.rel_err(g_sum, g_full) < 1e-12
+    ll0, g0 = p.oracle_ll_grad()
+    assert np.allclose(ll_sum, ll0, rtol=LL_RTOL) and H.rel_err(g_sum, g0) < G_RTOL
+    from theano_pyglm_amd import _lib
+    with pytest.raises(_lib.PglError):
+        dev.set_time_range(8, 100)          # not a multiple of 16
+    dev.close()

@@ -35,7 +35,26 @@ def _worker(rank, world, port, N, out):
     total, ll_all = PL.population_ll(local_eval, N)
     lo, hi = PL.shard_bounds(N, rank, world)
     rows = PL.gather_glm_params(p.theta[lo:hi], N)
-    out.put((rank, total, ll_all, calls, rows))
+
+    # time-sharded evaluation: partial sums over this rank's bins, all-reduced
+    from oracle import glm_oracle as O
+    tcalls = []
+
+    def local_time_eval(t_lo, t_hi):
+        tcalls.append((t_lo, t_hi))
+        Sf = p.S.astype(float)
+        lls, gs = np.zeros(N), np.zeros((N, p.P))
+        for n in range(N):
+            th = p.theta[n]
+            ll, gb, _, gw = O.glm_ll_grad(n, Sf[t_lo:t_hi], p.fS[t_lo:t_hi], th[1:].reshape(N, p.B),
+                                          p.Weff[:, n], th[0], p.dt, p.kind)
+            lls[n] = ll
+            gs[n, 0] = gb
+            gs[n, 1:] = gw.reshape(-1)
+        return lls, gs
+
+    ll_t, g_t = PL.population_ll_grad_time_sharded(local_time_eval, p.nT)
+    out.put((rank, total, ll_all, calls, rows, ll_t, g_t, tcalls))
     dist.destroy_process_group()
 
 
@@ -53,15 +72,22 @@ def test_sharded_population_ll(N):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     p = H.Problem(N, 700, H.std_ibasis(), seed=50, weighted=True)
-    ll0 = p.oracle_ll_grad()[0]
-    for rank, total, ll_all, calls, rows in res:
+    ll0, g0 = p.oracle_ll_grad()
+    for rank, total, ll_all, calls, rows, ll_t, g_t, tcalls in res:
         assert np.allclose(ll_all, ll0, rtol=1e-13) and np.isclose(total, ll0.sum(), rtol=1e-13)
         assert calls == [((N * rank) // 2, (N * (rank + 1)) // 2)]      # only its own shard
         assert np.array_equal(rows, p.theta)
+        assert np.allclose(ll_t, ll0, rtol=1e-12) and H.rel_err(g_t, g0) < 1e-12
+        assert tcalls == [(0, 352)] if rank == 0 else tcalls == [(352, 700)]
 
 
 def test_shard_bounds_cover():
     from theano_pyglm_amd import parallel as PL
+    for nT, G in ((600000, 8), (700, 2), (1000, 3), (17, 4)):
+        b = [PL.time_shard_bounds(nT, r, G) for r in range(G)]
+        assert b[0][0] == 0 and b[-1][1] == nT
+        assert all(b[i][1] == b[i + 1][0] for i in range(G - 1))
+        assert all(lo % 16 == 0 for lo, hi in b)
     for N, G in ((128, 8), (7, 3), (4, 8)):
         b = PL.all_shard_bounds(N, G)
         assert b[0][0] == 0 and b[-1][1] == N

@@ -22,7 +22,7 @@ OPT_KERNEL = 3
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     'pgl_last_error', 'pgl_version', 'pgl_device_count', 'pgl_create', 'pgl_destroy',
-    'pgl_set_option', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
+    'pgl_set_option', 'pgl_set_time_range', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
     'pgl_set_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info',
@@ -56,6 +56,7 @@ def load():
                                C.POINTER(vp)]
     lib.pgl_destroy.argtypes = [vp]
     lib.pgl_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.pgl_set_time_range.argtypes = [vp, C.c_int64, C.c_int64]
     lib.pgl_set_spikes_u8.argtypes = [vp, vp]
     lib.pgl_set_spikes_f64.argtypes = [vp, vp]
     lib.pgl_set_basis.argtypes = [vp, vp]
@@ -134,6 +135,10 @@ class DeviceGlm(object):
     # -- data ---------------------------------------------------------------
     def set_option(self, opt, value):
         _chk(self.lib.pgl_set_option(self.h, int(opt), int(value)))
+
+    def set_time_range(self, t_lo, t_hi):
+        """Evaluate only bins [t_lo, t_hi) (partial ll / gradient; t_lo multiple of 16)."""
+        _chk(self.lib.pgl_set_time_range(self.h, int(t_lo), int(t_hi)))
 
     def set_spikes(self, S):
         S = np.asarray(S)

@@ -44,6 +44,7 @@ struct pgl_context {
     int gibbs_npost = -1;
     double gibbs_bias = 0;
     int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0;
+    int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
 };
 
@@ -72,7 +73,8 @@ static void release(DevBuf& b)
 
 struct Plan {
     int npost, nPT, wpb, nPB, KT, KS, rsf, RP, nTiles, nChunks, tilesPerChunk, blocks, threads;
-    int version, PTW, KTW, KSPLIT;      // version 2: 8 waves, K split over KSPLIT waves per post tile
+    int tile0;
+    int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
     size_t lds;
     bool f32;
 };
@@ -87,15 +89,26 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.nPT = (pl.npost + 15) / 16;
     const int need = (h->Ktot + 15) / 16;
     pl.f32 = h->opt_f32 != 0;
-    pl.version = (h->opt_kernel == 1 || pl.f32) ? 1 : 2;
+    // version 2: f64 features, 8 waves (2 per SIMD), one workgroup per CU
+    // version 3: f32 features (PGL_OPT_FEATURE_F32), 4 waves, two workgroups per CU
+    // version 1: the 4-wave kernel of the first round (PGL_OPT_KERNEL = 1)
+    pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
     pl.RP = h->R + 32;
-    // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
-    // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
-    while (pl.RP % 32 != (pl.version == 2 ? 8 : 6)) ++pl.RP;
-    if (pl.version == 2) {
+    if (pl.version == 3) {
+        while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
+    } else {
+        // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
+        // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
+        while (pl.RP % 32 != (pl.version == 2 ? 8 : 6)) ++pl.RP;
+    }
+    pl.cap = (pl.version == 3) ? 12 : PGL_CAP;
+    if (pl.version >= 2) {
+        const int nw = (pl.version == 3) ? 4 : 8;
+        const int maxptw = (pl.version == 3) ? 2 : 4;
         pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
+        pl.PTW = std::min(pl.PTW, maxptw);
         if (h->opt_ptw == 1 || h->opt_ptw == 2 || h->opt_ptw == 4) pl.PTW = std::min(h->opt_ptw, pl.PTW);
-        pl.KSPLIT = 8 / pl.PTW;
+        pl.KSPLIT = nw / pl.PTW;
         const int needw = (need + pl.KSPLIT - 1) / pl.KSPLIT;
         pl.KTW = 0;
         for (int k : kKTW)
@@ -107,7 +120,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
             return fail(PGL_ERR_UNSUPPORTED,
                         "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
         pl.KT = pl.KTW * pl.KSPLIT;
-        pl.wpb = 8;
+        pl.wpb = nw;
         pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
     } else {
         pl.PTW = 0; pl.KTW = 0; pl.KSPLIT = 1;
@@ -126,24 +139,32 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
-    pl.nTiles = h->nT16;
-    int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, h->numCU / pl.nPB);
+    pl.tile0 = (int)(h->t_lo / 16);
+    pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
+    const int wgPerCU = (pl.version == 3) ? 2 : 1;
+    int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
     pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
     pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
     pl.blocks = pl.nChunks * pl.nPB;
     pl.threads = 64 * pl.wpb;
-    size_t off = ((size_t)16 * pl.rsf * (pl.f32 ? 4 : 8) + 15) & ~(size_t)15;
-    off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;
-    off += (size_t)h->N * PGL_CAP * 8;
-    if (pl.version == 2) {
+    const size_t esz = pl.f32 ? 4 : 8;
+    size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
+    if (pl.version == 1 && pl.f32)
+        off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;       // V1 keeps f64 tables
+    else
+        off += (((size_t)2 * h->B * pl.RP * esz) + 15) & ~(size_t)15;
+    off += (size_t)h->N * pl.cap * 8;
+    if (pl.version >= 2) {
         off += 2 * ((((size_t)2 * h->N * 4) + 15) & ~(size_t)15);
-        off += (size_t)8 * 256 * 8 + (size_t)pl.PTW * 256 * 8;
-        if (h->N * PGL_CAP > 4 * 512) return fail(PGL_ERR_UNSUPPORTED, "N > 128 neurons");
+        off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8;
+        if (h->N > 128) return fail(PGL_ERR_UNSUPPORTED, "N > 128 neurons");
     } else {
         off += 2 * ((((size_t)h->N * 4) + 15) & ~(size_t)15);
     }
     pl.lds = off;
+    if (pl.version == 3 && pl.lds > 80 * 1024)
+        return fail(PGL_ERR_UNSUPPORTED, "f32-feature kernel needs <= 80 KB LDS per workgroup");
     if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
     return PGL_OK;
 }
@@ -173,38 +194,46 @@ static hipError_t launch_fused_kt(const Plan& pl, const FusedParams& fp, hipStre
     return hipErrorInvalidValue;
 }
 
-template <int KTW, int PTW>
+template <int KTW, int PTW, int NW, int CAP, typename FT>
 static hipError_t launch_fused2_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
-    auto kern = k_fused2<KTW, PTW, double>;
+    auto kern = k_fused2<KTW, PTW, NW, CAP, FT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NW * 64), pl.lds, s, fp);
     return hipGetLastError();
 }
 
-template <int PTW>
+template <int PTW, int NW, int CAP, typename FT>
 static hipError_t launch_fused2_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    constexpr int KSPLIT = NW / PTW;
     switch (pl.KTW) {
-    case 1: return launch_fused2_t<1, PTW>(pl, fp, s);
-    case 2: return launch_fused2_t<2, PTW>(pl, fp, s);
-    case 3: return launch_fused2_t<3, PTW>(pl, fp, s);
-    case 5: return launch_fused2_t<5, PTW>(pl, fp, s);
-    case 7: if constexpr (PTW >= 2) return launch_fused2_t<7, PTW>(pl, fp, s); break;
-    case 10: if constexpr (PTW >= 2) return launch_fused2_t<10, PTW>(pl, fp, s); break;
-    case 20: if constexpr (PTW >= 4) return launch_fused2_t<20, PTW>(pl, fp, s); break;
+    case 1: return launch_fused2_t<1, PTW, NW, CAP, FT>(pl, fp, s);
+    case 2: return launch_fused2_t<2, PTW, NW, CAP, FT>(pl, fp, s);
+    case 3: return launch_fused2_t<3, PTW, NW, CAP, FT>(pl, fp, s);
+    case 5: return launch_fused2_t<5, PTW, NW, CAP, FT>(pl, fp, s);
+    case 7: if constexpr (7 * KSPLIT <= 40) return launch_fused2_t<7, PTW, NW, CAP, FT>(pl, fp, s); break;
+    case 10: if constexpr (10 * KSPLIT <= 40) return launch_fused2_t<10, PTW, NW, CAP, FT>(pl, fp, s); break;
+    case 20: if constexpr (20 * KSPLIT <= 40) return launch_fused2_t<20, PTW, NW, CAP, FT>(pl, fp, s); break;
     }
     return hipErrorInvalidValue;
 }
 
 static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.version == 3) {
+        switch (pl.PTW) {
+        case 1: return launch_fused2_k<1, 4, 12, float>(pl, fp, s);
+        case 2: return launch_fused2_k<2, 4, 12, float>(pl, fp, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.PTW) {
-    case 1: return launch_fused2_k<1>(pl, fp, s);
-    case 2: return launch_fused2_k<2>(pl, fp, s);
-    case 4: return launch_fused2_k<4>(pl, fp, s);
+    case 1: return launch_fused2_k<1, 8, PGL_CAP, double>(pl, fp, s);
+    case 2: return launch_fused2_k<2, 8, PGL_CAP, double>(pl, fp, s);
+    case 4: return launch_fused2_k<4, 8, PGL_CAP, double>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -238,6 +267,7 @@ int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
     pgl_context* h = new pgl_context();
     h->N = N; h->nT = nT; h->B = B; h->R = R; h->nlin = nlin; h->dt = dt; h->device = device;
     h->Kimp = N * B; h->Ktot = h->Kimp; h->nT16 = (int)((nT + 15) / 16);
+    h->t_lo = 0; h->t_hi = nT;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->numCU = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -264,6 +294,16 @@ int pgl_destroy(pgl_handle h)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return PGL_OK;
+}
+
+int pgl_set_time_range(pgl_handle h, int64_t t_lo, int64_t t_hi)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    if (t_lo < 0 || t_hi > h->nT || t_lo >= t_hi) return fail(PGL_ERR_ARG, "bad time range");
+    if (t_lo % 16 != 0) return fail(PGL_ERR_ARG, "t_lo must be a multiple of 16 bins");
+    h->t_lo = t_lo;
+    h->t_hi = t_hi;
     return PGL_OK;
 }
 
@@ -417,7 +457,7 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
         const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
         hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
                            (double*)h->Wfrag.p, (double*)h->bias.p, h->N, h->B, h->Dstim, h->Kimp,
-                           h->Ktot, pl.KS, n_lo, pl.npost, pl.nPT);
+                           h->Ktot, pl.KS, n_lo, pl.npost, pl.nPT, pl.version >= 2 ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     FusedParams fp;
@@ -431,11 +471,13 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
     fp.rsf = pl.rsf;
     fp.RP = pl.RP;
     fp.Gpart = (double*)h->Gpart.p; fp.llpart = (double*)h->llpart.p; fp.gbpart = (double*)h->gbpart.p;
+    fp.tile0 = pl.tile0;
+    fp.t_hi = h->t_hi;
     fp.want_grad = d_grad ? 1 : 0;
     fp.dbg = h->opt_dbg;
 
     HIPCHK(hipEventRecord(h->ev[1], h->stream));
-    hipError_t e = (pl.version == 2) ? launch_fused2(pl, fp, h->stream)
+    hipError_t e = (pl.version >= 2) ? launch_fused2(pl, fp, h->stream)
                    : pl.f32        ? launch_fused_kt<float>(pl, fp, h->stream)
                                    : launch_fused_kt<double>(pl, fp, h->stream);
     if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
@@ -533,9 +575,10 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     double v[9];
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;
-    v[6] = 4.0 * (double)h->nT * (double)h->Ktot * (double)pl.npost;
+    const double nrows = (double)(h->t_hi - h->t_lo);
+    v[6] = 4.0 * nrows * (double)h->Ktot * (double)pl.npost;
     // nT*N*1 (u8 counts) + nT*Dstim*8 + params in + (ll+grad) out
-    v[7] = (double)h->nT * h->N + (double)h->nT * h->Dstim * 8.0 + 8.0 * pl.npost * P +
+    v[7] = nrows * h->N + nrows * h->Dstim * 8.0 + 8.0 * pl.npost * P +
            8.0 * pl.npost * (1.0 + P);
     v[8] = (double)h->nnz;
     for (int i = 0; i < n_info && i < 9; ++i) info[i] = v[i];

@@ -56,6 +56,8 @@ struct FusedParams {
     double* __restrict__ Gpart;          // [nChunks][nPT][KT][4][64]
     double* __restrict__ llpart;         // [nChunks][nPT][64]
     double* __restrict__ gbpart;         // [nChunks][nPT][64]
+    int tile0;                           // first 16-row tile of the evaluated time range
+    long long t_hi;                      // rows >= t_hi are excluded from ll / gradient
     int want_grad;
     int dbg;                             // timing ablation bits (results invalid when != 0)
 };
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
     // wave-uniform base (SGPR pair) + lane offset: global_load saddr form, no per-step VGPR addresses
     const double* __restrict__ wrow = p.Wfrag + ((size_t)(active ? pt : 0) * KS) * 64;
 
-    const int tile_beg = chunk * p.tilesPerChunk;
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
-    if (tile_end > p.nTiles) tile_end = p.nTiles;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
 
     __syncthreads();
 
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long tg = (long long)t0 + grp + 4 * r;
-                vt[r] = valid_n && (tg < p.nT);
+                vt[r] = valid_n && (tg < p.t_hi);
                 const long long tc = (tg < p.nT) ? tg : (p.nT - 1);      // clamped: branch-free load
                 sc[r] = (double)p.S[tc * N + nglob];
             }
@@ -463,14 +465,19 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
 // even/odd basis table, count as float} -- the even/odd select and lag arithmetic are done
 // once per event at staging time instead of once per (event, column, row block).
 // ---------------------------------------------------------------------------
+template <int ESZ>
 __device__ __forceinline__ int2 pgl_decode_event(const int2 e, const int t0, const int oddoff)
 {
     const int base = t0 - e.x - 1 + 16;                       // >= 1, < R + 16
-    const int off = (base & 1) ? (oddoff + (base - 1) * 8) : base * 8;
+    const int off = (base & 1) ? (oddoff + (base - 1) * ESZ) : base * ESZ;
     return make_int2(off, __float_as_int((float)e.y));
 }
 
-template <int BB, typename FT>
+template <typename T> struct pgl_vec2;
+template <> struct pgl_vec2<double> { typedef double2 type; };
+template <> struct pgl_vec2<float> { typedef float2 type; };
+
+template <int BB, int CAP, typename FT>
 __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                                           const unsigned char* __restrict__ phiBytes,
                                           const int RP, const int2* __restrict__ s_dec,
@@ -480,31 +487,35 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                                           const int Kimp, const int tid, const int nthr)
 {
     // item = (feature column, q): rows {2q, 2q+1, 8+2q, 9+2q}.  With this interleave the four
-    // q-lanes of a column read one contiguous 64-byte span of the 16-tap slice per
-    // ds_read_b128 (taps 2q,2q+1 first, taps 8+2q,9+2q second), and with RP % 32 == 8 the
-    // basis rows b = 0..3 of a neuron sit 4 slots apart: a 16-lane LDS group of one neuron
-    // covers 16 distinct 16-byte slots.  The loop is LDS-bandwidth bound.
+    // q-lanes of a column read one contiguous span of the 16-tap slice per LDS read (taps
+    // 2q,2q+1 first, taps 8+2q,9+2q second) and the host picks RP so that the basis rows
+    // b = 0..3 of a neuron sit one such span apart: a 16-lane LDS group of one neuron covers
+    // 16 distinct slots.  FT = double: taps, FMAs and F in f64 (ds_read_b128);
+    // FT = float (PGL_OPT_FEATURE_F32): f32 taps / FMAs / F (ds_read_b64, half the LDS bytes).
+    // The loop is LDS-bandwidth bound.
+    typedef typename pgl_vec2<FT>::type V2;
+    constexpr int ESZ = sizeof(FT);
     const int nitems = Kimp * 4;
-    const int oddoff = B * RP * 8;
+    const int oddoff = B * RP * ESZ;
     for (int item = tid; item < nitems; item += nthr) {
         const int q = item & 3;
         const int colx = item >> 2;
         const int np = (BB > 0) ? colx / BB : colx / B;
         const int b = colx - np * ((BB > 0) ? BB : B);
         const int cnt = s_cnt[np];
-        const unsigned char* tb = phiBytes + b * RP * 8 + q * 16;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (cnt <= PGL_CAP) {
-            const int2* sp = s_dec + np * PGL_CAP;
+        const unsigned char* tb = phiBytes + (b * RP + q * 2) * ESZ;
+        FT a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (cnt <= CAP) {
+            const int2* sp = s_dec + np * CAP;
             for (int j = 0; j < cnt; j += 2) {
                 const int2 e0 = sp[j];
-                int2 e1 = sp[j + 1 < PGL_CAP ? j + 1 : j];
+                int2 e1 = sp[j + 1 < CAP ? j + 1 : j];
                 if (j + 1 >= cnt) e1 = make_int2(0, 0);       // zero-weight dummy, valid offset
-                const double c0 = (double)__int_as_float(e0.y);
-                const double c1 = (double)__int_as_float(e1.y);
-                const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
-                const double2* p1 = reinterpret_cast<const double2*>(tb + e1.x);
-                const double2 u0 = p0[0], u1 = p0[4], w0 = p1[0], w1 = p1[4];
+                const FT c0 = (FT)__int_as_float(e0.y);
+                const FT c1 = (FT)__int_as_float(e1.y);
+                const V2* p0 = reinterpret_cast<const V2*>(tb + e0.x);
+                const V2* p1 = reinterpret_cast<const V2*>(tb + e1.x);
+                const V2 u0 = p0[0], u1 = p0[4], w0 = p1[0], w1 = p1[4];
                 a0 = fma(c0, u0.x, a0);
                 a1 = fma(c0, u0.y, a1);
                 a2 = fma(c0, u1.x, a2);
@@ -517,10 +528,10 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
         } else {                                              // window overflowed the staging
             const int2* sp = spk + s_lo[np];
             for (int j = 0; j < cnt; ++j) {
-                const int2 e0 = pgl_decode_event(sp[j], t0, oddoff);
-                const double c0 = (double)__int_as_float(e0.y);
-                const double2* p0 = reinterpret_cast<const double2*>(tb + e0.x);
-                const double2 u0 = p0[0], u1 = p0[4];
+                const int2 e0 = pgl_decode_event<ESZ>(sp[j], t0, oddoff);
+                const FT c0 = (FT)__int_as_float(e0.y);
+                const V2* p0 = reinterpret_cast<const V2*>(tb + e0.x);
+                const V2 u0 = p0[0], u1 = p0[4];
                 a0 = fma(c0, u0.x, a0);
                 a1 = fma(c0, u0.y, a1);
                 a2 = fma(c0, u1.x, a2);
@@ -528,10 +539,10 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
             }
         }
         FT* fr = Fs + (2 * q) * rsf + colx;
-        fr[0] = (FT)a0;
-        fr[rsf] = (FT)a1;
-        fr[8 * rsf] = (FT)a2;
-        fr[9 * rsf] = (FT)a3;
+        fr[0] = a0;
+        fr[rsf] = a1;
+        fr[8 * rsf] = a2;
+        fr[9 * rsf] = a3;
     }
 }
 
@@ -560,11 +571,11 @@ __device__ __forceinline__ void pgl_epilogue(const double x, const double s, con
     gb_acc += res_out;
 }
 
-template <int KTW, int PTW, typename FT>
-__global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
+template <int KTW, int PTW, int NW, int CAP, typename FT>
+__global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
 {
     constexpr int TT = 16;
-    constexpr int NW = 8;
+    constexpr int ESZ = sizeof(FT);              // element size of the F tile and of the basis tables
     constexpr int KSPLIT = NW / PTW;
     constexpr int KSW = KTW * 4;                 // forward k-steps of this wave
     constexpr int KS_ALL = KSW * KSPLIT;         // k-steps of the whole padded K
@@ -587,11 +598,11 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
     // LDS carve (offsets multiples of 16)
     FT* Fs = reinterpret_cast<FT*>(smem);
     size_t off = ((size_t)TT * rsf * sizeof(FT) + 15) & ~(size_t)15;
-    double* phiE = reinterpret_cast<double*>(smem + off);
-    double* phiO = phiE + (size_t)B * RP;
-    off += (((size_t)2 * B * RP * 8) + 15) & ~(size_t)15;
+    FT* phiE = reinterpret_cast<FT*>(smem + off);
+    FT* phiO = phiE + (size_t)B * RP;
+    off += (((size_t)2 * B * RP * ESZ) + 15) & ~(size_t)15;
     int2* s_spk = reinterpret_cast<int2*>(smem + off);
-    off += (size_t)N * PGL_CAP * 8;
+    off += (size_t)N * CAP * 8;
     int* s_lo = reinterpret_cast<int*>(smem + off);           // [2][N]
     off += (((size_t)2 * N * 4) + 15) & ~(size_t)15;
     int* s_cnt = reinterpret_cast<int*>(smem + off);          // [2][N]
@@ -602,8 +613,8 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
 
     for (int i = tid; i < B * RP; i += nthr) {
         const int b = i / RP, k = i - b * RP;
-        phiE[i] = (k >= 16 && k < 16 + R) ? p.phi[b * R + k - 16] : 0.0;
-        phiO[i] = (k + 1 >= 16 && k + 1 < 16 + R) ? p.phi[b * R + k + 1 - 16] : 0.0;
+        phiE[i] = (FT)((k >= 16 && k < 16 + R) ? p.phi[b * R + k - 16] : 0.0);
+        phiO[i] = (FT)((k + 1 >= 16 && k + 1 < 16 + R) ? p.phi[b * R + k + 1 - 16] : 0.0);
     }
     for (int i = tid; i < TT * rsf; i += nthr) Fs[i] = (FT)0;
 
@@ -622,9 +633,9 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
         p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
     const int kcol0 = ksl * KTW * 16;            // first feature column of this wave's slice
 
-    const int tile_beg = chunk * p.tilesPerChunk;
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
-    if (tile_end > p.nTiles) tile_end = p.nTiles;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
 
     // prologue: windows of the first two tiles, events of the first tile
     if (tid < N) {
@@ -642,16 +653,16 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
     __syncthreads();
     {
         const int pb0 = (tile_beg & 1) * N;
-        for (int id = tid; id < N * PGL_CAP; id += nthr) {
-            const int np = id / PGL_CAP, sl = id % PGL_CAP;
+        for (int id = tid; id < N * CAP; id += nthr) {
+            const int np = id / CAP, sl = id % CAP;
             const int cnt = s_cnt[pb0 + np];
-            if (cnt <= PGL_CAP && sl < cnt)
-                s_spk[id] = pgl_decode_event(p.spk[s_lo[pb0 + np] + sl], tile_beg * TT, B * RP * 8);
+            if (cnt <= CAP && sl < cnt)
+                s_spk[id] = pgl_decode_event<ESZ>(p.spk[s_lo[pb0 + np] + sl], tile_beg * TT, B * RP * ESZ);
         }
     }
     __syncthreads();
 
-    constexpr int NPF = 4;                        // prefetched event slots per thread (N*CAP <= 2048)
+    constexpr int NPF = (128 * CAP + NW * 64 - 1) / (NW * 64);   // prefetched event slots per thread (N <= 128)
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         const int t0 = tile * TT;
         const int cur = (tile & 1) * N;
@@ -664,10 +675,10 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
             const int id = tid + q * nthr;
             pfv[q] = false;
             pf[q] = make_int2(0, 0);
-            if (id < N * PGL_CAP && tile + 1 < tile_end) {
-                const int np = id / PGL_CAP, sl = id % PGL_CAP;
+            if (id < N * CAP && tile + 1 < tile_end) {
+                const int np = id / CAP, sl = id % CAP;
                 const int cnt = s_cnt[nxt + np];
-                if (cnt <= PGL_CAP && sl < cnt) {
+                if (cnt <= CAP && sl < cnt) {
                     pf[q] = p.spk[s_lo[nxt + np] + sl];
                     pfv[q] = true;
                 }
@@ -691,13 +702,13 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
         if (!(p.dbg & 1)) {
             const unsigned char* phiBytes = reinterpret_cast<const unsigned char*>(phiE);
             if (B == 5)
-                gen_items<5, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<5, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
             else if (B == 3)
-                gen_items<3, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<3, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
             else
-                gen_items<0, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
+                gen_items<0, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                     p.Kimp, tid, nthr);
         }
         __syncthreads();
@@ -709,19 +720,23 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
             const FT* fa = Fs + col * rsf + kcol0 + grp;
             const double* wr_s = wrow;
             asm volatile("" : "+s"(wr_s));
-            constexpr int PW = (KSW < PGL_PW) ? KSW : PGL_PW;
+            // Wmat fragments: one 16-byte load per lane covers two k-steps (layout
+            // [pt][ks/2][lane][2]); ring of PW2 loads = 2*PW2 MFMA steps ahead
+            constexpr int PW2 = (KSW / 2 < PGL_PW / 2) ? KSW / 2 : PGL_PW / 2;
             constexpr int PA = (KSW < 4) ? KSW : 4;
-            double wr[PW], ar[PA];
+            const double2* wr2 = reinterpret_cast<const double2*>(wr_s);
+            double2 wr[PW2];
+            double ar[PA];
 #pragma unroll
-            for (int s = 0; s < PW; ++s) wr[s] = wr_s[s * 64 + lane];
+            for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
 #pragma unroll
             for (int s = 0; s < PA; ++s) ar[s] = (double)fa[4 * s];
 #pragma unroll
             for (int s = 0; s < KSW; ++s) {
                 const double a = ar[s % PA];
-                const double b = wr[s % PW];
+                const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
                 if (s + PA < KSW) ar[s % PA] = (double)fa[4 * (s + PA)];
-                if (s + PW < KSW) wr[s % PW] = wr_s[(s + PW) * 64 + lane];
+                if ((s & 1) && (s / 2 + PW2 < KSW / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
                 if (s & 1)
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
                 else
@@ -740,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int id = tid + q * nthr;
-            if (pfv[q]) s_spk[id] = pgl_decode_event(pf[q], t0 + TT, B * RP * 8);
+            if (pfv[q]) s_spk[id] = pgl_decode_event<ESZ>(pf[q], t0 + TT, B * RP * ESZ);
         }
         if (tid < N) {                            // windows of tile+2 go to the buffer of `tile`
             s_lo[cur + tid] = w2lo;
@@ -768,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
                 for (int k2 = 0; k2 < KSPLIT; ++k2)
                     x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
                 const long long tg = (long long)t0 + grp + 4 * r;
-                const bool vt = valid_n && (tg < p.nT) && mine;
+                const bool vt = valid_n && (tg < p.t_hi) && mine;
                 const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
                 const double sc = (double)p.S[tc * N + nglob];
                 double res;
@@ -828,7 +843,8 @@ __global__ __launch_bounds__(512, 2) void k_fused2(const FusedParams p)
 // ---------------------------------------------------------------------------
 __global__ void k_prep_w(const double* __restrict__ theta, const double* __restrict__ Weff,
                          double* __restrict__ Wfrag, double* __restrict__ bias, int N, int B,
-                         int Dstim, int Kimp, int Ktot, int KS, int n_lo, int npost, int nPT)
+                         int Dstim, int Kimp, int Ktot, int KS, int n_lo, int npost, int nPT,
+                         int pair)
 {
     const int P = 1 + Dstim + Kimp;
     const long long total = (long long)nPT * KS * 64;
@@ -848,7 +864,9 @@ __global__ void k_prep_w(const double* __restrict__ theta, const double* __restr
                 v = theta[(size_t)n * P + 1 + (k - Kimp)];
             }
         }
-        Wfrag[i] = v;
+        // pair layout (V2): [pt][ks/2][lane][ks&1] so that one 16-byte load feeds two k-steps
+        const long long o = pair ? (((long long)pt * (KS / 2) + (ks >> 1)) * 64 + lane) * 2 + (ks & 1) : i;
+        Wfrag[o] = v;
     }
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < nPT * 16; n += gridDim.x * blockDim.x)
         bias[n] = (n < npost) ? theta[(size_t)n * P] : 0.0;
