@@ -90,7 +90,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     const int need = (h->Ktot + 15) / 16;
     pl.f32 = h->opt_f32 != 0;
     // version 2: f64 features, 8 waves (2 per SIMD), one workgroup per CU
-    // version 3: f32 features (PGL_OPT_FEATURE_F32), 4 waves, two workgroups per CU
+    // version 3: the same kernel with f32 features / basis taps (PGL_OPT_FEATURE_F32)
     // version 1: the 4-wave kernel of the first round (PGL_OPT_KERNEL = 1)
     pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
     pl.RP = h->R + 32;
@@ -101,10 +101,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
         // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
         while (pl.RP % 32 != (pl.version == 2 ? 8 : 6)) ++pl.RP;
     }
-    pl.cap = (pl.version == 3) ? 12 : PGL_CAP;
+    pl.cap = PGL_CAP;
     if (pl.version >= 2) {
-        const int nw = (pl.version == 3) ? 4 : 8;
-        const int maxptw = (pl.version == 3) ? 2 : 4;
+        const int nw = 8;
+        const int maxptw = 4;
         pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
         pl.PTW = std::min(pl.PTW, maxptw);
         if (h->opt_ptw == 1 || h->opt_ptw == 2 || h->opt_ptw == 4) pl.PTW = std::min(h->opt_ptw, pl.PTW);
@@ -141,7 +141,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
     pl.tile0 = (int)(h->t_lo / 16);
     pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
-    const int wgPerCU = (pl.version == 3) ? 2 : 1;
+    const int wgPerCU = 1;
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
     pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
@@ -157,14 +157,12 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
     off += (size_t)h->N * pl.cap * 8;
     if (pl.version >= 2) {
         off += 2 * ((((size_t)2 * h->N * 4) + 15) & ~(size_t)15);
-        off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8;
+        off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8 + 256;
         if (h->N > 128) return fail(PGL_ERR_UNSUPPORTED, "N > 128 neurons");
     } else {
         off += 2 * ((((size_t)h->N * 4) + 15) & ~(size_t)15);
     }
     pl.lds = off;
-    if (pl.version == 3 && pl.lds > 80 * 1024)
-        return fail(PGL_ERR_UNSUPPORTED, "f32-feature kernel needs <= 80 KB LDS per workgroup");
     if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
     return PGL_OK;
 }
@@ -225,8 +223,9 @@ static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream
 {
     if (pl.version == 3) {
         switch (pl.PTW) {
-        case 1: return launch_fused2_k<1, 4, 12, float>(pl, fp, s);
-        case 2: return launch_fused2_k<2, 4, 12, float>(pl, fp, s);
+        case 1: return launch_fused2_k<1, 8, PGL_CAP, float>(pl, fp, s);
+        case 2: return launch_fused2_k<2, 8, PGL_CAP, float>(pl, fp, s);
+        case 4: return launch_fused2_k<4, 8, PGL_CAP, float>(pl, fp, s);
         }
         return hipErrorInvalidValue;
     }

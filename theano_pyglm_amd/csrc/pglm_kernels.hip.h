@@ -106,9 +106,8 @@ __device__ __forceinline__ double pgl_rcp(const double b)
 }
 
 // exp(y): k = rint(y/ln2), r = y - k ln2 (hi/lo split), degree-13 Taylor in |r| <= 0.347, ldexp
-__device__ __forceinline__ double pgl_exp(const double y)
+__device__ __forceinline__ double pgl_exp(const double y, const double* __restrict__ C)
 {
-    const double* __restrict__ C = PGL_C;
     const double k = rint(y * C[0]);
     double r = fma(-k, C[1], y);
     r = fma(-k, C[2], r);
@@ -124,11 +123,10 @@ __device__ __forceinline__ double pgl_exp(const double y)
 
 // log(v) for v >= 0 (fdlibm e_log.c scheme: v = 2^e m, m in [sqrt(1/2), sqrt 2),
 // s = f/(2+f), 7-term polynomial in s^2); log(0) = -inf, inf/NaN pass through
-__device__ __forceinline__ double pgl_log(const double v)
+__device__ __forceinline__ double pgl_log(const double v, const double* __restrict__ C)
 {
     double m = __builtin_amdgcn_frexp_mant(v);    // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(v);
-    const double* __restrict__ C = PGL_C;
     const bool lt = m < C[21];
     m = lt ? m + m : m;
     e = lt ? e - 1 : e;
@@ -158,32 +156,33 @@ __device__ __forceinline__ double pgl_log(const double v)
 // when every lane of the wave has exp(-|x|) < 9.6e-5 (|x| > 9.25, the operating regime of
 // standard_glm's bias ~ 20) log1p and 1/(1+e) come from their alternating series (error < e^6).
 __device__ __forceinline__ void pgl_rate_terms(const double x, const double s, const int nlin,
-                                               const double dt, double& term, double& res)
+                                               const double dt, double& term, double& res,
+                                               const double* __restrict__ C)
 {
     if (nlin == 1) {
-        const double e = pgl_exp(-fabs(x));
+        const double e = pgl_exp(-fabs(x), C);
         double l1p, inv;
-        if (__all(e < PGL_C[23])) {
-            l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), PGL_C[22]), 0.5), 1.0);
+        if (__all(e < C[23])) {
+            l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), C[22]), 0.5), 1.0);
             inv = fma(-e, fma(-e, fma(-e, fma(-e, fma(-e, 1.0, 1.0), 1.0), 1.0), 1.0), 1.0);
         } else {
             const double u = 1.0 + e;
             inv = pgl_rcp(u);
-            l1p = pgl_log(u) + (e - (u - 1.0)) * inv;
+            l1p = pgl_log(u, C) + (e - (u - 1.0)) * inv;
         }
         const double lam = fmax(x, 0.0) + l1p;
         const double sig = (x >= 0.0) ? inv : e * inv;
         term = -dt * lam;
         res = -dt * sig;
         if (s > 0.0) {
-            term = fma(pgl_log(lam), s, term);
+            term = fma(pgl_log(lam, C), s, term);
             res = (-dt + s * pgl_rcp(lam)) * sig;
         }
         // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52)
         term = (lam == 0.0) ? __builtin_nan("") : term;
         res = (x != x) ? x : res;
     } else {
-        const double lam = pgl_exp(x);
+        const double lam = pgl_exp(x, C);
         term = fma(x, s, -dt * lam);
         res = fma(-dt, lam, s);
     }
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
                     term = x * sc[r];
                     res = x - sc[r];
                 } else {
-                    pgl_rate_terms(x, sc[r], p.nlin, p.dt, term, res);
+                    pgl_rate_terms(x, sc[r], p.nlin, p.dt, term, res, PGL_C);
                 }
                 ll_acc += vt[r] ? term : 0.0;
                 rr[r] = vt[r] ? res : 0.0;
@@ -562,10 +561,11 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void pgl_epilogue(const double x, const double s, const bool valid,
                                              const int nlin, const double dt, double& ll_acc,
-                                             double& gb_acc, double& res_out)
+                                             double& gb_acc, double& res_out,
+                                             const double* __restrict__ C)
 {
     double term, res;
-    pgl_rate_terms(x, s, nlin, dt, term, res);
+    pgl_rate_terms(x, s, nlin, dt, term, res, C);
     ll_acc += valid ? term : 0.0;
     res_out = valid ? res : 0.0;
     gb_acc += res_out;
@@ -610,6 +610,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
     double* Xp = reinterpret_cast<double*>(smem + off);       // [NW][4][64] partial X
     off += (size_t)NW * 256 * 8;
     double* Rb = reinterpret_cast<double*>(smem + off);       // [PTW][4][64] residuals r
+    off += (size_t)PTW * 256 * 8;
+    double* Cs = reinterpret_cast<double*>(smem + off);       // [32] math constants (see epilogue)
+    if (tid < 32) Cs[tid] = PGL_C[tid];
 
     for (int i = tid; i < B * RP; i += nthr) {
         const int b = i / RP, k = i - b * RP;
@@ -792,7 +795,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                     res = vt ? x - sc : 0.0;
                     gb_acc += res;
                 } else {
-                    pgl_epilogue(x, sc, vt, p.nlin, p.dt, ll_acc, gb_acc, res);
+                    // constants come from LDS through an opaque pointer: as literals or hoisted
+                    // scalar loads they pin ~50 registers for the whole kernel and spill
+                    const double* Cl = Cs;
+                    asm volatile("" : "+v"(Cl));
+                    pgl_epilogue(x, sc, vt, p.nlin, p.dt, ll_acc, gb_acc, res, Cl);
                 }
                 if (mine) Rb[(size_t)ptl * 256 + r * 64 + lane] = res;
             }
