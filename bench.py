@@ -57,6 +57,25 @@ def standard_ibasis(R=200):
     return ib
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_bench.sh).
+    FETCH_SIZE is taken at face value: on this access pattern (byte / 4-byte / 8-byte loads, no
+    16-B streams) the guide's x2 correction does not apply -- calibrated on k_transpose_u8, whose
+    76.8 MB read is reported as 76.8 MB (profiles/r01_v1_pmc_hbm.json)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+                best = (f, (v['FETCH_SIZE']['avg'] + v['WRITE_SIZE']['avg']) * 1024.0)
+    return best
+
+
 def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     """Oracle C port (oracle/glm_oracle.c: the reference's per-neuron dataflow on
     materialised features) timed single-threaded on a bounded sample: the first
@@ -247,6 +266,11 @@ def main():
                 "algorithmic_bytes_per_launch": info['bytes'],
             },
         }
+        if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
+            tr = pmc_traffic('void k_fused2<20, 4, 8, 16, double>')
+            if tr is not None:
+                out["roofline"]["traffic"] = tr[1]
+                out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         print(json.dumps(out))
