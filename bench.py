@@ -76,6 +76,29 @@ def pmc_traffic(kernel_prefix):
     return best
 
 
+def map_wall_clock(S, N, dt):
+    """Secondary metric (BASELINE.json "MAP wall-clock"): one
+    coord_descent(maxiter=1) sweep of standard_glm on the same spike matrix = all N per-neuron
+    BFGS fits (<= 225 iterations each, coord_descent.py:161-204) advanced in lock-step with the
+    optimizer state on the GPU; excludes data generation / upload."""
+    import copy
+    from theano_pyglm_amd.models.model_factory import make_model
+    from theano_pyglm_amd.population import Population
+    from theano_pyglm_amd.inference import coord_descent as cd
+    popn = Population(make_model('standard_glm', N=N, dt=dt))
+    popn.add_data({'S': S, 'N': N, 'dt': dt, 'T': S.shape[0] * dt, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(0))
+    lp0 = popn.compute_log_p(x0)
+    t0 = time.perf_counter()
+    x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+    wall = time.perf_counter() - t0
+    lp1 = popn.compute_log_p(x)
+    popn.release_data()
+    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": wall,
+            "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
+            "optimizer": "lock-step batched BFGS, maxiter 225, GPU-resident state"}
+
+
 def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     """Oracle C port (oracle/glm_oracle.c: the reference's per-neuron dataflow on
     materialised features) timed single-threaded on a bounded sample: the first
@@ -113,6 +136,7 @@ def main():
     ap.add_argument('--seconds', type=float, default=600.0)
     ap.add_argument('--f32-features', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
     ap.add_argument('--shard', choices=['time', 'neurons'], default='time')
     # dev-only: exercise the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo collectives)
     ap.add_argument('--debug-single-device', action='store_true')
@@ -271,6 +295,8 @@ def main():
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
+        if world == 1 and not args.no_map and not args.f32_features:
+            out["secondary"] = map_wall_clock(S, N, dt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         print(json.dumps(out))

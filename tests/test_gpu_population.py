@@ -99,6 +99,10 @@ def test_fit_glm_and_coord_descent(std4):
     assert lp_seq > lp0 + 1.0 and lp_bat > lp0 + 1.0
     # both optimisers reach the same concave optimum
     assert abs(lp_seq - lp_bat) < 1e-2 * max(1.0, abs(lp_seq) * 1e-3)
+    # GPU-resident optimizer state (torch plumbing around the same HIP ll+grad)
+    x_t = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+    lp_t = popn.compute_log_p(x_t)
+    assert abs(lp_t - lp_bat) < 1e-6 * max(1.0, abs(lp_bat))
     # and the oracle agrees on the fitted state
     assert np.allclose(lp_bat, oracle_log_p(popn, data, x_bat)[0], rtol=1e-9)
 

@@ -36,6 +36,30 @@ class PglError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip():
+    """One HIP runtime per process.  PyTorch (used for device tensors / torch.distributed by
+    bench.py, parallel.py and the GPU-resident optimizer) bundles its own libamdhip64 /
+    libhsa-runtime64 with the same SONAMEs as the system ROCm ones this library links to.  If the
+    system copies are mapped first, a later `import torch` resolves its HIP symbols against them
+    and cannot initialise ("No HIP GPUs are available"); mapped in the other order everything
+    works.  So when torch is installed its runtime is mapped before libpyglm_hip.so -- without
+    importing torch."""
+    if os.environ.get('PYGLM_NO_TORCH_PRELOAD'):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+        for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libpyglm_hip.so (once).  Fails loudly when it has not been built."""
     global _lib
@@ -45,6 +69,7 @@ def load():
         raise PglError("HIP library %s not found: run `python -c 'import __graft_entry__ as g; "
                        "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
                        % LIB_PATH)
+    _preload_torch_hip()
     lib = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p

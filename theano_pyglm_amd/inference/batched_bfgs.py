@@ -1,0 +1,147 @@
+"""
+Lock-step BFGS for all neurons with the optimizer state resident on the GPU.
+
+For standard_glm-like models (LinearBasisImpulses + No/Basis stimulus) the packed
+per-neuron vector of coord_descent ([bias, w_stim, w_ir]) *is* the flat
+feature-weight row the device kernel consumes, and the N per-neuron MAP problems are
+independent (constant weights / complete graph).  So the whole sweep of
+coord_descent.fit_glm over n = 0..N-1 (coord_descent.py:161-204, 243-247) runs as one
+batched BFGS: per iteration one fused ll+grad launch on device pointers, the priors and the
+dense inverse-Hessian updates (M x P x P) as torch tensor ops on the same GPU -- nothing but
+a few scalars crosses PCIe.  PyTorch is plumbing here (device memory + batched BLAS); the
+likelihood and its gradient come from the HIP kernels.
+
+NaN semantics of fit_glm are kept: nll NaN -> 1e16, NaN gradient -> 0 (coord_descent.py:170-182).
+"""
+import numpy as np
+
+from theano_pyglm_amd.components.bkgd import NoStimulus, BasisStimulus
+from theano_pyglm_amd.components.impulse import LinearBasisImpulses
+from theano_pyglm_amd.components.priors import Gaussian, GroupLasso
+
+
+def supported(population):
+    glm = population.glm
+    return isinstance(glm.imp_model, LinearBasisImpulses) and \
+        isinstance(glm.bkgd_model, (NoStimulus, BasisStimulus))
+
+
+def _prior_terms(population, torch, X):
+    """log prior (M,) and its gradient (M,P) of the rows [bias, w_stim, w_ir] in torch."""
+    glm = population.glm
+    N, B, D = population.N, glm.imp_model.B, glm.Dstim
+    b = X[:, 0]
+    mu_b, sg_b = float(glm.bias_model.mu_bias), float(glm.bias_model.sig_bias)
+    lp = -0.5 / sg_b ** 2 * (b - mu_b) ** 2                                   # bias.py:33
+    G = torch.zeros_like(X)
+    G[:, 0] = -(b - mu_b) / sg_b ** 2
+    if D > 0:                                                                 # bkgd.py:76
+        ws = X[:, 1:1 + D]
+        lp = lp - 0.5 / (0.01 ** 2) * (ws ** 2).sum(1)
+        G[:, 1:1 + D] = -ws / (0.01 ** 2)
+    w = X[:, 1 + D:].reshape(-1, N, B)
+    pr = glm.imp_model.prior
+    if isinstance(pr, GroupLasso):                                            # priors.py:202
+        z = (w - float(pr.mu)) / float(pr.sigma)
+        nrm = torch.sqrt((z ** 2).sum(2, keepdim=True))
+        lp = lp - float(pr.lam) * nrm.sum((1, 2))
+        G[:, 1 + D:] = (-float(pr.lam) * z / nrm / float(pr.sigma)).reshape(X.shape[0], -1)   # 0/0 -> NaN
+    elif isinstance(pr, Gaussian):                                            # priors.py:139
+        lp = lp - 0.5 / float(pr.sigma) ** 2 * ((w - float(pr.mu)) ** 2).sum((1, 2))
+        G[:, 1 + D:] = (-(w - float(pr.mu)) / float(pr.sigma) ** 2).reshape(X.shape[0], -1)
+    else:
+        raise Exception("unsupported impulse prior for the batched GPU optimizer")
+    return lp, G
+
+
+def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False):
+    """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations)."""
+    import torch
+    if not supported(population):
+        raise Exception("batched GPU BFGS needs LinearBasisImpulses and No/Basis stimulus")
+    N = population.N
+    n_hi = N if n_hi is None else n_hi
+    M = n_hi - n_lo
+    dev = torch.device('cuda', population.device)
+    handles = []
+    for data in population.data_sequences:
+        population.set_data(data)
+        handles.append(population._handle(data))
+    X = torch.tensor(population.theta_matrix(x, n_lo, n_hi), dtype=torch.float64, device=dev)
+    P = X.shape[1]
+    Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
+    ll = torch.zeros(M, dtype=torch.float64, device=dev)
+    gr = torch.zeros((M, P), dtype=torch.float64, device=dev)
+    n_evals = [0]
+
+    def evaluate(Xt):
+        Xt = Xt.contiguous()
+        lp, G = _prior_terms(population, torch, Xt)
+        torch.cuda.current_stream(dev).synchronize()
+        for h in handles:
+            h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(), gr.data_ptr(), n_lo, n_hi)
+            h.sync()
+            lp = lp + ll
+            G = G + gr
+        n_evals[0] += 1
+        f, g = -lp, -G
+        f = torch.where(torch.isnan(f), torch.full_like(f, 1e16), f)
+        bad = torch.isnan(g).any(1)
+        g = torch.where(bad[:, None], torch.zeros_like(g), g)
+        return f, g
+
+    f, g = evaluate(X)
+    H = torch.eye(P, dtype=torch.float64, device=dev).repeat(M, 1, 1)
+    active = g.abs().amax(1) > gtol
+    it = 0
+    while it < maxiter and bool(active.any()):
+        it += 1
+        p = -torch.bmm(H, g[:, :, None])[:, :, 0]
+        slope = (p * g).sum(1)
+        bad = slope >= 0
+        if bool(bad.any()):
+            H[bad] = torch.eye(P, dtype=torch.float64, device=dev)
+            p = torch.where(bad[:, None], -g, p)
+            slope = (p * g).sum(1)
+        alpha = torch.ones(M, dtype=torch.float64, device=dev)
+        if it == 1:
+            alpha = torch.clamp(1.0 / g.norm(dim=1).clamp_min(1e-300), max=1.0)
+        done = ~active
+        Xn, fn, gn = X.clone(), f.clone(), g.clone()
+        for _ls in range(30):
+            Xt = torch.where(done[:, None], Xn, X + alpha[:, None] * p)
+            ft, gt = evaluate(Xt)
+            ok = (~done) & (ft <= f + 1e-4 * alpha * slope)
+            Xn = torch.where(ok[:, None], Xt, Xn)
+            fn = torch.where(ok, ft, fn)
+            gn = torch.where(ok[:, None], gt, gn)
+            done = done | ok
+            if bool(done.all()):
+                break
+            alpha = torch.where(done, alpha, alpha * 0.5)
+        stalled = ~done
+        s = Xn - X
+        y = gn - g
+        sy = (s * y).sum(1)
+        upd = active & (~stalled) & (sy > 1e-12)
+        if bool(upd.any()):
+            rho = torch.where(upd, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy))
+            Hy = torch.bmm(H, y[:, :, None])[:, :, 0]
+            yHy = (y * Hy).sum(1)
+            c = (1.0 + rho * yHy) * rho
+            H += c[:, None, None] * (s[:, :, None] * s[:, None, :])
+            H -= rho[:, None, None] * (Hy[:, :, None] * s[:, None, :] + s[:, :, None] * Hy[:, None, :])
+        X, f, g = Xn, fn, gn
+        active = active & (~stalled) & (g.abs().amax(1) > gtol)
+        if verbose:
+            print("batched BFGS iter %d: active %d, mean nlp %.3f, evals %d"
+                  % (it, int(active.sum()), float(f.mean()), n_evals[0]))
+    Xh = X.cpu().numpy()
+    D = population.glm.Dstim
+    for i, n in enumerate(range(n_lo, n_hi)):
+        xn = x['glms'][n]
+        xn['bias']['bias'] = Xh[i, 0:1].copy()
+        if D > 0:
+            xn['bkgd']['w_stim'] = Xh[i, 1:1 + D].copy()
+        xn['imp']['w_ir'] = Xh[i, 1 + D:].copy()
+    return f.cpu().numpy(), it, n_evals[0]

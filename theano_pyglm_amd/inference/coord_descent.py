@@ -11,8 +11,9 @@ ll+grad kernel plus closed-form prior gradients.
 For standard_glm-like models (constant weights, complete graph) the N per-neuron problems
 are independent, so `fit_glms_batched` advances all of them in lock-step:
 one fused device pass per iteration evaluates ll and gradient of every neuron at its own
-trial point.  `coord_descent(..., batched=True)` uses it; the default reproduces the
-reference's sequential sweep.
+trial point.  `coord_descent(..., batched=True)` uses it (optimizer state in numpy),
+`batched='torch'` keeps the optimizer state on the GPU (inference/batched_bfgs.py); the
+default reproduces the reference's sequential sweep.
 """
 import copy
 
@@ -228,7 +229,10 @@ def coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=False, ver
     it = 0
     while not converged and it < maxiter:
         it += 1
-        if batched:
+        if batched == 'torch':
+            from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+            fit_glms_batched_torch(population, x, verbose=verbose)
+        elif batched:
             fit_glms_batched(population, x, verbose=verbose)
         else:
             for n in np.arange(N):
