@@ -226,6 +226,9 @@ def main():
                 dist.all_reduce(d_out)               # population (ll, grad) on every rank
             else:
                 dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB)
+            # the collective runs on torch's stream, the next evaluation on the library's own
+            # stream: finish the collective before d_out / d_ll are overwritten
+            torch.cuda.current_stream().synchronize()
 
     for _ in range(args.warmup):
         step(False)
