@@ -48,7 +48,13 @@ def main():
     popn = Population(model)
     popn.add_data(data)
     rng = np.random.RandomState(0)
-    gibbs_network_sweeps(popn, popn.sample(rng), args.N_samples, rng)
+    # The reference initialises MCMC from a MAP fit converted to this model
+    # (gibbs.py:2490-2507); a raw prior draw of W ~ N(0,1) can drive every quadrature node to
+    # lam = 0 ("log_G not finie", gibbs.py:1024-1026).  Start from a prior draw with the weights
+    # shrunk towards zero instead.
+    x0 = popn.sample(rng)
+    x0['net']['weights']['W'] = 0.05 * x0['net']['weights']['W']
+    gibbs_network_sweeps(popn, x0, args.N_samples, rng)
 
 
 if __name__ == '__main__':
