@@ -39,6 +39,7 @@ struct pgl_context {
     bool have_spikes = false, have_basis = false;
     int64_t nnz = 0;
     DevBuf S, ST, spk, wlo, whi, phi, fstim;
+    std::vector<int> h_ptr;              // host copy of the event-list row pointers (N+1)
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart;
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
@@ -371,6 +372,7 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->nnz = nnz;
+    h->h_ptr = cnt;
     h->have_spikes = true;
     h->gibbs_npost = -1;
     return PGL_OK;
@@ -664,20 +666,27 @@ static int run_ll_current(pgl_handle h, const double* d_base, const double* d_st
                           const double* d_col, int n_post, double bias, double aw_cur,
                           const double* w, int K, double* ll_out)
 {
-    const int nblocks = 1024;
-    ENSURE(h->part, (size_t)nblocks * PGL_KMAX * 8);
+    // blocks of the streaming part; the spike-bin part writes one more partial row
+    const int nblocks = (int)std::min<int64_t>(1024, (h->nT + 255) / 256);
+    const int e_lo = h->h_ptr[n_post], e_hi = h->h_ptr[n_post + 1];
+    const int sblocks = std::max(1, std::min(256, (e_hi - e_lo + 255) / 256));
+    ENSURE(h->part, (size_t)(nblocks + sblocks) * PGL_KMAX * 8);
     ENSURE(h->outK, PGL_KMAX * 8);
     ENSURE(h->wsmall, std::max<size_t>((size_t)h->Kimp, PGL_KMAX) * 8);
-    const uint8_t* Sn = (const uint8_t*)h->ST.p + (size_t)n_post * h->nT;
     for (int k0 = 0; k0 < K; k0 += PGL_KMAX) {
         const int kk = std::min(PGL_KMAX, K - k0);
         HIPCHK(hipMemcpyAsync(h->wsmall.p, w + k0, (size_t)kk * 8, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_ll_current, dim3(nblocks), dim3(256), 0, h->stream, d_base, d_stim,
-                           d_col, Sn, bias, aw_cur, (const double*)h->wsmall.p, kk, h->nlin, h->dt,
+                           d_col, bias, aw_cur, (const double*)h->wsmall.p, kk, h->nlin, h->dt,
                            (long long)h->nT, (double*)h->part.p);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(64), 0, h->stream, (const double*)h->part.p,
-                           nblocks, kk, (double*)h->outK.p);
+        hipLaunchKernelGGL(k_ll_current_spikes, dim3(sblocks), dim3(256), 0, h->stream,
+                           (const int2*)h->spk.p, e_lo, e_hi, d_base, d_stim, d_col, bias, aw_cur,
+                           (const double*)h->wsmall.p, kk, h->nlin,
+                           (double*)h->part.p + (size_t)nblocks * PGL_KMAX);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_parts, dim3(kk), dim3(64), 0, h->stream, (const double*)h->part.p,
+                           nblocks + sblocks, kk, (double*)h->outK.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ll_out + k0, h->outK.p, (size_t)kk * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -1057,12 +1057,29 @@ __global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, dou
 
 // MCMC inner ll (gibbs.py:910-937): for k < K:
 //   x = bias + stim[t] + base[t] - aw_cur*col[t] + w[k]*col[t]
-//   part[block][k] = sum_t (-dt*lam + log(lam)*S_T[t])
+//   ll_k = sum_t -dt*lam_k(t)  +  sum_{spike bins of n_post} S*log(lam_k(t))
+// The first sum streams all nT bins (k_ll_current: one exp per element and weight, log1p by
+// its series in the |x| > 9.25 tail); the second only visits the post-synaptic neuron's own
+// spike events (k_ll_current_spikes, ~2 % of the bins), so no log is evaluated for silent bins.
 #define PGL_KMAX 16
+__device__ __forceinline__ double pgl_lambda_only(const double x, const int nlin,
+                                                  const double* __restrict__ C)
+{
+    if (nlin != 1) return pgl_exp(x, C);
+    const double e = pgl_exp(-fabs(x), C);
+    double l1p;
+    if (__all(e < C[23])) {
+        l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), C[22]), 0.5), 1.0);
+    } else {
+        const double u = 1.0 + e;
+        l1p = pgl_log(u, C) + (e - (u - 1.0)) * pgl_rcp(u);
+    }
+    return fmax(x, 0.0) + l1p;
+}
+
 __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ base,
                                                     const double* __restrict__ stim,
-                                                    const double* __restrict__ colv,
-                                                    const uint8_t* __restrict__ Sn, double bias,
+                                                    const double* __restrict__ colv, double bias,
                                                     double aw_cur, const double* __restrict__ w,
                                                     int K, int nlin, double dt, long long nT,
                                                     double* __restrict__ part)
@@ -1078,20 +1095,12 @@ __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ b
          t += (long long)gridDim.x * blockDim.x) {
         const double c = colv[t];
         const double x0 = bias + (stim ? stim[t] : 0.0) + base[t] - aw_cur * c;
-        const double s = (double)Sn[t];
 #pragma unroll
         for (int k = 0; k < PGL_KMAX; ++k) {
             if (k < K) {
-                const double x = fma(wk[k], c, x0);
-                double term;
-                if (nlin == 1) {
-                    double sig, loglam;
-                    const double lam = pgl_softplus_parts(x, sig, loglam);
-                    term = -dt * lam + loglam * s;
-                } else {
-                    term = -dt * exp(x) + x * s;
-                }
-                acc[k] += term;
+                const double lam = pgl_lambda_only(fma(wk[k], c, x0), nlin, PGL_C);
+                // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
+                acc[k] += (lam == 0.0) ? __builtin_nan("") : -dt * lam;
             }
         }
     }
@@ -1108,15 +1117,55 @@ __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ b
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void k_reduce_parts(const double* __restrict__ part, int nblocks, int K,
-                               double* __restrict__ out)
+// spike-bin part: events [e_lo, e_hi) of the post-synaptic neuron, grid-strided; one partial
+// row per block (fixed order)
+__global__ __launch_bounds__(256) void k_ll_current_spikes(const int2* __restrict__ spk, int e_lo,
+                                                           int e_hi, const double* __restrict__ base,
+                                                           const double* __restrict__ stim,
+                                                           const double* __restrict__ colv,
+                                                           double bias, double aw_cur,
+                                                           const double* __restrict__ w, int K,
+                                                           int nlin, double* __restrict__ part)
 {
-    const int k = threadIdx.x;
-    if (k < K) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * PGL_KMAX + k];
-        out[k] = s;
+    __shared__ double red[4][PGL_KMAX];
+    double acc[PGL_KMAX];
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
+    for (int i = e_lo + blockIdx.x * blockDim.x + threadIdx.x; i < e_hi; i += gridDim.x * blockDim.x) {
+        const int2 e = spk[i];
+        const long long t = e.x;
+        const double c = colv[t];
+        const double x0 = bias + (stim ? stim[t] : 0.0) + base[t] - aw_cur * c;
+        const double s = (double)e.y;
+        for (int k = 0; k < K; ++k) {
+            const double x = fma(w[k], c, x0);
+            const double loglam = (nlin == 1) ? pgl_log(pgl_lambda_only(x, nlin, PGL_C), PGL_C) : x;
+            acc[k] = fma(s, loglam, acc[k]);
+        }
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PGL_KMAX)
+        part[(size_t)blockIdx.x * PGL_KMAX + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[k] = sum over the partial rows; one 64-lane block per k (fixed summation order)
+__global__ __launch_bounds__(64) void k_reduce_parts(const double* __restrict__ part, int nblocks,
+                                                     int K, double* __restrict__ out)
+{
+    const int k = blockIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(size_t)b * PGL_KMAX + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[k] = s;
 }
 
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
