@@ -199,3 +199,54 @@ def test_time_range_partial_sums():
     with pytest.raises(_lib.PglError):
         dev.set_time_range(8, 100)          # not a multiple of 16
     dev.close()
+
+
+def test_full_size_properties_c3():
+    """BASELINE config C3 at full size (N=128, T=600 s, nT=600 000): size-independent
+    properties of the device path, plus an oracle spot check on a time sub-range.
+      * ll of the ll-only call == ll of the ll+grad call; chunk decomposition invariance;
+      * additivity over time shards (the multi-GPU split);
+      * directional derivative of the device ll == device gradient . direction;
+      * oracle parity on bins [0, 24000) (features only depend on the past)."""
+    rng = np.random.default_rng(77)
+    N, nT = 128, 600000
+    p = H.Problem(N, nT, H.std_ibasis(), seed=1234 + 3, w_scale=0.5)
+    dev = p.device()
+    ll, g = dev.ll_grad(p.theta, p.Weff)
+    assert np.all(np.isfinite(ll)) and np.all(np.isfinite(g))
+    ll_only, _ = dev.ll_grad(p.theta, p.Weff, want_grad=False)
+    assert np.array_equal(ll, ll_only)
+    # chunk decomposition
+    from theano_pyglm_amd import _lib
+    dev.set_option(_lib.OPT_NCHUNKS, 61)
+    ll_c, g_c = dev.ll_grad(p.theta, p.Weff)
+    dev.set_option(_lib.OPT_NCHUNKS, 0)
+    assert np.allclose(ll_c, ll, rtol=1e-12) and H.rel_err(g_c, g) < 1e-11
+    # time shards (8 ranks)
+    from theano_pyglm_amd import parallel as PL
+    ll_s, g_s = 0.0, 0.0
+    for r in range(8):
+        lo, hi = PL.time_shard_bounds(nT, r, 8)
+        dev.set_time_range(lo, hi)
+        a, b = dev.ll_grad(p.theta, p.Weff)
+        ll_s, g_s = ll_s + a, g_s + b
+    dev.set_time_range(0, nT)
+    assert np.allclose(ll_s, ll, rtol=1e-12) and H.rel_err(g_s, g) < 1e-11
+    # directional derivative (per neuron), central differences on the device ll
+    d = rng.standard_normal(p.theta.shape)
+    eps = 1e-6
+    lp, _ = dev.ll_grad(p.theta + eps * d, p.Weff, want_grad=False)
+    lm, _ = dev.ll_grad(p.theta - eps * d, p.Weff, want_grad=False)
+    fd = (lp - lm) / (2 * eps)
+    an = np.sum(g * d, axis=1)
+    assert np.max(np.abs(fd - an)) < 1e-5 * np.max(np.abs(an))
+    # oracle spot check on the first 24000 bins, 3 neurons
+    nsub = 24000
+    dev.set_time_range(0, nsub)
+    q = H.Problem(N, nsub, H.std_ibasis(), seed=0)
+    q.S, q.theta, q.Weff, q._fS = p.S[:nsub], p.theta, p.Weff, None
+    for n in (0, 77, 127):
+        a, b = dev.ll_grad(p.theta[n:n + 1], p.Weff, n, n + 1)
+        a0, b0 = q.oracle_ll_grad(n, n + 1)
+        assert np.allclose(a, a0, rtol=LL_RTOL) and H.rel_err(b, b0) < G_RTOL
+    dev.close()

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             const int id = tid + q * nthr;
             pfv[q] = false;
             pf[q] = make_int2(0, 0);
-            if (id < N * CAP && tile + 1 < tile_end) {
+            if (id < N * CAP && tile + 1 < tile_end && !(p.dbg & 2)) {
                 const int np = id / CAP, sl = id % CAP;
                 const int cnt = s_cnt[nxt + np];
                 if (cnt <= CAP && sl < cnt) {
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             }
         }
         int w2lo = 0, w2cnt = 0;
-        if (tid < N && tile + 2 < tile_end) {
+        if (tid < N && tile + 2 < tile_end && !(p.dbg & 32)) {
             w2lo = p.wlo[(size_t)(tile + 2) * N + tid];
             w2cnt = p.whi[(size_t)(tile + 2) * N + tid] - w2lo;
         }
