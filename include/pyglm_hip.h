@@ -124,6 +124,22 @@ int pgl_gibbs_ll(pgl_handle h, int n_pre, double aw_cur, const double* w, int K,
  * new sample into the state dict): I_net += delta * I_imp[:,n_pre] on the device. */
 int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
 
+/* Population.simulate (population.py:233-389), native host implementation (no GPU needed):
+ * integrate-and-fire thinning of the conditional intensity.  Per bin t: lam = nlin(X[t,:]),
+ * acc += lam*dt, a neuron spikes while acc > thr (thr ~ Exp(1), redrawn after each spike,
+ * population.py:321-360); every spike of n_pre adds AW[n_pre,:,n_post] to X[t+1 : t+R+1, n_post]
+ * (351-353); at most 10 spikes per bin (345-349: the round that would exceed the cap is dropped).
+ *   X     (nT,N) in/out: on entry bias + stimulus current (population.py:252-268), on exit the
+ *         total current; S (nT,N) out, float64 counts.
+ *   AW    (N, R, N) = A[n_pre,n_post]*W[n_pre,n_post]*impulse[n_pre->n_post][tau], layout
+ *         [n_pre][tau][n_post].
+ *   uniforms: optional stream of U(0,1) numbers consumed in the reference's draw order (N for the
+ *         initial thresholds, then one per spiking neuron per round); when exhausted (or NULL) a
+ *         splitmix64 generator seeded with `seed` continues.  n_exceptions_out may be NULL. */
+int pgl_simulate(int N, int64_t nT, int R, int nlin, double dt, double* X, const double* AW,
+                 const double* uniforms, int64_t n_uniforms, uint64_t seed, double* S,
+                 int64_t* n_exceptions_out);
+
 /* Timing of the most recent pgl_ll_grad[_dev] call, measured with HIP events on the
  * handle's stream: ms of the fused kernel alone and of the whole call (prep +
  * fused + finalize).  For the _dev form call after pgl_sync. */

@@ -156,13 +156,43 @@ def test_stimulus_preprocessing_matches_oracle():
     assert np.allclose(d2['fstim'], ref, atol=1e-12)
 
 
+def test_native_simulate_matches_python_loop():
+    """pgl_simulate (C++) consumes the uniform stream in the reference's draw order: same spikes
+    as the line-by-line Python restatement of population.py:291-364."""
+    from theano_pyglm_amd import _lib
+    for name, N in (('standard_glm', 3), ('sparse_weighted_model', 4)):
+        m = stabilize_sparsity(make_model(name, N=N, dt=0.001))
+        p = Population(m)
+        x = p.sample(np.random.RandomState(5))
+        S_py, X_py = p.simulate(x, (0, 1.2), 0.001, None, 0.1, rng=np.random.RandomState(6), native=False)
+        # same stream for the native loop
+        nT = 1200
+        X0 = np.zeros((nT, N))
+        for n in range(N):
+            X0[:, n] = x['glms'][n]['bias']['bias'][0]
+        imps = np.array([p.glm.imp_model.impulse(x['glms'][n]['imp']) for n in range(N)])
+        AW = p.W_eff(x)[:, :, None] * np.transpose(imps, axes=[1, 0, 2])      # (pre, post, R)
+        u = np.random.RandomState(6).random_sample(200000)
+        S_c, X_c, nexc = _lib.simulate(X0, np.ascontiguousarray(np.transpose(AW, (0, 2, 1))),
+                                       p.glm.nlin_model.kind, 0.001, uniforms=u, seed=1)
+        assert S_py.sum() > 10
+        assert np.array_equal(S_py, S_c)
+        assert np.allclose(X_py, X_c, rtol=1e-10, atol=1e-10)
+        # and through Population.simulate(native=True): the reference's consistency invariant
+        S_n, X_n = p.simulate(x, (0, 1.2), 0.001, None, 0.1, rng=np.random.RandomState(7))
+        for n in range(N):
+            xd = O.direct_currents(S_n, p.glm.imp_model.impulse(x['glms'][n]['imp']), p.W_eff(x)[:, n],
+                                   x['glms'][n]['bias']['bias'][0])
+            assert np.allclose(X_n[:, n], xd)
+
+
 def test_simulate_consistency_host():
     """Population.simulate reproduces the superposition the oracle restates
     (population.py:351-353): X equals direct_currents of the spikes it emitted."""
     rng = np.random.RandomState(4)
     p = Population(make_model('standard_glm', N=3, dt=0.001))
     x = p.sample(rng)
-    S, X = p.simulate(x, (0, 1.5), 0.001, None, 0.1, rng=rng)
+    S, X = p.simulate(x, (0, 1.5), 0.001, None, 0.1, rng=rng, native=False)
     assert S.shape == (1500, 3) and S.max() <= 10
     for n in range(3):
         imps = p.glm.imp_model.impulse(x['glms'][n]['imp'])

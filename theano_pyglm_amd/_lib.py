@@ -25,7 +25,7 @@ SYMBOLS = [
     'pgl_set_option', 'pgl_set_time_range', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
     'pgl_set_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
-    'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info',
+    'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate',
 ]
 
 
@@ -98,6 +98,8 @@ def load():
     lib.pgl_gibbs_update.argtypes = [vp, C.c_int, C.c_double]
     lib.pgl_last_timing.argtypes = [vp, dp, dp]
     lib.pgl_info.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    lib.pgl_simulate.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, vp, vp, vp,
+                                 C.c_int64, C.c_uint64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ('pgl_last_error',):
@@ -124,6 +126,24 @@ def _f64(a, shape=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def simulate(X0, AW, nlin, dt, uniforms=None, seed=0):
+    """Native Population.simulate (population.py:233-389); host code, needs no GPU.
+    X0 (nT,N) background current, AW (N,R,N) [n_pre][tau][n_post].  Returns (S, X, n_exceptions)."""
+    lib = load()
+    X = np.array(X0, dtype=np.float64, order='C')
+    nT, N = X.shape
+    AW = _f64(AW)
+    assert AW.ndim == 3 and AW.shape[0] == N and AW.shape[2] == N
+    R = AW.shape[1]
+    S = np.empty((nT, N))
+    u = None if uniforms is None else _f64(uniforms)
+    nexc = C.c_int64(0)
+    kind = {'exp': NLIN_EXP, 'explinear': NLIN_EXPLINEAR}.get(nlin, nlin)
+    _chk(lib.pgl_simulate(N, nT, R, int(kind), float(dt), _ptr(X), _ptr(AW), _ptr(u),
+                          0 if u is None else u.size, int(seed), _ptr(S), C.byref(nexc)))
+    return S, X, int(nexc.value)
 
 
 class DeviceGlm(object):

@@ -745,6 +745,79 @@ int pgl_ll_from_current(pgl_handle h, int n_post, double I_bias, const double* I
                           I_bias, 0.0, w, K, ll_out);
 }
 
+namespace {
+struct UniformStream {
+    const double* buf;
+    int64_t n, pos;
+    uint64_t state;
+    double next()
+    {
+        if (buf && pos < n) return buf[pos++];
+        uint64_t z = (state += 0x9e3779b97f4a7c15ULL);        // splitmix64
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        z ^= z >> 31;
+        return ((z >> 11) + 0.5) * (1.0 / 9007199254740992.0); // (0,1)
+    }
+};
+inline double host_nlin(double x, int nlin)
+{
+    return nlin == 1 ? std::fmax(x, 0.0) + std::log1p(std::exp(-std::fabs(x))) : std::exp(x);
+}
+}  // namespace
+
+int pgl_simulate(int N, int64_t nT, int R, int nlin, double dt, double* X, const double* AW,
+                 const double* uniforms, int64_t n_uniforms, uint64_t seed, double* S,
+                 int64_t* n_exceptions_out)
+{
+    if (N <= 0 || nT <= 0 || R <= 0 || !X || !AW || !S) return fail(PGL_ERR_ARG, "bad argument");
+    if (nlin != PGL_NLIN_EXP && nlin != PGL_NLIN_EXPLINEAR) return fail(PGL_ERR_ARG, "unknown nonlinearity");
+    UniformStream u{uniforms, uniforms ? n_uniforms : 0, 0, seed};
+    std::vector<double> acc(N, 0.0), thr(N);
+    std::vector<char> spk(N);
+    for (int n = 0; n < N; ++n) thr[n] = -std::log(u.next());             // population.py:293
+    std::memset(S, 0, sizeof(double) * (size_t)nT * N);
+    int64_t n_exc = 0;
+    for (int64_t t = 0; t < nT; ++t) {
+        double* Xt = X + (size_t)t * N;
+        double* St = S + (size_t)t * N;
+        int n_spk = 0;
+        for (int n = 0; n < N; ++n) {
+            acc[n] += host_nlin(Xt[n], nlin) * dt;                       // population.py:317-318
+            spk[n] = acc[n] > thr[n];
+            if (spk[n]) { St[n] += 1.0; ++n_spk; }
+        }
+        const int64_t t_imp = std::min<int64_t>(nT - t - 1, R);          // population.py:326
+        while (n_spk > 0) {
+            bool capped = false;
+            for (int n = 0; n < N; ++n) capped = capped || (St[n] >= 10.0);
+            if (capped) { ++n_exc; break; }                              // population.py:345-349
+            for (int np = 0; np < N; ++np) {
+                if (!spk[np]) continue;
+                const double* aw = AW + (size_t)np * R * N;
+                for (int64_t tau = 0; tau < t_imp; ++tau) {              // population.py:351-353
+                    double* xr = X + (size_t)(t + 1 + tau) * N;
+                    const double* ar = aw + (size_t)tau * N;
+                    for (int n = 0; n < N; ++n) xr[n] += ar[n];
+                }
+            }
+            for (int n = 0; n < N; ++n) {                                // population.py:355-360
+                if (spk[n]) acc[n] -= thr[n];
+                if (acc[n] < 0) acc[n] = 0;
+            }
+            for (int n = 0; n < N; ++n)
+                if (spk[n]) thr[n] = -std::log(u.next());
+            n_spk = 0;
+            for (int n = 0; n < N; ++n) {
+                spk[n] = acc[n] > thr[n];
+                if (spk[n]) { St[n] += 1.0; ++n_spk; }
+            }
+        }
+    }
+    if (n_exceptions_out) *n_exceptions_out = n_exc;
+    return PGL_OK;
+}
+
 int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col, double* lam_out,
               double* I_net_out, double* I_stim_out)
 {

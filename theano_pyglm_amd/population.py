@@ -240,10 +240,12 @@ class Population(object):
         return state
 
     # -- simulation ------------------------------------------------------------------------
-    def simulate(self, vars, T_range, dt, stim, dt_stim, rng=None, verbose=False):
+    def simulate(self, vars, T_range, dt, stim, dt_stim, rng=None, verbose=False, native=True):
         """population.py:233-389: integrate-and-fire thinning with exponential thresholds;
         every spike adds A*W*impulse to X[t+1 : t+R+1] (351-353); <= 10 spikes per bin.
-        Host-side restatement (seeded; the reference uses the global np.random)."""
+        Seeded (the reference uses the global np.random).  native=True runs the time loop in the
+        C++ library (pgl_simulate, ~100x the Python loop, same draw order); native=False is the
+        line-by-line Python restatement kept for cross-checking."""
         from theano_pyglm_amd.components.priors import _rng
         r = _rng(rng)
         T_start, T_stop = T_range
@@ -263,6 +265,17 @@ class Population(object):
         imps = np.transpose(imps, axes=[1, 0, 2])
         T_imp = imps.shape[2]
         AW = self.W_eff(vars)[:, :, None] * imps              # (n_pre, n_post, R)
+        if native:
+            # uniforms in the reference's draw order come from `rng`; the library continues with
+            # its own generator if the pre-drawn stream runs out
+            n_draw = int(N + 4 * max(1.0, np.sum(self.glm.nlin_model.f_nlin(X)) * dt) + 1000)
+            u = r.random_sample(min(n_draw, 50000000))
+            seed = int(r.randint(0, 2 ** 31 - 1))
+            S, X, n_exc = _lib.simulate(X, np.ascontiguousarray(np.transpose(AW, (0, 2, 1))),
+                                        self.glm.nlin_model.kind, dt, uniforms=u, seed=seed)
+            if verbose:
+                print("Number of exceptions arising from multiple spikes per bin: %d" % n_exc)
+            return S, X
         f_nlin = self.glm.nlin_model.f_nlin
         S = np.zeros((nT, N))
         acc = np.zeros(N)
