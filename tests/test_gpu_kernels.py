@@ -250,3 +250,47 @@ def test_full_size_properties_c3():
         a0, b0 = q.oracle_ll_grad(n, n + 1)
         assert np.allclose(a, a0, rtol=LL_RTOL) and H.rel_err(b, b0) < G_RTOL
     dev.close()
+
+
+def test_tiny_shapes():
+    """Degenerate sizes: one neuron; fewer bins than one 16-row tile; fewer bins than taps."""
+    _check(H.Problem(1, 40, H.std_ibasis(), seed=15, rate_hz=100.0))
+    _check(H.Problem(3, 7, H.std_ibasis(), seed=16, rate_hz=200.0))
+    _check(H.Problem(2, 1, H.std_ibasis(), seed=17, rate_hz=500.0))
+    _check(H.Problem(17, 100, H.st_ibasis(), kind='exp', seed=18, rate_hz=50.0, w_scale=0.01))
+
+
+def test_unsupported_shapes_fail_loudly():
+    from theano_pyglm_amd import _lib
+    p = H.Problem(130, 64, H.std_ibasis(), seed=19)          # 130*5 = 650 > 640 feature columns
+    dev = p.device()
+    with pytest.raises(_lib.PglError, match="640"):
+        dev.ll_grad(p.theta, p.Weff)
+    dev.close()
+    q = H.Problem(128, 64, H.std_ibasis(), seed=20)
+    dq = q.device()
+    with pytest.raises(_lib.PglError):
+        dq.set_stim_features(np.zeros((64, 8)))              # 640 + 8 columns
+    with pytest.raises((_lib.PglError, ValueError)):
+        dq.ll_grad(q.theta[:3], q.Weff, 5, 4)                # empty / reversed neuron range
+    with pytest.raises(_lib.PglError, match="range"):
+        dq.ll_grad(q.theta[:3], q.Weff, 127, 130)            # beyond N
+    dq.close()
+
+
+def test_legacy_and_f32_kernels_agree():
+    """PGL_OPT_KERNEL=1 (4-wave kernel of the first version) and PGL_OPT_FEATURE_F32 against
+    the default path."""
+    from theano_pyglm_amd import _lib
+    p = H.Problem(48, 3000, H.std_ibasis(), seed=21, weighted=True)
+    d0 = p.device()
+    ll0, g0 = d0.ll_grad(p.theta, p.Weff)
+    d1 = p.device()
+    d1.set_option(_lib.OPT_KERNEL, 1)
+    ll1, g1 = d1.ll_grad(p.theta, p.Weff)
+    assert np.allclose(ll1, ll0, rtol=1e-12) and H.rel_err(g1, g0) < 1e-12
+    d2 = p.device(f32=True)
+    ll2, g2 = d2.ll_grad(p.theta, p.Weff)
+    assert np.allclose(ll2, ll0, rtol=1e-8) and H.rel_err(g2, g0) < 1e-6
+    for d in (d0, d1, d2):
+        d.close()
