@@ -635,6 +635,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
     const double* __restrict__ wrow =
         p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
     const int kcol0 = ksl * KTW * 16;            // first feature column of this wave's slice
+    // epilogue ownership: the 256 elements (4 regs x 64 lanes) of a post tile are split over its
+    // KSPLIT waves: KSPLIT=2 -> regs {2ks,2ks+1}; 4 -> reg ks; 8 -> reg ks/2, lane half ks&1
+    constexpr int EPW = (KSPLIT >= 4) ? 1 : 4 / KSPLIT;
+    int er[EPW];
+#pragma unroll
+    for (int e = 0; e < EPW; ++e) er[e] = (KSPLIT == 8) ? (ksl >> 1) : (KSPLIT == 4) ? ksl : ksl * EPW + e;
+    const bool emine = (KSPLIT == 8) ? ((lane >> 5) == (ksl & 1)) : true;
 
     const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
@@ -716,6 +723,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         }
         __syncthreads();
 
+        // post-synaptic counts of the elements this wave owns in the epilogue: issued before the
+        // forward pass so that the global-load latency hides under the MFMAs
+        double sc[EPW];
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) {
+            const long long tg = (long long)t0 + grp + 4 * er[e];
+            const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+            sc[e] = (double)p.S[tc * N + nglob];
+        }
         // ---- forward over this wave's K slice ----
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
         d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -768,40 +784,28 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
 
         // ---- epilogue: the tile's 256 elements are split over its KSPLIT waves ----
         if (active) {
-            constexpr int EPW = (KSPLIT >= 4) ? 1 : 4 / KSPLIT;      // regs handled per wave
 #pragma unroll
             for (int e = 0; e < EPW; ++e) {
-                int r;
-                bool mine = true;
-                if (KSPLIT == 8) {
-                    r = ksl >> 1;
-                    mine = ((lane >> 5) == (ksl & 1));
-                } else if (KSPLIT == 4) {
-                    r = ksl;
-                } else {
-                    r = ksl * EPW + e;
-                }
+                const int r = er[e];
                 double x = bias_l;
 #pragma unroll
                 for (int k2 = 0; k2 < KSPLIT; ++k2)
                     x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
                 const long long tg = (long long)t0 + grp + 4 * r;
-                const bool vt = valid_n && (tg < p.t_hi) && mine;
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                const double sc = (double)p.S[tc * N + nglob];
+                const bool vt = valid_n && (tg < p.t_hi) && emine;
                 double res;
                 if (p.dbg & 4) {
-                    ll_acc += x * sc;
-                    res = vt ? x - sc : 0.0;
+                    ll_acc += x * sc[e];
+                    res = vt ? x - sc[e] : 0.0;
                     gb_acc += res;
                 } else {
                     // constants come from LDS through an opaque pointer: as literals or hoisted
                     // scalar loads they pin ~50 registers for the whole kernel and spill
                     const double* Cl = Cs;
                     asm volatile("" : "+v"(Cl));
-                    pgl_epilogue(x, sc, vt, p.nlin, p.dt, ll_acc, gb_acc, res, Cl);
+                    pgl_epilogue(x, sc[e], vt, p.nlin, p.dt, ll_acc, gb_acc, res, Cl);
                 }
-                if (mine) Rb[(size_t)ptl * 256 + r * 64 + lane] = res;
+                if (emine) Rb[(size_t)ptl * 256 + r * 64 + lane] = res;
             }
         }
         __syncthreads();
