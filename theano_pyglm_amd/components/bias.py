@@ -1,43 +1,44 @@
-"""Constant bias current (counterpart of pyglm/components/bias.py)."""
+"""Bias current of a GLM neuron: a single scalar with a Gaussian prior
+(behavioural counterpart of pyglm/components/bias.py: I_bias = bias[0], :32;
+log p = -(bias - mu)^2 / (2 sigma^2), :33; sample = mu + sigma * randn(1), :51-56)."""
 import numpy as np
 
 from theano_pyglm_amd.components.component import Component
 from theano_pyglm_amd.components.priors import _rng
 
 
-def create_bias_component(model, glm, latent):
-    typ = model['bias']['type'].lower()
-    if typ == 'constant':
-        return ConstantBias(model)
-    raise Exception("Unrecognized bias model: %s" % typ)
-
-
 class ConstantBias(Component):
-    """I_bias = bias[0] (bias.py:32), log_p = -0.5/sigma^2 (bias-mu)^2 (bias.py:33)."""
-
     def __init__(self, model):
-        prms = model['bias']
-        self.mu_bias = prms['mu']
-        self.sig_bias = prms['sigma']
+        self.set_hyperparameters(model['bias'])
+
+    def set_hyperparameters(self, model):
+        self.mu_bias, self.sig_bias = model['mu'], model['sigma']
 
     def get_variables(self):
         return {'bias': (1,)}
 
-    def I_bias(self, vars):
-        return float(np.asarray(vars['bias']).reshape(-1)[0])
+    @staticmethod
+    def I_bias(vars):
+        return float(np.ravel(vars['bias'])[0])
+
+    def _z(self, vars):
+        return (self.I_bias(vars) - self.mu_bias) / self.sig_bias
 
     def log_p(self, vars):
-        return -0.5 / self.sig_bias ** 2 * (self.I_bias(vars) - self.mu_bias) ** 2
+        return -0.5 * self._z(vars) ** 2
 
     def grad_log_p(self, vars):
-        return {'bias': np.array([-(self.I_bias(vars) - self.mu_bias) / self.sig_bias ** 2])}
-
-    def set_hyperparameters(self, model):
-        self.mu_bias = model['mu']
-        self.sig_bias = model['sigma']
+        return {'bias': np.array([-self._z(vars) / self.sig_bias])}
 
     def get_state(self, vars=None):
-        return {} if vars is None else {'bias': vars['bias']}
+        return {'bias': vars['bias']} if vars is not None else {}
 
     def sample(self, acc, rng=None):
         return {'bias': self.mu_bias + self.sig_bias * _rng(rng).standard_normal(1)}
+
+
+def create_bias_component(model, glm, latent):
+    kind = model['bias']['type'].lower()
+    if kind != 'constant':
+        raise Exception("Unrecognized bias model: %s" % kind)
+    return ConstantBias(model)

@@ -1,101 +1,110 @@
 """
-Flatten / unflatten nested parameter dicts in sorted-key depth-first order
-(counterpart of pyglm/utils/packvec.py and theano_func_wrapper._flatten; the order
-defines the layout of every packed parameter / gradient vector).
+Flatten / unflatten nested parameter dictionaries.
+
+Behavioural counterpart of pyglm/utils/packvec.py (and of theano_func_wrapper._flatten):
+leaves are visited depth-first in sorted-key order, which fixes the layout of every packed
+per-neuron parameter / gradient vector (e.g. standard_glm: [bias, w_ir]).
+Implemented as a single tree walk that yields (path, leaf) pairs.
 """
 import numpy as np
 
 
-def _items(d):
-    return sorted(d.items(), key=lambda kv: kv[0])
+def _walk(tree, path=()):
+    """Yield (path, leaf) for every non-dict leaf, children in sorted-key order."""
+    for key in sorted(tree):
+        node = tree[key]
+        if isinstance(node, dict):
+            for item in _walk(node, path + (key,)):
+                yield item
+        else:
+            yield path + (key,), node
+
+
+def _put(tree, path, value):
+    for key in path[:-1]:
+        tree = tree.setdefault(key, {})
+    tree[path[-1]] = value
+
+
+def _skeleton(tree):
+    """Same nesting with empty dicts kept (the shapes dict mirrors sub-dicts even when empty)."""
+    return dict((k, _skeleton(v)) for k, v in tree.items() if isinstance(v, dict))
 
 
 def packdict(var_dict, on_unpackable_type='raise'):
-    """packvec.py:17-45.  Returns (vector, shapes) with shapes mirroring the dict."""
-    parts, shapes = [], {}
-    for key, val in _items(var_dict):
-        if isinstance(val, dict):
-            sub, sshapes = packdict(val, on_unpackable_type)
-            parts.append(sub)
-            shapes[key] = sshapes
+    """(vector, shapes): concatenation of all leaves and a dict of their shapes
+    (packvec.py:17-45).  Empty lists are skipped; non-arrays raise unless told otherwise."""
+    strict = on_unpackable_type.lower() == 'raise'
+    shapes = _skeleton(var_dict)
+    chunks = []
+    for path, leaf in _walk(var_dict):
+        if isinstance(leaf, list) and not leaf:
             continue
-        if isinstance(val, list) and len(val) == 0:
-            continue
-        if not isinstance(val, np.ndarray):
-            if on_unpackable_type.lower() == 'raise':
+        if not isinstance(leaf, np.ndarray):
+            if strict:
                 raise Exception("Can only pack numpy arrays!")
-            val = np.asarray(val)
-        shapes[key] = val.shape
-        parts.append(np.reshape(val, (val.size,)).astype(float))
-    vec = np.concatenate(parts) if parts else np.zeros((0,))
-    return vec, shapes
-
-
-def _unpack(vec, shapes, offset):
-    out = {}
-    for key, shp in _items(shapes):
-        if isinstance(shp, dict):
-            out[key], offset = _unpack(vec, shp, offset)
-        elif isinstance(shp, tuple):
-            n = int(np.prod(shp))
-            out[key] = np.reshape(vec[offset:offset + n], shp)
-            offset += n
-        else:
-            raise Exception("Can only unpack shape tuples!")
-    return out, offset
+            leaf = np.asarray(leaf)
+        _put(shapes, path, leaf.shape)
+        chunks.append(np.asarray(leaf, dtype=float).reshape(-1))
+    return (np.concatenate(chunks) if chunks else np.zeros((0,))), shapes
 
 
 def unpackdict(vec, shapes):
-    """packvec.py:58-83."""
-    out, used = _unpack(np.asarray(vec), shapes, 0)
+    """Inverse of packdict (packvec.py:58-83)."""
+    vec = np.asarray(vec)
+    out = _skeleton(shapes)
+    cursor = 0
+    for path, shp in _walk(shapes):
+        if not isinstance(shp, tuple):
+            raise Exception("Can only unpack shape tuples!")
+        size = int(np.prod(shp))
+        _put(out, path, vec[cursor:cursor + size].reshape(shp))
+        cursor += size
     return out
 
 
 def pack(var_list):
-    """packvec.py:3-15."""
-    shapes = [np.shape(v) for v in var_list]
-    vec = np.concatenate([np.reshape(v, (-1,)) for v in var_list]) if var_list else np.zeros((0,))
-    return vec, shapes
+    """List form (packvec.py:3-15)."""
+    arrays = [np.asarray(v) for v in var_list]
+    flat = [a.reshape(-1) for a in arrays]
+    return (np.concatenate(flat) if flat else np.zeros((0,))), [a.shape for a in arrays]
 
 
 def unpack(vec, shapes):
-    """packvec.py:47-56."""
-    out, off = [], 0
-    for shp in shapes:
-        n = int(np.prod(shp))
-        out.append(np.reshape(vec[off:off + n], shp))
-        off += n
-    assert off == len(vec), "Unpack was called with incorrect shapes!"
-    return out
+    """List form inverse (packvec.py:47-56)."""
+    sizes = [int(np.prod(s)) for s in shapes]
+    assert sum(sizes) == len(vec), "Unpack was called with incorrect shapes!"
+    bounds = np.cumsum([0] + sizes)
+    return [np.reshape(vec[a:b], s) for a, b, s in zip(bounds[:-1], bounds[1:], shapes)]
 
 
 def get_vars(syms, vars):
-    """packvec.py:86-96: the sub-dict of `vars` named by `syms`."""
-    out = {}
-    for k, v in syms.items():
-        assert k in vars.keys(), "ERROR: syms key %s not found in vars!" % k
-        out[k] = get_vars(v, vars[k]) if isinstance(v, dict) else vars[k]
-    return out
+    """The part of `vars` that `syms` names (packvec.py:86-96)."""
+    picked = {}
+    for name, sym in syms.items():
+        if name not in vars:
+            raise AssertionError("ERROR: syms key %s not found in vars!" % name)
+        picked[name] = get_vars(sym, vars[name]) if isinstance(sym, dict) else vars[name]
+    return picked
 
 
 def set_vars(syms, vars, vals):
-    """packvec.py:98-113."""
-    if isinstance(syms, dict):
-        for k, v in syms.items():
-            assert k in vars.keys(), "ERROR: syms key %s not found in vars!" % k
-            assert k in vals.keys(), "ERROR: syms key %s not found in vals!" % k
-            if isinstance(v, dict):
-                vars[k] = set_vars(v, vars[k], vals[k])
-            else:
-                vars[k] = vals[k]
-    elif syms in vars:
+    """Write `vals` into `vars` for every variable `syms` names (packvec.py:98-113);
+    `syms` may also be a single key."""
+    if not isinstance(syms, dict):
+        if syms not in vars:
+            raise Exception("Can only set variables for a dictionary of symbolic vars"
+                            "or a specific key in vars")
         vars[syms] = vals
-    else:
-        raise Exception("Can only set variables for a dictionary of symbolic vars"
-                        "or a specific key in vars")
+        return vars
+    for name, sym in syms.items():
+        for where, d in (("vars", vars), ("vals", vals)):
+            if name not in d:
+                raise AssertionError("ERROR: syms key %s not found in %s!" % (name, where))
+        vars[name] = set_vars(sym, vars[name], vals[name]) if isinstance(sym, dict) else vals[name]
     return vars
 
 
 def get_shapes(x, syms):
-    """packvec.py:115-117."""
+    """Shapes of the variables `syms` names in state `x` (packvec.py:115-117)."""
     return packdict(get_vars(syms, x))[1]
