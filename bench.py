@@ -96,6 +96,8 @@ def map_wall_clock(S, N, dt):
     popn.release_data()
     return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": wall,
             "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
+            "bfgs_iterations": getattr(popn, 'last_fit_stats', {}).get('iterations'),
+            "ll_grad_evaluations": getattr(popn, 'last_fit_stats', {}).get('evaluations'),
             "optimizer": "lock-step batched BFGS, maxiter 225, GPU-resident state"}
 
 

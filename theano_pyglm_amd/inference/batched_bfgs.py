@@ -144,4 +144,5 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         if D > 0:
             xn['bkgd']['w_stim'] = Xh[i, 1:1 + D].copy()
         xn['imp']['w_ir'] = Xh[i, 1 + D:].copy()
+    population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0]}
     return f.cpu().numpy(), it, n_evals[0]
