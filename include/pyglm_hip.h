@@ -73,6 +73,18 @@ int pgl_set_basis(pgl_handle h, const double* ibasis);
  * fstim is (nT, Dstim) row-major; Dstim = 0 / NULL = NoStimulus (bkgd.py:29-43). */
 int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim);
 
+/* BasisStimulus / SpatiotemporalStimulus.preprocess_data on the device (bkgd.py:122-154,
+ * 303-340; basis.py:201-273): linear interpolation of the raw stimulus (Tstim, D) from the dt_stim
+ * grid to the dt grid (np.interp, clamped at the ends), projection on the spatial basis
+ * basis_x (D,Bx) (NULL = identity), strictly causal convolution with every temporal basis
+ * basis_t (Rt,Bt).  The features stay on the device as the Dstim = Bx*Bt extra columns of F:
+ * layout 0: column bt*Bx+bx (SpatiotemporalStimulus, bkgd.py:337-340), layout 1: column bx*Bt+bt
+ * (BasisStimulus d*B+b, bkgd.py:148-152).  pgl_get_stim_features copies them out (nT, Dstim). */
+int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
+                     const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt,
+                     int layout);
+int pgl_get_stim_features(pgl_handle h, double* fstim_out);
+
 /* Restrict pgl_ll_grad to the bins [t_lo, t_hi) (t_lo a multiple of 16): ll and gradient
  * become the partial sums over that range, while features still see the spikes before t_lo.
  * The likelihood is a sum over data segments (population.py:41-43), so a time range per GPU

@@ -25,7 +25,15 @@ def oracle_log_p(popn, data, x):
     N = popn.N
     S = np.asarray(data['S'], dtype=float)
     fS = O.convolve_with_basis_fft(S, glm.imp_model.ibasis)
-    fstim = data.get('fstim', None)
+    fstim = None
+    if glm.Dstim > 0:           # oracle features from the raw stimulus (bkgd.py:122-154 / 303-340)
+        bk = glm.bkgd_model
+        if hasattr(bk, 'ibasis_x'):
+            fstim = O.spatiotemporal_stim_features(np.asarray(data['stim'], float), data['dt_stim'], glm.dt,
+                                                   S.shape[0], bk.ibasis_x, bk.ibasis_t)
+        else:
+            fstim = O.basis_stim_features(np.asarray(data['stim'], float), data['dt_stim'], glm.dt,
+                                          S.shape[0], bk.ibasis)
     Weff = popn.W_eff(x)
     lp = popn.network.log_p(x['net'])
     lls = []
@@ -166,6 +174,31 @@ def test_sparse_weighted_model_log_p_and_gibbs():
     assert np.allclose(popn.compute_log_p(x), oracle_log_p(popn, data, x)[0], rtol=1e-9)
 
 
+def test_device_stimulus_features(golden):
+    """pgl_set_stimulus (interp + projection + causal temporal filtering on the GPU) against the
+    reference's convolve_with_low_rank_2d_basis golden vectors and against the oracle."""
+    from theano_pyglm_amd import _lib
+    stim, ibx, ibt = golden['lr2d_stim'], golden['lr2d_ibasis_x'], golden['lr2d_ibasis_t']
+    T = stim.shape[0]
+    d = _lib.DeviceGlm(2, T, 3, 300, 'exp', 0.001)
+    d.set_stimulus(stim, 0.001, ibt, ibx, layout=0)               # dt_stim == dt: no interpolation
+    f = d.get_stim_features().reshape(T, 3, 3)                    # (t, bt, bx)
+    assert np.max(np.abs(np.transpose(f, (0, 2, 1)) - golden['lr2d_fstim'])) < 1e-12
+    d.set_stimulus(stim, 0.001, ibt, None, layout=1)              # BasisStimulus layout d*B+b
+    f1 = d.get_stim_features()
+    assert np.max(np.abs(f1 - O.basis_stim_features(stim, 0.001, 0.001, T, ibt))) < 1e-12
+    d.close()
+    # with interpolation from a coarse grid (dt_stim = 0.1 s), ragged end
+    rng = np.random.RandomState(3)
+    nT = 2345
+    coarse = rng.randn(24, 3)
+    d = _lib.DeviceGlm(2, nT, 3, 300, 'exp', 0.001)
+    d.set_stimulus(coarse, 0.1, ibt, ibx, layout=0)
+    ref = O.spatiotemporal_stim_features(coarse, 0.1, 0.001, nT, ibx, ibt)
+    assert np.max(np.abs(d.get_stim_features() - ref)) < 1e-11
+    d.close()
+
+
 def test_spatiotemporal_glm():
     def tame(x):                               # keep rates finite under the exp nonlinearity
         for xn in x['glms']:
@@ -193,3 +226,33 @@ def test_spatiotemporal_glm():
 
     g_fd = fd_grad(lp_of, v0, eps=1e-6)
     assert np.max(np.abs(g - g_fd)) < 2e-4 * max(1.0, np.max(np.abs(g_fd)))
+
+
+def test_basis_stimulus_model():
+    """standard_glm with the BasisStimulus background (bkgd.py:45-169): device-built features,
+    log p and packed gradient [bias, w_stim, w_ir] against the oracle."""
+    from theano_pyglm_amd.models import templates
+    tmpl = templates.standard_glm()
+    tmpl['bkgd']['type'] = 'basis'
+    model, popn, data = make_dataset(tmpl, 3, 4.0, seed=31, check=True)
+    assert popn.glm.Dstim == 3 and popn.stim_features().shape == (4000, 3)
+    x = popn.sample(np.random.RandomState(32))
+    lp = popn.compute_log_p(x)
+    lp0, _ = oracle_log_p(popn, data, x)
+    assert np.allclose(lp, lp0, rtol=1e-10)
+    n = 1
+    syms = popn.glm_syms()
+    v0, shapes = packdict(get_vars(syms, x['glms'][n]))
+    assert v0.size == 1 + 3 + 5 * 3
+    g = popn.compute_grad(x, n)
+
+    def lp_of(v):
+        x2 = copy.deepcopy(x)
+        set_vars(syms, x2['glms'][n], unpackdict(v, shapes))
+        return oracle_log_p(popn, data, x2)[0]
+
+    g_fd = fd_grad(lp_of, v0, eps=1e-7)
+    assert np.max(np.abs(g - g_fd)) < 1e-3 * max(1.0, np.max(np.abs(g_fd)))
+    # the GPU-resident batched optimizer handles the stimulus weights too
+    x_t = cd.coord_descent(popn, x0=copy.deepcopy(x), maxiter=1, batched='torch')
+    assert popn.compute_log_p(x_t) > lp

@@ -138,22 +138,26 @@ def test_flat_weights_and_chain_rules():
     assert np.allclose(q.W_eff(y), y['net']['graph']['A'] * y['net']['weights']['W'].reshape(3, 3))
 
 
-def test_stimulus_preprocessing_matches_oracle():
+def test_stimulus_host_twin_matches_oracle():
+    """The numpy twin of the device stimulus-feature build (used by the host simulator)."""
     rng = np.random.RandomState(3)
     st = Population(make_model('spatiotemporal_glm', N=2, dt=0.001))
     stim = rng.randn(20, 3)
     data = {'S': np.zeros((2000, 2)), 'stim': stim, 'dt_stim': 0.1, 'T': 2.0, 'dt': 0.001, 'N': 2}
     st.preprocess_data(data)
+    f = st.glm.bkgd_model.host_features(data, 2000)
     ref = O.spatiotemporal_stim_features(stim, 0.1, 0.001, 2000, st.glm.bkgd_model.ibasis_x,
                                          st.glm.bkgd_model.ibasis_t)
-    assert data['fstim'].shape == (2000, 9) and np.allclose(data['fstim'], ref, atol=1e-12)
+    assert f.shape == (2000, 9) and np.allclose(f, ref, atol=1e-12)
     m = make_model('standard_glm', N=2, dt=0.001)
     m['bkgd']['type'] = 'basis'
     bs = Population(m)
     d2 = {'S': np.zeros((2000, 2)), 'stim': stim[:, :1], 'dt_stim': 0.1, 'T': 2.0, 'dt': 0.001, 'N': 2}
     bs.preprocess_data(d2)
     ref = O.basis_stim_features(stim[:, :1], 0.1, 0.001, 2000, bs.glm.bkgd_model.ibasis)
-    assert np.allclose(d2['fstim'], ref, atol=1e-12)
+    assert np.allclose(bs.glm.bkgd_model.host_features(d2, 2000), ref, atol=1e-12)
+    with pytest.raises(Exception, match="Stim dimension"):
+        bs.preprocess_data({'S': np.zeros((2000, 2)), 'stim': stim, 'dt_stim': 0.1, 'T': 2.0})
 
 
 def test_native_simulate_matches_python_loop():

@@ -23,7 +23,7 @@ OPT_KERNEL = 3
 SYMBOLS = [
     'pgl_last_error', 'pgl_version', 'pgl_device_count', 'pgl_create', 'pgl_destroy',
     'pgl_set_option', 'pgl_set_time_range', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
-    'pgl_set_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
+    'pgl_set_stim_features', 'pgl_set_stimulus', 'pgl_get_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate',
 ]
@@ -86,6 +86,9 @@ def load():
     lib.pgl_set_spikes_f64.argtypes = [vp, vp]
     lib.pgl_set_basis.argtypes = [vp, vp]
     lib.pgl_set_stim_features.argtypes = [vp, vp, C.c_int]
+    lib.pgl_set_stimulus.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int,
+                                     C.c_int, C.c_int]
+    lib.pgl_get_stim_features.argtypes = [vp, vp]
     lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
@@ -210,6 +213,25 @@ class DeviceGlm(object):
             raise ValueError("fstim must be (nT,Dstim)")
         _chk(self.lib.pgl_set_stim_features(self.h, _ptr(f), int(f.shape[1])))
         self.Dstim = int(f.shape[1])
+
+    def set_stimulus(self, stim, dt_stim, basis_t, basis_x=None, layout=0):
+        """Build the dense stimulus feature columns on the device from the raw stimulus
+        (interp -> spatial projection -> causal temporal filtering); see pgl_set_stimulus."""
+        stim = _f64(stim)
+        if stim.ndim != 2:
+            raise ValueError("stim must be (Tstim, D)")
+        bt = _f64(basis_t)
+        bx = None if basis_x is None else _f64(basis_x, (stim.shape[1], np.shape(basis_x)[1]))
+        Bx = stim.shape[1] if bx is None else bx.shape[1]
+        _chk(self.lib.pgl_set_stimulus(self.h, _ptr(stim), stim.shape[0], stim.shape[1], float(dt_stim),
+                                       _ptr(bx), int(Bx), _ptr(bt), bt.shape[0], bt.shape[1],
+                                       int(layout)))
+        self.Dstim = int(Bx * bt.shape[1])
+
+    def get_stim_features(self):
+        out = np.empty((self.nT, self.Dstim))
+        _chk(self.lib.pgl_get_stim_features(self.h, _ptr(out)))
+        return out
 
     # -- hot path -------------------------------------------------------------
     def ll_grad(self, theta, Weff, n_lo=0, n_hi=None, want_grad=True):

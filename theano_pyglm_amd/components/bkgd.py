@@ -39,6 +39,9 @@ class NoStimulus(Component):
     def preprocess_data(self, data):
         data['fstim'] = None
 
+    def upload(self, handle, data):
+        pass
+
 
 def _interp_stim(stim, dt_stim, t):
     t_stim = dt_stim * np.arange(stim.shape[0])
@@ -85,18 +88,26 @@ class BasisStimulus(Component):
         return st
 
     def preprocess_data(self, data):
-        """bkgd.py:122-154."""
+        """bkgd.py:122-154: validation only -- the feature columns themselves
+        (interp + causal convolution, column d*B+b) are built on the device at upload time."""
         if not abs(data['stim'].shape[0] * data['dt_stim'] - data['T']) < data['dt_stim']:
             raise Exception('Stimulus length is not the same as data time length!')
         D = self.bkgd_model['D_stim']
         if not D == data['stim'].shape[1]:
             raise Exception("Stim dimension (%d) is not equal to that specified by model (%d)"
                             % (data['stim'].shape[1], D))
-        t = self.model['dt'] * np.arange(data['S'].shape[0])
+
+    def upload(self, handle, data):
+        dt_stim = self.bkgd_model.get('dt_stim', data['dt_stim'])
+        handle.set_stimulus(np.asarray(data['stim'], dtype=float), dt_stim, self.ibasis, None, layout=1)
+
+    def host_features(self, data, nT):
+        """numpy twin of the device build (used by the host-side simulator only)."""
+        t = self.model['dt'] * np.arange(nT)
         dt_stim = self.bkgd_model.get('dt_stim', data['dt_stim'])
         stim = _interp_stim(np.asarray(data['stim'], dtype=float), dt_stim, t)
         c = bs.convolve_with_basis(stim, self.ibasis)           # (nT,D,B)
-        data['fstim'] = np.ascontiguousarray(c.reshape(c.shape[0], -1))
+        return np.ascontiguousarray(c.reshape(c.shape[0], -1))
 
     def sample(self, acc, rng=None):
         return {'w_stim': 0.01 * _rng(rng).standard_normal(self.n_vars)}
@@ -160,13 +171,23 @@ class SpatiotemporalStimulus(Component):
         return st
 
     def preprocess_data(self, data):
-        """bkgd.py:303-340: interpolate, low-rank convolution, (nT, Bt*Bx) with column bt*Bx+bx."""
-        dt = self.model['dt']
-        t = np.arange(0, data['T'], dt)
+        """bkgd.py:303-340: validation only -- interpolation, spatial projection and the causal
+        temporal filtering ((nT, Bt*Bx), column bt*Bx+bx) run on the device at upload time."""
+        if not self.bkgd_model['D_stim'] == data['stim'].shape[1]:
+            raise Exception("Stim dimension (%d) is not equal to that specified by model (%d)"
+                            % (data['stim'].shape[1], self.bkgd_model['D_stim']))
+
+    def upload(self, handle, data):
+        handle.set_stimulus(np.asarray(data['stim'], dtype=float), data['dt_stim'], self.ibasis_t,
+                            self.ibasis_x, layout=0)
+
+    def host_features(self, data, nT):
+        """numpy twin of the device build (used by the host-side simulator only)."""
+        t = self.model['dt'] * np.arange(nT)
         stim = _interp_stim(np.asarray(data['stim'], dtype=float), data['dt_stim'], t)
         f = bs.convolve_with_low_rank_2d_basis(stim, self.ibasis_x, self.ibasis_t)   # (nt,Bx,Bt)
         f = np.transpose(f, axes=[0, 2, 1])
-        data['fstim'] = np.ascontiguousarray(f.reshape(len(t), self.Bt * self.Bx))
+        return np.ascontiguousarray(f.reshape(len(t), self.Bt * self.Bx))
 
     def sample(self, acc, rng=None):
         r = _rng(rng)

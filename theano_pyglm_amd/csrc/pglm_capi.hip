@@ -432,6 +432,64 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     return PGL_OK;
 }
 
+int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
+                     const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt, int layout)
+{
+    if (!h || !stim || !basis_t) return fail(PGL_ERR_ARG, "null argument");
+    if (Tstim <= 0 || D <= 0 || Bx <= 0 || Rt <= 0 || Bt <= 0 || !(dt_stim > 0) || (layout != 0 && layout != 1))
+        return fail(PGL_ERR_ARG, "bad stimulus description");
+    if (!basis_x && Bx != D) return fail(PGL_ERR_ARG, "identity spatial basis needs Bx == D");
+    const int Dstim = Bx * Bt;
+    if ((h->Kimp + Dstim + 15) / 16 > 40)
+        return fail(PGL_ERR_UNSUPPORTED, "N*B + Dstim exceeds 640 feature columns");
+    if ((size_t)(Rt + 256 + Rt * Bt) * 8 > 64 * 1024) return fail(PGL_ERR_UNSUPPORTED, "temporal basis too long");
+    HIPCHK(hipSetDevice(h->device));
+    DevBuf dstim, dbx, dbt, dzx;
+    auto cleanup = [&]() { release(dstim); release(dbx); release(dbt); release(dzx); };
+    int rc = ensure(dstim, (size_t)Tstim * D * 8);
+    if (!rc) rc = ensure(dbt, (size_t)Rt * Bt * 8);
+    if (!rc) rc = ensure(dzx, (size_t)h->nT * Bx * 8);
+    if (!rc && basis_x) rc = ensure(dbx, (size_t)D * Bx * 8);
+    if (!rc) rc = ensure(h->fstim, (size_t)h->nT * Dstim * 8);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(dstim.p, stim, (size_t)Tstim * D * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbt.p, basis_t, (size_t)Rt * Bt * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && basis_x)
+        e = hipMemcpyAsync(dbx.p, basis_x, (size_t)D * Bx * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const long long total = (long long)h->nT * Bx;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 65535);
+        hipLaunchKernelGGL(k_stim_project, dim3(blocks), dim3(256), 0, h->stream, (const double*)dstim.p,
+                           (long long)Tstim, D, dt_stim, h->dt, basis_x ? (const double*)dbx.p : nullptr,
+                           Bx, (double*)dzx.p, (long long)h->nT);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        dim3 grid((unsigned)((h->nT + 255) / 256), (unsigned)Bx);
+        hipLaunchKernelGGL(k_stim_conv, grid, dim3(256), (size_t)(Rt + 256 + Rt * Bt) * 8, h->stream,
+                           (const double*)dzx.p, (const double*)dbt.p, Rt, Bt, Bx, layout,
+                           (double*)h->fstim.p, (long long)h->nT);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_set_stimulus: ") + hipGetErrorString(e));
+    h->Dstim = Dstim;
+    h->Ktot = h->Kimp + Dstim;
+    h->gibbs_npost = -1;
+    return PGL_OK;
+}
+
+int pgl_get_stim_features(pgl_handle h, double* fstim_out)
+{
+    if (!h || !fstim_out) return fail(PGL_ERR_ARG, "null argument");
+    if (h->Dstim <= 0) return fail(PGL_ERR_STATE, "no stimulus features on the device");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(fstim_out, h->fstim.p, (size_t)h->nT * h->Dstim * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PGL_OK;
+}
+
 static int check_ready(pgl_handle h)
 {
     if (!h) return fail(PGL_ERR_ARG, "null handle");

@@ -1172,6 +1172,81 @@ __global__ __launch_bounds__(64) void k_reduce_parts(const double* __restrict__ 
     if (threadIdx.x == 0) out[k] = s;
 }
 
+// ---------------------------------------------------------------------------
+// Stimulus feature build on the device (bkgd.py:122-154, 303-340; basis.py:201-273):
+//   1. zx[t,bx] = sum_d interp(stim)[t,d] * basis_x[d,bx]   (np.interp onto the dt grid, then the
+//      spatial projection; basis_x == nullptr means identity, Bx == D)
+//   2. f[t,bx,bt] = sum_{tau=1..Rt} zx[t-tau,bx] * basis_t[tau-1,bt]   (strictly causal)
+// written as fstim[t][col], col = bt*Bx+bx (layout 0, SpatiotemporalStimulus) or bx*Bt+bt
+// (layout 1, BasisStimulus: d*B+b).
+// ---------------------------------------------------------------------------
+__global__ void k_stim_project(const double* __restrict__ stim, long long Tstim, int D,
+                               double dt_stim, double dt, const double* __restrict__ basis_x,
+                               int Bx, double* __restrict__ zx, long long nT)
+{
+    const long long total = nT * Bx;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / Bx;
+        const int bx = (int)(i - t * Bx);
+        const double x = dt * (double)t;
+        // np.interp: clamp outside [xp[0], xp[-1]], else slope form on the bracketing interval
+        long long i0 = (long long)floor(x / dt_stim);
+        if (i0 > Tstim - 2) i0 = Tstim - 2;
+        if (i0 < 0) i0 = 0;
+        // guard against x/dt_stim rounding across a knot
+        while (i0 + 1 < Tstim - 1 && dt_stim * (double)(i0 + 1) <= x) ++i0;
+        while (i0 > 0 && dt_stim * (double)i0 > x) --i0;
+        const double x0 = dt_stim * (double)i0, x1 = dt_stim * (double)(i0 + 1);
+        const bool beyond = (Tstim < 2) || (x >= dt_stim * (double)(Tstim - 1));
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double v;
+            if (beyond) {
+                v = stim[(Tstim - 1) * D + d];
+            } else {
+                const double f0 = stim[i0 * D + d], f1 = stim[(i0 + 1) * D + d];
+                v = (f1 - f0) / (x1 - x0) * (x - x0) + f0;
+            }
+            if (basis_x == nullptr) {
+                if (d == bx) acc = v;
+            } else {
+                acc = fma(v, basis_x[(size_t)d * Bx + bx], acc);
+            }
+        }
+        zx[i] = acc;
+    }
+}
+
+// one block = 256 consecutive bins of one spatial column bx; zx window and basis_t in LDS
+__global__ __launch_bounds__(256) void k_stim_conv(const double* __restrict__ zx,
+                                                   const double* __restrict__ basis_t, int Rt,
+                                                   int Bt, int Bx, int layout,
+                                                   double* __restrict__ fstim, long long nT)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* zs = reinterpret_cast<double*>(smem);           // [Rt + 256]
+    double* bs = zs + Rt + 256;                             // [Rt][Bt]
+    const int bx = blockIdx.y;
+    const long long t0 = (long long)blockIdx.x * 256;
+    for (int i = threadIdx.x; i < Rt + 256; i += 256) {
+        const long long t = t0 - Rt + i;
+        zs[i] = (t >= 0 && t < nT) ? zx[t * Bx + bx] : 0.0;
+    }
+    for (int i = threadIdx.x; i < Rt * Bt; i += 256) bs[i] = basis_t[i];
+    __syncthreads();
+    const long long t = t0 + threadIdx.x;
+    if (t >= nT) return;
+    const int Dst = Bx * Bt;
+    for (int bt = 0; bt < Bt; ++bt) {
+        double a = 0.0;
+        // zs index of bin t - tau is threadIdx.x + Rt - tau
+        for (int tau = 1; tau <= Rt; ++tau) a = fma(zs[threadIdx.x + Rt - tau], bs[(tau - 1) * Bt + bt], a);
+        const int colo = layout == 0 ? bt * Bx + bx : bx * Bt + bt;
+        fstim[t * Dst + colo] = a;
+    }
+}
+
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
 __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restrict__ ST,
                                long long nT, int N)

@@ -102,7 +102,10 @@ class Population(object):
             h.set_spikes(S)
             h.set_basis(imp.ibasis)
             if self.glm.Dstim > 0:
-                h.set_stim_features(data['fstim'])
+                if data.get('fstim', None) is not None:
+                    h.set_stim_features(data['fstim'])      # caller-supplied dense features
+                else:
+                    self.glm.bkgd_model.upload(h, data)     # built on the device from data['stim']
             self._handles[id(data)] = h
             data['_device_handle'] = h        # keeps the handle alive as long as the data dict
         return h
@@ -113,6 +116,15 @@ class Population(object):
             'Data must be preprocessed before it can be set'
         self._handle(data)
         self._current = data
+
+    def stim_features(self, data=None):
+        """The dense stimulus feature columns `fstim` (nT, Dstim) of a data sequence (the reference
+        keeps them in data['fstim'], bkgd.py:154 / 340); here they live on the device and are
+        copied out on request."""
+        data = self._current if data is None else data
+        if self.glm.Dstim == 0:
+            return None
+        return self._handle(data).get_stim_features()
 
     def release_data(self):
         """Free the device buffers of every data sequence."""
@@ -257,9 +269,9 @@ class Population(object):
         if self.glm.Dstim > 0:
             tmp = {'S': np.zeros((nT, N)), 'stim': stim, 'dt_stim': dt_stim, 'T': float(T_stop - T_start),
                    'dt': dt}
-            self.glm.bkgd_model.preprocess_data(tmp)
+            fst = self.glm.bkgd_model.host_features(tmp, nT)
             for n in range(N):
-                X[:, n] += tmp['fstim'].dot(self.glm.bkgd_model.flat_weights(vars['glms'][n]['bkgd']))
+                X[:, n] += fst.dot(self.glm.bkgd_model.flat_weights(vars['glms'][n]['bkgd']))
         # imps[n_pre, n_post, :] (population.py:275-282)
         imps = np.array([self.glm.imp_model.impulse(vars['glms'][n]['imp']) for n in range(N)])
         imps = np.transpose(imps, axes=[1, 0, 2])
