@@ -44,7 +44,7 @@ class Problem(object):
         theta = np.zeros((N, P))
         theta[:, 0] = bias_mu + 0.3 * rng.standard_normal(N)
         if Dstim > 0:
-            theta[:, 1:1 + Dstim] = 0.1 * rng.standard_normal((N, Dstim))
+            theta[:, 1:1 + Dstim] = (0.1 if Dstim < 64 else 0.01) * rng.standard_normal((N, Dstim))
         theta[:, 1 + Dstim:] = w_scale * rng.standard_normal((N, N * self.B))
         self.theta = theta
         if weighted:

@@ -260,17 +260,34 @@ def test_tiny_shapes():
     _check(H.Problem(17, 100, H.st_ibasis(), kind='exp', seed=18, rate_hz=50.0, w_scale=0.01))
 
 
+def test_sliced_path_large_populations():
+    """More than 128 neurons / 640 feature columns: the 3-phase sliced path (forward launches
+    accumulating the currents, one elementwise pass, backward launches per slice)."""
+    _check(H.Problem(150, 900, H.std_ibasis(), seed=30, w_scale=0.3))                 # 128 + 22
+    _check(H.Problem(260, 400, H.std_ibasis(), seed=31, w_scale=0.2, weighted=True))  # 3 slices
+    # 640 impulse columns + 8 stimulus columns -> the stimulus gets a slice of its own
+    _check(H.Problem(128, 500, H.std_ibasis(), seed=32, Dstim=8, w_scale=0.3))
+    # dense stimulus wider than one slice (700 columns), few neurons
+    _check(H.Problem(6, 600, H.st_ibasis(), kind='exp', Dstim=700, seed=33, w_scale=0.02), g_rtol=1e-8)
+    # neuron shard + time range on the sliced path
+    p = H.Problem(140, 1000, H.std_ibasis(), seed=34, w_scale=0.3)
+    dev = p.device()
+    ll_f, g_f = dev.ll_grad(p.theta[100:140], p.Weff, 100, 140)
+    ll0, g0 = p.oracle_ll_grad(100, 140)
+    assert np.allclose(ll_f, ll0, rtol=LL_RTOL) and H.rel_err(g_f, g0) < G_RTOL
+    acc_ll, acc_g = 0.0, 0.0
+    for a, b in ((0, 496), (496, 1000)):
+        dev.set_time_range(a, b)
+        ll, g = dev.ll_grad(p.theta[100:140], p.Weff, 100, 140)
+        acc_ll, acc_g = acc_ll + ll, acc_g + g
+    assert np.allclose(acc_ll, ll_f, rtol=1e-12) and H.rel_err(acc_g, g_f) < 1e-12
+    dev.close()
+
+
 def test_unsupported_shapes_fail_loudly():
     from theano_pyglm_amd import _lib
-    p = H.Problem(130, 64, H.std_ibasis(), seed=19)          # 130*5 = 650 > 640 feature columns
-    dev = p.device()
-    with pytest.raises(_lib.PglError, match="640"):
-        dev.ll_grad(p.theta, p.Weff)
-    dev.close()
     q = H.Problem(128, 64, H.std_ibasis(), seed=20)
     dq = q.device()
-    with pytest.raises(_lib.PglError):
-        dq.set_stim_features(np.zeros((64, 8)))              # 640 + 8 columns
     with pytest.raises((_lib.PglError, ValueError)):
         dq.ll_grad(q.theta[:3], q.Weff, 5, 4)                # empty / reversed neuron range
     with pytest.raises(_lib.PglError, match="range"):

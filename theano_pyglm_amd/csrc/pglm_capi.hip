@@ -40,7 +40,7 @@ struct pgl_context {
     int64_t nnz = 0;
     DevBuf S, ST, spk, wlo, whi, phi, fstim;
     std::vector<int> h_ptr;              // host copy of the event-list row pointers (N+1)
-    DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart;
+    DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -80,15 +80,43 @@ struct Plan {
     bool f32;
 };
 
+// A launch covers a slice of the feature columns: presynaptic neurons [np0, np0+Ns) and dense
+// stimulus columns [ds0, ds0+Ds).  One slice = everything when N <= 128 and N*B + Dstim <= 640
+// (the fused path); otherwise the 3-phase path runs forward / backward launches per slice.
+struct Slice {
+    int np0, Ns, ds0, Ds;
+};
+
+static std::vector<Slice> make_slices(const pgl_context* h)
+{
+    std::vector<Slice> out;
+    const int maxNs = std::min(128, 640 / h->B);
+    int ds_left = h->Dstim, ds0 = 0;
+    for (int np0 = 0; np0 < h->N; np0 += maxNs) {
+        Slice sl{np0, std::min(maxNs, h->N - np0), 0, 0};
+        if (np0 + sl.Ns >= h->N && ds_left > 0 && sl.Ns * h->B + ds_left <= 640) {
+            sl.ds0 = ds0; sl.Ds = ds_left; ds0 += ds_left; ds_left = 0;     // stimulus rides along
+        }
+        out.push_back(sl);
+    }
+    while (ds_left > 0) {
+        const int d = std::min(640, ds_left);
+        out.push_back(Slice{0, 0, ds0, d});
+        ds0 += d; ds_left -= d;
+    }
+    return out;
+}
+
 static const int kKT[] = {2, 4, 10, 13, 20, 40};
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 
-static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
+static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl)
 {
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
     pl.nPT = (pl.npost + 15) / 16;
-    const int need = (h->Ktot + 15) / 16;
+    const int ktot_s = sl.Ns * h->B + sl.Ds;
+    const int need = std::max(1, (ktot_s + 15) / 16);
     pl.f32 = h->opt_f32 != 0;
     // version 2: f64 features, 8 waves (2 per SIMD), one workgroup per CU
     // version 3: the same kernel with f32 features / basis taps (PGL_OPT_FEATURE_F32)
@@ -119,7 +147,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
             }
         if (pl.KTW == 0 || pl.KTW * pl.KSPLIT > 40)
             return fail(PGL_ERR_UNSUPPORTED,
-                        "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
+                        "slice of " + std::to_string(ktot_s) + " feature columns exceeds 640");
         pl.KT = pl.KTW * pl.KSPLIT;
         pl.wpb = nw;
         pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
@@ -155,13 +183,12 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, Plan& pl)
         off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;       // V1 keeps f64 tables
     else
         off += (((size_t)2 * h->B * pl.RP * esz) + 15) & ~(size_t)15;
-    off += (size_t)h->N * pl.cap * 8;
+    off += (size_t)sl.Ns * pl.cap * 8;
     if (pl.version >= 2) {
-        off += 2 * ((((size_t)2 * h->N * 4) + 15) & ~(size_t)15);
+        off += 2 * ((((size_t)2 * sl.Ns * 4) + 15) & ~(size_t)15);
         off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8 + 256;
-        if (h->N > 128) return fail(PGL_ERR_UNSUPPORTED, "N > 128 neurons");
     } else {
-        off += 2 * ((((size_t)h->N * 4) + 15) & ~(size_t)15);
+        off += 2 * ((((size_t)sl.Ns * 4) + 15) & ~(size_t)15);
     }
     pl.lds = off;
     if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
@@ -287,7 +314,7 @@ int pgl_destroy(pgl_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
-                      &h->gbpart, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
+                      &h->gbpart, &h->Xbuf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan};
     for (DevBuf* b : bufs) release(*b);
     for (int i = 0; i < 4; ++i)
@@ -418,8 +445,6 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     if (!h) return fail(PGL_ERR_ARG, "null handle");
     if (Dstim < 0 || (Dstim > 0 && !fstim)) return fail(PGL_ERR_ARG, "bad stimulus features");
     HIPCHK(hipSetDevice(h->device));
-    if ((h->Kimp + Dstim + 15) / 16 > 40)
-        return fail(PGL_ERR_UNSUPPORTED, "N*B + Dstim exceeds 640 feature columns");
     h->Dstim = Dstim;
     h->Ktot = h->Kimp + Dstim;
     h->gibbs_npost = -1;
@@ -440,8 +465,6 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
         return fail(PGL_ERR_ARG, "bad stimulus description");
     if (!basis_x && Bx != D) return fail(PGL_ERR_ARG, "identity spatial basis needs Bx == D");
     const int Dstim = Bx * Bt;
-    if ((h->Kimp + Dstim + 15) / 16 > 40)
-        return fail(PGL_ERR_UNSUPPORTED, "N*B + Dstim exceeds 640 feature columns");
     if ((size_t)(Rt + 256 + Rt * Bt) * 8 > 64 * 1024) return fail(PGL_ERR_UNSUPPORTED, "temporal basis too long");
     HIPCHK(hipSetDevice(h->device));
     DevBuf dstim, dbx, dbt, dzx;
@@ -498,30 +521,13 @@ static int check_ready(pgl_handle h)
     return PGL_OK;
 }
 
-// Enqueue prep + fused + finalize on the handle's stream.  All pointers are device pointers.
-static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double* d_theta,
-                           const double* d_Weff, double* d_ll, double* d_grad)
+static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, bool want_grad,
+                        int mode, FusedParams& fp)
 {
-    const int P = 1 + h->Dstim + h->Kimp;
-    (void)P;
-    ENSURE(h->Wfrag, (size_t)pl.nPT * pl.KS * 64 * 8);
-    ENSURE(h->bias, (size_t)pl.nPT * 16 * 8);
-    ENSURE(h->llpart, (size_t)pl.nChunks * pl.nPT * pl.KSPLIT * 64 * 8);
-    ENSURE(h->gbpart, (size_t)pl.nChunks * pl.nPT * pl.KSPLIT * 64 * 8);
-    if (d_grad) ENSURE(h->Gpart, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
-
-    HIPCHK(hipEventRecord(h->ev[0], h->stream));
-    {
-        const long long total = (long long)pl.nPT * pl.KS * 64;
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
-                           (double*)h->Wfrag.p, (double*)h->bias.p, h->N, h->B, h->Dstim, h->Kimp,
-                           h->Ktot, pl.KS, n_lo, pl.npost, pl.nPT, pl.version >= 2 ? 1 : 0);
-        HIPCHK(hipGetLastError());
-    }
-    FusedParams fp;
-    fp.nT = h->nT; fp.N = h->N; fp.B = h->B; fp.R = h->R; fp.nlin = h->nlin;
-    fp.Dstim = h->Dstim; fp.Kimp = h->Kimp; fp.Ktot = h->Ktot; fp.dt = h->dt;
+    fp.nT = h->nT; fp.N = sl.Ns; fp.B = h->B; fp.R = h->R; fp.nlin = h->nlin;
+    fp.Dstim = sl.Ds; fp.Kimp = sl.Ns * h->B; fp.Ktot = fp.Kimp + sl.Ds; fp.dt = h->dt;
+    fp.Nall = h->N; fp.np0 = sl.np0; fp.DsAll = h->Dstim; fp.ds0 = sl.ds0;
+    fp.mode = mode; fp.Xbuf = (double*)h->Xbuf.p; fp.xstride = pl.nPT * 16;
     fp.spk = (const int2*)h->spk.p; fp.wlo = (const int*)h->wlo.p; fp.whi = (const int*)h->whi.p;
     fp.S = (const uint8_t*)h->S.p; fp.fstim = (const double*)h->fstim.p; fp.phi = (const double*)h->phi.p;
     fp.Wfrag = (const double*)h->Wfrag.p; fp.bias = (const double*)h->bias.p;
@@ -532,29 +538,142 @@ static int enqueue_ll_grad(pgl_handle h, const Plan& pl, int n_lo, const double*
     fp.Gpart = (double*)h->Gpart.p; fp.llpart = (double*)h->llpart.p; fp.gbpart = (double*)h->gbpart.p;
     fp.tile0 = pl.tile0;
     fp.t_hi = h->t_hi;
-    fp.want_grad = d_grad ? 1 : 0;
+    fp.want_grad = want_grad ? 1 : 0;
     fp.dbg = h->opt_dbg;
+}
 
-    HIPCHK(hipEventRecord(h->ev[1], h->stream));
-    hipError_t e = (pl.version >= 2) ? launch_fused2(pl, fp, h->stream)
-                   : pl.f32        ? launch_fused_kt<float>(pl, fp, h->stream)
-                                   : launch_fused_kt<double>(pl, fp, h->stream);
-    if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
-    HIPCHK(hipEventRecord(h->ev[2], h->stream));
-    {
+static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
+                       const double* d_Weff)
+{
+    ENSURE(h->Wfrag, (size_t)pl.nPT * pl.KS * 64 * 8);
+    ENSURE(h->bias, (size_t)pl.nPT * 16 * 8);
+    const long long total = (long long)pl.nPT * pl.KS * 64;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
+                       (double*)h->Wfrag.p, (double*)h->bias.p, sl.Ns, h->B, sl.Ds, sl.Ns * h->B,
+                       sl.Ns * h->B + sl.Ds, pl.KS, n_lo, pl.npost, pl.nPT, pl.version >= 2 ? 1 : 0,
+                       h->N, sl.np0, h->Dstim, sl.ds0);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
+                                const double* d_Weff, double* d_ll, double* d_grad)
+{
+    const long long nfrag = (long long)pl.nPT * pl.KT * 256;
+    const int blocks = (int)((nfrag + 255) / 256);
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->Gpart.p,
+                       (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
+                       sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
+                       pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    return (pl.version >= 2) ? launch_fused2(pl, fp, s)
+           : pl.f32          ? launch_fused_kt<float>(pl, fp, s)
+                             : launch_fused_kt<double>(pl, fp, s);
+}
+
+// Enqueue one evaluation on the handle's stream.  All pointers are device pointers.
+//  * one slice (N <= 128 and N*B + Dstim <= 640): prep + fused kernel + finalize;
+//  * otherwise the 3-phase path: per slice a forward-only launch accumulating the currents in
+//    Xbuf (nT x 16*nPT doubles), one elementwise pass Xbuf -> (ll, r), per slice a backward-only
+//    launch.  Same kernels, the F tile is simply generated twice per slice.
+static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
+                           const double* d_Weff, double* d_ll, double* d_grad)
+{
+    const std::vector<Slice> slices = make_slices(h);
+    std::vector<Plan> plans(slices.size());
+    for (size_t i = 0; i < slices.size(); ++i) {
+        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i]);
+        if (rc) return rc;
+    }
+    const bool sliced = slices.size() > 1;
+    if (sliced && plans[0].version < 2)
+        return fail(PGL_ERR_UNSUPPORTED, "PGL_OPT_KERNEL=1 supports N <= 128 and <= 640 feature columns");
+    size_t maxG = 0, maxLL = 0;
+    for (const Plan& pl : plans) {
+        maxG = std::max(maxG, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
+        maxLL = std::max(maxLL, (size_t)pl.nChunks * pl.nPT * pl.KSPLIT * 64 * 8);
+    }
+    ENSURE(h->llpart, maxLL);
+    ENSURE(h->gbpart, maxLL);
+    if (d_grad) ENSURE(h->Gpart, maxG);
+    const int P = 1 + h->Dstim + h->Kimp;
+
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    if (!sliced) {
+        const Plan& pl = plans[0];
+        int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
+        if (rc) return rc;
+        FusedParams fp;
+        fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
+        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        hipError_t e = launch_any(pl, fp, h->stream);
+        if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
+        HIPCHK(hipEventRecord(h->ev[2], h->stream));
         if (d_grad) {
-            const long long nfrag = (long long)pl.nPT * pl.KT * 256;
-            const int blocks = (int)((nfrag + 255) / 256);
-            hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream,
-                               (const double*)h->Gpart.p, (const double*)h->llpart.p,
-                               (const double*)h->gbpart.p, d_Weff, d_ll, d_grad, h->N, h->B,
-                               h->Dstim, h->Kimp, h->Ktot, pl.KT, n_lo, pl.npost, pl.nPT, pl.nChunks);
-            HIPCHK(hipGetLastError());
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad);
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(64), 0, h->stream,
-                           (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad,
-                           1 + h->Dstim + h->Kimp, pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
+                           (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
+                           pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
         HIPCHK(hipGetLastError());
+    } else {
+        const Plan& p0 = plans[0];
+        const int xs = p0.nPT * 16;
+        const long long row0 = (long long)p0.tile0 * 16;
+        const long long row1 = std::min<long long>(h->nT, (long long)(p0.tile0 + p0.nTiles) * 16);
+        ENSURE(h->Xbuf, (size_t)h->nT * xs * 8);
+        HIPCHK(hipMemsetAsync((double*)h->Xbuf.p + row0 * xs, 0, (size_t)(row1 - row0) * xs * 8, h->stream));
+        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        for (size_t i = 0; i < slices.size(); ++i) {          // phase 1: X += F_s . W_s
+            int rc = launch_prep(h, plans[i], slices[i], n_lo, d_theta, d_Weff);
+            if (rc) return rc;
+            FusedParams fp;
+            fill_params(h, plans[i], slices[i], n_lo, false, 1, fp);
+            hipError_t e = launch_any(plans[i], fp, h->stream);
+            if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("forward launch: ") + hipGetErrorString(e));
+        }
+        {                                                      // phase 2: X -> (ll, r)
+            const int rows = 512;
+            const long long nrows = h->t_hi - h->t_lo;
+            const int nblk = (int)((nrows + rows - 1) / rows);
+            ENSURE(h->tmpA, (size_t)nblk * p0.npost * 8);
+            ENSURE(h->tmpB, (size_t)nblk * p0.npost * 8);
+            dim3 grid((unsigned)nblk, (unsigned)((p0.npost + 255) / 256));
+            hipLaunchKernelGGL(k_rows_epilogue, grid, dim3(256), 0, h->stream, (double*)h->Xbuf.p, xs,
+                               (const double*)h->bias.p, (const uint8_t*)h->S.p, h->N, n_lo, p0.npost,
+                               (long long)h->t_lo, (long long)h->t_hi, rows, h->nlin, h->dt,
+                               (double*)h->tmpA.p, (double*)h->tmpB.p);
+            HIPCHK(hipGetLastError());
+            if (row1 > h->t_hi) {
+                hipLaunchKernelGGL(k_rows_zero, dim3(64), dim3(256), 0, h->stream, (double*)h->Xbuf.p, xs,
+                                   (long long)h->t_hi, row1);
+                HIPCHK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_rows_reduce, dim3(p0.npost), dim3(64), 0, h->stream,
+                               (const double*)h->tmpA.p, (const double*)h->tmpB.p, nblk, p0.npost, P,
+                               d_ll, d_grad);
+            HIPCHK(hipGetLastError());
+        }
+        if (d_grad) {                                          // phase 3: G_s += F_s^T . r
+            for (size_t i = 0; i < slices.size(); ++i) {
+                int rc = launch_prep(h, plans[i], slices[i], n_lo, d_theta, d_Weff);   // only geometry/bias
+                if (rc) return rc;
+                FusedParams fp;
+                fill_params(h, plans[i], slices[i], n_lo, true, 2, fp);
+                hipError_t e = launch_any(plans[i], fp, h->stream);
+                if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
+                rc = launch_finalize_grad(h, plans[i], slices[i], n_lo, d_Weff, d_ll, d_grad);
+                if (rc) return rc;
+            }
+        }
+        HIPCHK(hipEventRecord(h->ev[2], h->stream));
     }
     HIPCHK(hipEventRecord(h->ev[3], h->stream));
     h->timing_valid = true;
@@ -568,10 +687,8 @@ int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta, con
     if (rc) return rc;
     if (!d_theta || !d_Weff || !d_ll) return fail(PGL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    Plan pl;
-    rc = make_plan(h, n_lo, n_hi, pl);
-    if (rc) return rc;
-    return enqueue_ll_grad(h, pl, n_lo, d_theta, d_Weff, d_ll, d_grad);
+    if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
+    return enqueue_ll_grad(h, n_lo, n_hi, d_theta, d_Weff, d_ll, d_grad);
 }
 
 int pgl_sync(pgl_handle h)
@@ -589,18 +706,16 @@ int pgl_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* theta, const dou
     if (rc) return rc;
     if (!theta || !Weff || !ll_out) return fail(PGL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    Plan pl;
-    rc = make_plan(h, n_lo, n_hi, pl);
-    if (rc) return rc;
+    if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     const size_t P = 1 + (size_t)h->Dstim + h->Kimp;
-    const size_t np = (size_t)pl.npost;
+    const size_t np = (size_t)(n_hi - n_lo);
     ENSURE(h->theta, np * P * 8);
     ENSURE(h->Weff, (size_t)h->N * h->N * 8);
     ENSURE(h->ll, np * 8);
     if (grad_out) ENSURE(h->grad, np * P * 8);
     HIPCHK(hipMemcpyAsync(h->theta.p, theta, np * P * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->Weff.p, Weff, (size_t)h->N * h->N * 8, hipMemcpyHostToDevice, h->stream));
-    rc = enqueue_ll_grad(h, pl, n_lo, (const double*)h->theta.p, (const double*)h->Weff.p,
+    rc = enqueue_ll_grad(h, n_lo, n_hi, (const double*)h->theta.p, (const double*)h->Weff.p,
                          (double*)h->ll.p, grad_out ? (double*)h->grad.p : nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ll_out, h->ll.p, np * 8, hipMemcpyDeviceToHost, h->stream));
@@ -627,8 +742,9 @@ int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms)
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
 {
     if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
+    const std::vector<Slice> slices = make_slices(h);
     Plan pl;
-    int rc = make_plan(h, n_lo, n_hi, pl);
+    int rc = make_plan(h, n_lo, n_hi, slices[0], pl);
     if (rc) return rc;
     const double P = 1.0 + h->Dstim + h->Kimp;
     double v[9];

@@ -56,6 +56,13 @@ struct FusedParams {
     double* __restrict__ Gpart;          // [nChunks][nPT][KT][4][64]
     double* __restrict__ llpart;         // [nChunks][nPT][64]
     double* __restrict__ gbpart;         // [nChunks][nPT][64]
+    // feature-column slice (general path for N > 128 or more than 640 columns): this launch
+    // covers presynaptic neurons [np0, np0+N) and stimulus columns [ds0, ds0+Dstim); N / Dstim /
+    // Kimp above are then the slice's, Nall / DsAll the strides of S, the window tables and fstim
+    int Nall, np0, DsAll, ds0;
+    int mode;                            // 0 fused; 1 forward only: X += F.W; 2 backward only: r from Rbuf
+    double* __restrict__ Xbuf;           // (nT, xstride) currents / residuals of the 3-phase path
+    int xstride;
     int tile0;                           // first 16-row tile of the evaluated time range
     long long t_hi;                      // rows >= t_hi are excluded from ll / gradient
     int want_grad;
@@ -653,8 +660,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             const int tl = tile_beg + q;
             int lo = 0, cnt = 0;
             if (tl < tile_end) {
-                lo = p.wlo[(size_t)tl * N + tid];
-                cnt = p.whi[(size_t)tl * N + tid] - lo;
+                lo = p.wlo[(size_t)tl * p.Nall + p.np0 + tid];
+                cnt = p.whi[(size_t)tl * p.Nall + p.np0 + tid] - lo;
             }
             s_lo[(tl & 1) * N + tid] = lo;
             s_cnt[(tl & 1) * N + tid] = cnt;
@@ -696,8 +703,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         }
         int w2lo = 0, w2cnt = 0;
         if (tid < N && tile + 2 < tile_end && !(p.dbg & 32)) {
-            w2lo = p.wlo[(size_t)(tile + 2) * N + tid];
-            w2cnt = p.whi[(size_t)(tile + 2) * N + tid] - w2lo;
+            w2lo = p.wlo[(size_t)(tile + 2) * p.Nall + p.np0 + tid];
+            w2cnt = p.whi[(size_t)(tile + 2) * p.Nall + p.np0 + tid] - w2lo;
         }
         // dense stimulus feature columns of this tile
         if (p.Dstim > 0) {
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 const int t = id / p.Dstim;
                 const int j = id % p.Dstim;
                 const long long tg = (long long)t0 + t;
-                Fs[t * rsf + p.Kimp + j] = (FT)((tg < p.nT) ? p.fstim[tg * p.Dstim + j] : 0.0);
+                Fs[t * rsf + p.Kimp + j] = (FT)((tg < p.nT) ? p.fstim[tg * p.DsAll + p.ds0 + j] : 0.0);
             }
         }
         // ---- F tile from the staged events ----
@@ -730,12 +737,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         for (int e = 0; e < EPW; ++e) {
             const long long tg = (long long)t0 + grp + 4 * er[e];
             const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-            sc[e] = (double)p.S[tc * N + nglob];
+            sc[e] = (double)p.S[tc * p.Nall + nglob];
         }
         // ---- forward over this wave's K slice ----
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
         d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-        if (active && !(p.dbg & 8)) {
+        if (active && !(p.dbg & 8) && p.mode != 2) {
             const FT* fa = Fs + col * rsf + kcol0 + grp;
             const double* wr_s = wrow;
             asm volatile("" : "+s"(wr_s));
@@ -783,7 +790,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         __syncthreads();
 
         // ---- epilogue: the tile's 256 elements are split over its KSPLIT waves ----
-        if (active) {
+        if (active && p.mode == 1) {
+            // forward-only launch of the sliced path: add this slice's partial currents to Xbuf
+#pragma unroll
+            for (int e = 0; e < EPW; ++e) {
+                const int r = er[e];
+                double x = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < KSPLIT; ++k2)
+                    x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
+                const long long tg = (long long)t0 + grp + 4 * r;
+                if (emine && tg < p.nT) p.Xbuf[tg * p.xstride + pt * 16 + col] += x;
+            }
+        } else if (active && p.mode == 0) {
 #pragma unroll
             for (int e = 0; e < EPW; ++e) {
                 const int r = er[e];
@@ -811,10 +830,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         __syncthreads();
 
         // ---- backward on this wave's K slice ----
-        if (active && p.want_grad && !(p.dbg & 16)) {
+        if (active && p.want_grad && !(p.dbg & 16) && p.mode != 1) {
             double rr[4];
+            if (p.mode == 2) {              // residuals of the sliced path come from Xbuf
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rr[r] = Rb[(size_t)ptl * 256 + r * 64 + lane];
+                for (int r = 0; r < 4; ++r) {
+                    const long long tg = (long long)t0 + grp + 4 * r;
+                    rr[r] = (tg < p.nT) ? p.Xbuf[tg * p.xstride + pt * 16 + col] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rr[r] = Rb[(size_t)ptl * 256 + r * 64 + lane];
+            }
             const FT* fb = Fs + grp * rsf + kcol0 + col;
             constexpr int NS = 4 * KTW;
             constexpr int PD = (NS < 4) ? NS : 4;
@@ -855,9 +882,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
 __global__ void k_prep_w(const double* __restrict__ theta, const double* __restrict__ Weff,
                          double* __restrict__ Wfrag, double* __restrict__ bias, int N, int B,
                          int Dstim, int Kimp, int Ktot, int KS, int n_lo, int npost, int nPT,
-                         int pair)
+                         int pair, int Nall, int np0, int DsAll, int ds0)
 {
-    const int P = 1 + Dstim + Kimp;
+    // N / Dstim / Kimp describe the launch's feature-column slice (see FusedParams)
+    const int P = 1 + DsAll + Nall * B;
     const long long total = (long long)nPT * KS * 64;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -869,10 +897,10 @@ __global__ void k_prep_w(const double* __restrict__ theta, const double* __restr
         double v = 0.0;
         if (n < npost && k < Ktot) {
             if (k < Kimp) {
-                const int npre = k / B;
-                v = theta[(size_t)n * P + 1 + Dstim + k] * Weff[(size_t)npre * N + (n_lo + n)];
+                const int npre = np0 + k / B;
+                v = theta[(size_t)n * P + 1 + DsAll + np0 * B + k] * Weff[(size_t)npre * Nall + (n_lo + n)];
             } else {
-                v = theta[(size_t)n * P + 1 + (k - Kimp)];
+                v = theta[(size_t)n * P + 1 + ds0 + (k - Kimp)];
             }
         }
         // pair layout (V2): [pt][ks/2][lane][ks&1] so that one 16-byte load feeds two k-steps
@@ -891,9 +919,9 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
                            const double* __restrict__ gbpart, const double* __restrict__ Weff,
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
-                           int nChunks)
+                           int nChunks, int Nall, int np0, int DsAll, int ds0)
 {
-    const int P = 1 + Dstim + Kimp;
+    const int P = 1 + DsAll + Nall * B;
     const long long nfrag = (long long)nPT * KT * 256;
     const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (grad_out != nullptr && gid < nfrag) {
@@ -908,10 +936,10 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
             for (int c = 0; c < nChunks; ++c)
                 s += Gpart[((size_t)c * nPT + pt) * (size_t)KT * 256 + (size_t)(kt * 4 + r) * 64 + lane];
             if (k < Kimp) {
-                const int npre = k / B;
-                grad_out[(size_t)n * P + 1 + Dstim + k] = s * Weff[(size_t)npre * N + (n_lo + n)];
+                const int npre = np0 + k / B;
+                grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (n_lo + n)];
             } else {
-                grad_out[(size_t)n * P + 1 + (k - Kimp)] = s;
+                grad_out[(size_t)n * P + 1 + ds0 + (k - Kimp)] = s;
             }
         }
     }
@@ -944,6 +972,69 @@ __global__ __launch_bounds__(64) void k_finalize_ll(const double* __restrict__ l
     if (threadIdx.x == 0) {
         ll_out[n] = sl;
         if (grad_out != nullptr) grad_out[(size_t)n * P] = sg;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sliced (general) path, phase 2: x = Xbuf + bias -> ll terms and residuals r (in place).
+// Thread = one column n of `rows` consecutive bins; per-thread ll / sum(r) partials are reduced
+// per neuron by k_rows_reduce (fixed order).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_epilogue(double* __restrict__ Xbuf, int xstride,
+                                                       const double* __restrict__ bias,
+                                                       const uint8_t* __restrict__ S, int Nall,
+                                                       int n_lo, int npost, long long t_lo,
+                                                       long long t_hi, int rows, int nlin, double dt,
+                                                       double* __restrict__ llp,
+                                                       double* __restrict__ gbp)
+{
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= npost) return;
+    const long long t0 = t_lo + (long long)blockIdx.x * rows;
+    long long t1 = t0 + rows;
+    if (t1 > t_hi) t1 = t_hi;
+    const double b = bias[n];
+    double ll = 0.0, gb = 0.0;
+    for (long long t = t0; t < t1; ++t) {
+        const double x = Xbuf[t * xstride + n] + b;
+        const double s = (double)S[t * Nall + n_lo + n];
+        double term, res;
+        pgl_rate_terms(x, s, nlin, dt, term, res, PGL_C);
+        ll += term;
+        gb += res;
+        Xbuf[t * xstride + n] = res;
+    }
+    llp[(size_t)blockIdx.x * npost + n] = ll;
+    gbp[(size_t)blockIdx.x * npost + n] = gb;
+}
+
+// rows [t_lo,t_hi) outside the evaluated range must carry r = 0 for the backward launches
+__global__ void k_rows_zero(double* __restrict__ Xbuf, int xstride, long long r0, long long r1)
+{
+    const long long total = (r1 - r0) * xstride;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x)
+        Xbuf[r0 * xstride + i] = 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_rows_reduce(const double* __restrict__ llp,
+                                                    const double* __restrict__ gbp, int nblk,
+                                                    int npost, int P, double* __restrict__ ll_out,
+                                                    double* __restrict__ grad_out)
+{
+    const int n = blockIdx.x;
+    double a = 0.0, g = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+        a += llp[(size_t)b * npost + n];
+        g += gbp[(size_t)b * npost + n];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        g += __shfl_xor(g, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        ll_out[n] = a;
+        if (grad_out != nullptr) grad_out[(size_t)n * P] = g;
     }
 }
 
