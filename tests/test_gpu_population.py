@@ -256,3 +256,43 @@ def test_basis_stimulus_model():
     # the GPU-resident batched optimizer handles the stimulus weights too
     x_t = cd.coord_descent(popn, x0=copy.deepcopy(x), maxiter=1, batched='torch')
     assert popn.compute_log_p(x_t) > lp
+
+
+def test_wide_spatiotemporal_stimulus_sliced():
+    """spatiotemporal_glm with a wide stimulus (D_stim = 256, identity spatial basis ->
+    3*256 = 768 stimulus columns + 3*N impulse columns > 640): device feature build and the
+    sliced ll+grad path against the oracle (a small version of the C5 stress variant)."""
+    from theano_pyglm_amd.models import templates
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = 256
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': 256}
+    tmpl['bkgd']['sigma'] = 0.05
+
+    def tame(x):
+        for xn in x['glms']:
+            xn['bias']['bias'] = np.array([2.0])
+
+    model, popn, data = make_dataset(tmpl, 4, 1.5, seed=41, check=True, adjust=tame)
+    assert popn.glm.Dstim == 768
+    x = popn.sample(np.random.RandomState(42))
+    tame(x)
+    lp = popn.compute_log_p(x)
+    lp0, _ = oracle_log_p(popn, data, x)
+    assert np.isfinite(lp) and np.allclose(lp, lp0, rtol=1e-10)
+    # packed gradient [bias, w_t(3), w_x(256), w_ir(12)] along a random direction vs oracle differences
+    n = 2
+    syms = popn.glm_syms()
+    v0, shapes = packdict(get_vars(syms, x['glms'][n]))
+    assert v0.size == 1 + 3 + 256 + 12
+    g = popn.compute_grad(x, n)
+    d = np.random.RandomState(43).randn(v0.size)
+    d /= np.linalg.norm(d)
+
+    def lp_of(v):
+        x2 = copy.deepcopy(x)
+        set_vars(syms, x2['glms'][n], unpackdict(v, shapes))
+        return oracle_log_p(popn, data, x2)[0]
+
+    eps = 1e-6
+    fd = (lp_of(v0 + eps * d) - lp_of(v0 - eps * d)) / (2 * eps)
+    assert abs(fd - g.dot(d)) < 1e-4 * max(1.0, abs(fd))

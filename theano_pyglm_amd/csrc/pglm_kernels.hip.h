@@ -1291,7 +1291,9 @@ __global__ void k_stim_project(const double* __restrict__ stim, long long Tstim,
         const double x0 = dt_stim * (double)i0, x1 = dt_stim * (double)(i0 + 1);
         const bool beyond = (Tstim < 2) || (x >= dt_stim * (double)(Tstim - 1));
         double acc = 0.0;
-        for (int d = 0; d < D; ++d) {
+        const int d_lo = (basis_x == nullptr) ? bx : 0;          // identity spatial basis: column bx only
+        const int d_hi = (basis_x == nullptr) ? bx + 1 : D;
+        for (int d = d_lo; d < d_hi; ++d) {
             double v;
             if (beyond) {
                 v = stim[(Tstim - 1) * D + d];
@@ -1299,11 +1301,7 @@ __global__ void k_stim_project(const double* __restrict__ stim, long long Tstim,
                 const double f0 = stim[i0 * D + d], f1 = stim[(i0 + 1) * D + d];
                 v = (f1 - f0) / (x1 - x0) * (x - x0) + f0;
             }
-            if (basis_x == nullptr) {
-                if (d == bx) acc = v;
-            } else {
-                acc = fma(v, basis_x[(size_t)d * Bx + bx], acc);
-            }
+            acc = (basis_x == nullptr) ? v : fma(v, basis_x[(size_t)d * Bx + bx], acc);
         }
         zx[i] = acc;
     }
