@@ -311,3 +311,28 @@ def test_legacy_and_f32_kernels_agree():
     assert np.allclose(ll2, ll0, rtol=1e-8) and H.rel_err(g2, g0) < 1e-6
     for d in (d0, d1, d2):
         d.close()
+
+
+def test_nonfinite_semantics_match_reference_expression():
+    """lam underflows to 0 for x < -745: glm.py:52 gives log(0)*S = NaN (and a NaN gradient),
+    which fit_glm maps to 1e16 / 0 (coord_descent.py:170-182).  exp overflow gives -inf.  Other
+    neurons of the same launch stay finite."""
+    p = H.Problem(5, 800, H.std_ibasis(), seed=60)
+    p.theta[1, 0] = -900.0                       # neuron 1: lam == 0 everywhere
+    dev = p.device()
+    ll, g = dev.ll_grad(p.theta, p.Weff)
+    ll0, g0 = p.oracle_ll_grad()
+    assert np.isnan(ll[1]) and np.isnan(ll0[1])
+    assert np.all(np.isnan(g[1])) 
+    ok = [0, 2, 3, 4]
+    assert np.allclose(ll[ok], ll0[ok], rtol=LL_RTOL) and H.rel_err(g[ok], g0[ok]) < G_RTOL
+    dev.close()
+    q = H.Problem(3, 400, H.st_ibasis(), kind='exp', seed=61, w_scale=0.01)
+    q.theta[2, 0] = 800.0                        # exp(800) = inf
+    dq = q.device()
+    ll, g = dq.ll_grad(q.theta, q.Weff)
+    with np.errstate(over='ignore', invalid='ignore'):
+        ll0, g0 = q.oracle_ll_grad()
+    assert ll[2] == -np.inf and ll0[2] == -np.inf
+    assert np.allclose(ll[:2], ll0[:2], rtol=LL_RTOL)
+    dq.close()

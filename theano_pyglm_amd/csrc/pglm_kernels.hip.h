@@ -185,9 +185,10 @@ __device__ __forceinline__ void pgl_rate_terms(const double x, const double s, c
             term = fma(pgl_log(lam, C), s, term);
             res = (-dt + s * pgl_rcp(lam)) * sig;
         }
-        // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52)
+        // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52), and
+        // its derivative S*lam'/lam = 0/0 = NaN (callers zero NaN gradients, coord_descent.py:179)
         term = (lam == 0.0) ? __builtin_nan("") : term;
-        res = (x != x) ? x : res;
+        res = (lam == 0.0 || x != x) ? __builtin_nan("") : res;
     } else {
         const double lam = pgl_exp(x, C);
         term = fma(x, s, -dt * lam);
