@@ -136,6 +136,14 @@ int pgl_gibbs_ll(pgl_handle h, int n_pre, double aw_cur, const double* w, int K,
  * new sample into the state dict): I_net += delta * I_imp[:,n_pre] on the device. */
 int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
 
+/* Spike-triggered average, pyglm/utils/sta.py:6-85 (used by smart_init.py:28-98 and 100-158):
+ *   A[i,l,d] = sum_t S[t,n_i] * istim[t-l,d] / sum_t S[t,n_i],  l = 0..L-1, terms with t-l < 0 dropped,
+ * istim = np.interp of stim (Tstim,D) to the bin grid, divided by dt_stim/dt (sta.py:27-41).
+ *   neurons: n_sel indices (NULL = all N);  A_out host (n_sel, L, D).  A silent neuron gives NaN
+ *   like the reference's 0/0.  Uses the spike data already resident on the handle. */
+int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
+            const int* neurons, int n_sel, double* A_out);
+
 /* Population.simulate (population.py:233-389), native host implementation (no GPU needed):
  * integrate-and-fire thinning of the conditional intensity.  Per bin t: lam = nlin(X[t,:]),
  * acc += lam*dt, a neuron spikes while acc > thr (thr ~ Exp(1), redrawn after each spike,

@@ -201,6 +201,53 @@ def spatiotemporal_stim_features(stim, dt_stim, dt, nT, ibasis_x, ibasis_t):
     return f.reshape(nT, -1)
 
 
+def project_onto_basis(f, basis, lam=0.0):
+    """basis.py:416-436: beta = inv(basis^T basis + lam I) basis^T f, shape (B,1)."""
+    R, B = basis.shape
+    f = np.asarray(f, dtype=float).reshape(R, -1)
+    return np.dot(np.dot(np.linalg.inv(np.dot(basis.T, basis) + lam * np.eye(B)), basis.T), f)
+
+
+def sta(stim, S, dt, dt_stim, L, Ns):
+    """pyglm/utils/sta.py:6-85 in its dense form: interpolate the stimulus to the bin grid and
+    divide by dt_stim/dt (27-41), pad L zero rows in front (44-45), build the lag matrix
+    stim_lag[t, l*D+d] = istim_padded[L+t-l, d] (62-66), A[i] = S[:,n]^T stim_lag reshaped (L,D)
+    (68-76), divided by the neuron's spike count (79-80)."""
+    nT = S.shape[0]
+    D = stim.shape[1]
+    istim = interp_stim(stim, dt_stim, dt, nT) / (dt_stim / dt)
+    pad = np.vstack((np.zeros((L, D)), istim))
+    A = np.zeros((len(Ns), L, D))
+    for l in range(L):
+        lagged = pad[L - l:L + nT - l, :]                   # (nT, D): istim[t-l], zero for t<l
+        for i, n in enumerate(Ns):
+            A[i, l, :] = np.dot(S[:, n], lagged)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for i, n in enumerate(Ns):
+            A[i] /= np.sum(S[:, n])
+    return A
+
+
+def sta_stim_weights(sn, kind, ibasis_t, ibasis_x=None):
+    """smart_init.py:66-98: 'spatiotemporal' -> leading singular pair of the (L,D) STA scaled by
+    sqrt(sigma_0), projected on the temporal/spatial bases; 'basis' -> per-dimension projection
+    on the temporal basis, stacked d*B+b."""
+    sn = np.asarray(sn, dtype=float)
+    if sn.ndim == 1:
+        sn = sn.reshape(-1, 1)
+    if kind == 'spatiotemporal':
+        U, Sig, V = np.linalg.svd(sn)
+        f_t = U[:, 0] * np.sqrt(Sig[0])
+        f_x = V[0, :] * np.sqrt(Sig[0])
+        return {'w_t': np.ravel(project_onto_basis(f_t, ibasis_t)),
+                'w_x': np.ravel(project_onto_basis(f_x, ibasis_x))}
+    B = ibasis_t.shape[1]
+    w = np.zeros(B * sn.shape[1])
+    for d in range(sn.shape[1]):
+        w[d * B:(d + 1) * B] = np.ravel(project_onto_basis(sn[:, d], ibasis_t))
+    return {'w_stim': w}
+
+
 # ----------------------------------------------------------------------------
 # A5. the GLM log likelihood (glm.py:31-52 and the component expressions)
 # ----------------------------------------------------------------------------

@@ -86,6 +86,13 @@ def main():
     out['shift_stim'] = st
     out['shift_fstim'] = rb.convolve_with_basis(st, one)
 
+    # --- project_onto_basis (basis.py:416-436), used by the STA initialisation ------------
+    rng2 = np.random.default_rng(20260202)
+    f = rng2.standard_normal(Rt)
+    out['proj_f'] = f
+    out['proj_beta'] = rb.project_onto_basis(f, ibt)
+    out['proj_beta_ridge'] = rb.project_onto_basis(f, ibt, lam=0.5)
+
     np.savez_compressed(os.path.join(here, 'basis_golden.npz'), **out)
 
     # --- the three template dicts (hyper-parameters only: data, not code) -------------

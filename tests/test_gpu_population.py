@@ -296,3 +296,69 @@ def test_wide_spatiotemporal_stimulus_sliced():
     eps = 1e-6
     fd = (lp_of(v0 + eps * d) - lp_of(v0 - eps * d)) / (2 * eps)
     assert abs(fd - g.dot(d)) < 1e-4 * max(1.0, abs(fd))
+
+
+def test_sta_matches_oracle():
+    """pgl_sta (event-list STA on the device) against the dense lag-matrix restatement of
+    pyglm/utils/sta.py, with interpolation from a coarse stimulus grid, a neuron subset, a
+    multi-spike bin, spikes inside the first L bins and a silent neuron."""
+    from theano_pyglm_amd.utils.sta import sta
+    rng = np.random.RandomState(8)
+    nT, N, D, L = 5000, 5, 3, 120
+    S = (rng.rand(nT, N) < 0.03).astype(float)
+    S[3, 0] = 2.0
+    S[nT - 1, 4] = 1.0
+    S[:, 2] = 0.0
+    stim = rng.randn(nT // 100, D)
+    data = {'S': S, 'dt': 0.001, 'dt_stim': 0.1, 'N': N, 'T': nT * 0.001}
+    A = sta(stim, data, L, Ns=[0, 2, 4])
+    A0 = O.sta(stim, S, 0.001, 0.1, L, [0, 2, 4])
+    assert A.shape == (3, L, D)
+    assert np.all(np.isnan(A[1])) and np.all(np.isnan(A0[1]))
+    assert np.allclose(A[[0, 2]], A0[[0, 2]], rtol=1e-11, atol=1e-14)
+    assert np.allclose(sta(stim, data, L, Ns=3)[0], O.sta(stim, S, 0.001, 0.1, L, [3])[0], rtol=1e-11, atol=1e-14)
+    # wide stimulus, all neurons (many output tiles, one event chunk)
+    stim2 = rng.randn(nT // 10, 200)
+    data2 = {'S': S[:, [0, 1]], 'dt': 0.001, 'dt_stim': 0.01}
+    assert np.allclose(sta(stim2, data2, 30), O.sta(stim2, S[:, [0, 1]], 0.001, 0.01, 30, [0, 1]),
+                       rtol=1e-11, atol=1e-14)
+
+
+def test_initialize_with_sta():
+    """smart_init.initialize_stim_with_sta on the spatiotemporal and basis-stimulus models: device
+    STA + host factorisation equal the oracle's, and the warm start beats the prior draw."""
+    from theano_pyglm_amd.inference import smart_init
+    from theano_pyglm_amd.models import templates
+
+    def tame(x):
+        for xn in x['glms']:
+            xn['bias']['bias'] = np.array([2.0])
+            xn['bkgd']['w_x'] = np.array([0.8, -0.4, 0.3]) * (1 + 0.1 * xn['n'])
+            xn['bkgd']['w_t'] = np.array([1.0, 0.3, 0.1])
+            xn['imp']['w_ir'] = xn['imp']['w_ir'] * 0.2
+
+    model, popn, data = make_dataset('spatiotemporal_glm', 3, 20.0, seed=41, adjust=tame)
+    x0 = popn.sample(np.random.RandomState(42))
+    ll_prior_draw = popn.compute_ll(x0)
+    smart_init.initialize_with_data(popn, data, x0)
+    bk = popn.glm.bkgd_model
+    A0 = O.sta(np.asarray(data['stim'], float), np.asarray(data['S'], float), data['dt'], data['dt_stim'],
+               bk.ibasis_t.shape[0], range(3))
+    for n in range(3):
+        w0 = O.sta_stim_weights(A0[n], 'spatiotemporal', bk.ibasis_t, bk.ibasis_x)
+        w = x0['glms'][n]['bkgd']
+        # the singular pair is defined up to a common sign
+        assert np.allclose(np.outer(w['w_t'], w['w_x']), np.outer(w0['w_t'], w0['w_x']), rtol=1e-7, atol=1e-10)
+    assert popn.compute_ll(x0) > ll_prior_draw
+    # basis-stimulus model
+    tmpl = templates.standard_glm()
+    tmpl['bkgd']['type'] = 'basis'
+    model, popn, data = make_dataset(tmpl, 3, 6.0, seed=43)
+    x0 = popn.sample(np.random.RandomState(44))
+    smart_init.initialize_stim_with_sta(popn, data, x0, Ns=1)
+    bk = popn.glm.bkgd_model
+    A0 = O.sta(np.asarray(data['stim'], float), np.asarray(data['S'], float), data['dt'],
+               data['dt_stim'], bk.ibasis.shape[0], [1])
+    assert np.allclose(x0['glms'][1]['bkgd']['w_stim'],
+                       O.sta_stim_weights(A0[0], 'basis', bk.ibasis)['w_stim'], rtol=1e-8, atol=1e-12)
+    assert np.isfinite(popn.compute_log_p(x0))

@@ -202,3 +202,31 @@ def test_simulate_consistency_host():
         imps = p.glm.imp_model.impulse(x['glms'][n]['imp'])
         xd = O.direct_currents(S, imps, np.ones(3), x['glms'][n]['bias']['bias'][0])
         assert np.allclose(X[:, n], xd)
+
+
+def test_data_io_roundtrip_and_segment(tmp_path):
+    """utils/io.py: the data-dict schema survives .pkl and .mat round trips (io.py:82-124) and
+    segment_data cuts spikes on the dt grid and the stimulus on the dt_stim grid (io.py:126-149)."""
+    from theano_pyglm_amd.utils import io
+    rng = np.random.RandomState(0)
+    data = {'S': (rng.rand(4000, 3) < 0.02).astype(float), 'N': 3, 'dt': 0.001, 'T': 4.0,
+            'stim': rng.randn(40, 2), 'dt_stim': 0.1, 'vars': {'glms': [{'bias': {'bias': np.array([1.0])}}]},
+            'preprocessed': True, '_device_handle': object()}
+    for ext in ('pkl', 'mat'):
+        p = str(tmp_path / ('d.' + ext))
+        io.save_data(data, p)
+        d2 = io.load_data(p)
+        assert isinstance(d2['N'], int) and d2['N'] == 3 and d2['T'] == 4.0 and d2['dt'] == 0.001
+        assert np.array_equal(d2['S'], data['S']) and np.array_equal(d2['stim'], data['stim'])
+        assert '_device_handle' not in d2 and 'preprocessed' not in d2
+    assert io.load_data(str(tmp_path / 'd.pkl'))['vars']['glms'][0]['bias']['bias'][0] == 1.0
+    seg = io.segment_data(data, (1.0, 2.5))
+    assert seg['T'] == 1.5 and abs(seg['S'].shape[0] - 1500) <= 1 and abs(seg['stim'].shape[0] - 15) <= 1
+    # the reference indexes with float floor division (io.py:141-147): 1.0 // 0.001 == 999.0
+    i0, i1, j0, j1 = int(1.0 // 0.001), int(2.5 // 0.001), int(1.0 // 0.1), int(2.5 // 0.1)
+    assert np.array_equal(seg['S'], data['S'][i0:i1]) and np.array_equal(seg['stim'], data['stim'][j0:j1])
+    assert 'preprocessed' not in seg and data['S'].shape == (4000, 3)
+    with pytest.raises(AssertionError):
+        io.segment_data(data, (3.0, 5.0))
+    with pytest.raises(Exception):
+        io.load_data(str(tmp_path / 'd.txt'))

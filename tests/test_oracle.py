@@ -166,3 +166,41 @@ def test_packing_order():
          'bkgd': {'w_x': np.array([7.0, 8.0]), 'w_t': np.array([5.0, 6.0])}, 'nlin': {}, 'n': {}}
     v, shapes = O.packdict(d)
     assert np.array_equal(v, [9, 5, 6, 7, 8, 0, 1, 2, 3])
+
+
+def test_project_onto_basis_golden(golden):
+    """oracle and host mirror of project_onto_basis against the reference's own output."""
+    from theano_pyglm_amd.utils import basis as hb
+    f, ibt = golden['proj_f'], golden['lr2d_ibasis_t']
+    for lam, key in ((0, 'proj_beta'), (0.5, 'proj_beta_ridge')):
+        assert np.allclose(O.project_onto_basis(f, ibt, lam), golden[key], rtol=1e-10, atol=1e-12)
+        assert np.allclose(hb.project_onto_basis(f, ibt, lam), golden[key], rtol=1e-10, atol=1e-12)
+
+
+def test_sta_oracle_definition():
+    """the dense-lag-matrix STA (sta.py:56-80) equals the per-spike definition: the average of the
+    stimulus windows preceding each spike; and STA-initialised weights recover a planted filter."""
+    rng = np.random.RandomState(4)
+    nT, D, L = 3000, 2, 40
+    stim = rng.randn(nT, D)
+    S = (rng.rand(nT, 3) < 0.05).astype(float)
+    S[7, 0] = 3.0
+    A = O.sta(stim, S, 0.001, 0.001, L, [0, 2])
+    for i, n in enumerate([0, 2]):
+        acc = np.zeros((L, D))
+        for t in np.nonzero(S[:, n])[0]:
+            for l in range(min(L, t + 1)):
+                acc[l] += S[t, n] * stim[t - l]
+        assert np.allclose(A[i], acc / S[:, n].sum(), rtol=1e-12, atol=1e-14)
+    # silent neuron -> NaN (0/0) as in the reference
+    S[:, 1] = 0
+    assert np.all(np.isnan(O.sta(stim, S, 0.001, 0.001, L, [1])))
+    # rank-1 planted STA is recovered by the SVD + projection (smart_init.py:66-84)
+    ibt = np.linalg.qr(rng.randn(L, 3))[0]
+    ibx = np.eye(D)
+    wt, wx = np.array([1.0, -0.5, 0.25]), np.array([0.7, -1.2])
+    sn = np.outer(ibt.dot(wt), ibx.dot(wx))
+    w = O.sta_stim_weights(sn, 'spatiotemporal', ibt, ibx)
+    assert np.allclose(np.outer(w['w_t'], w['w_x']), np.outer(wt, wx), atol=1e-12)
+    wb = O.sta_stim_weights(sn, 'basis', ibt)
+    assert np.allclose(wb['w_stim'].reshape(D, 3), np.outer(wx, wt), atol=1e-12)

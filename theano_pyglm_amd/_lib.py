@@ -25,7 +25,7 @@ SYMBOLS = [
     'pgl_set_option', 'pgl_set_time_range', 'pgl_set_spikes_u8', 'pgl_set_spikes_f64', 'pgl_set_basis',
     'pgl_set_stim_features', 'pgl_set_stimulus', 'pgl_get_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
-    'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate',
+    'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
 ]
 
 
@@ -89,6 +89,7 @@ def load():
     lib.pgl_set_stimulus.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int,
                                      C.c_int, C.c_int]
     lib.pgl_get_stim_features.argtypes = [vp, vp]
+    lib.pgl_sta.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int, vp]
     lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
@@ -231,6 +232,18 @@ class DeviceGlm(object):
     def get_stim_features(self):
         out = np.empty((self.nT, self.Dstim))
         _chk(self.lib.pgl_get_stim_features(self.h, _ptr(out)))
+        return out
+
+    def sta(self, stim, dt_stim, L, Ns=None):
+        """Spike-triggered average (n_sel, L, D) of the resident spikes; see pgl_sta."""
+        stim = _f64(stim)
+        if stim.ndim != 2:
+            raise ValueError("stim must be (Tstim, D)")
+        sel = None if Ns is None else np.ascontiguousarray(np.atleast_1d(Ns), dtype=np.int32)
+        nsel = self.N if sel is None else int(sel.size)
+        out = np.empty((nsel, int(L), stim.shape[1]))
+        _chk(self.lib.pgl_sta(self.h, _ptr(stim), stim.shape[0], stim.shape[1], float(dt_stim), int(L),
+                              _ptr(sel), nsel, _ptr(out)))
         return out
 
     # -- hot path -------------------------------------------------------------

@@ -503,6 +503,66 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
     return PGL_OK;
 }
 
+int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
+            const int* neurons, int n_sel, double* A_out)
+{
+    if (!h || !stim || !A_out) return fail(PGL_ERR_ARG, "null argument");
+    if (!h->have_spikes) return fail(PGL_ERR_STATE, "pgl_set_spikes_* has not been called");
+    if (Tstim <= 0 || D <= 0 || L <= 0 || !(dt_stim > 0)) return fail(PGL_ERR_ARG, "bad stimulus description");
+    const int nSel = neurons ? n_sel : h->N;
+    if (nSel <= 0 || nSel > 65535) return fail(PGL_ERR_ARG, "bad neuron selection");
+    std::vector<int> eoff((size_t)2 * nSel);
+    for (int i = 0; i < nSel; ++i) {
+        const int n = neurons ? neurons[i] : i;
+        if (n < 0 || n >= h->N) return fail(PGL_ERR_ARG, "neuron index out of range");
+        eoff[2 * i] = h->h_ptr[n];
+        eoff[2 * i + 1] = h->h_ptr[n + 1];
+    }
+    const long long LD = (long long)L * D;
+    const long long xb = (LD + 255) / 256;
+    if (xb > 0x7fffffffLL) return fail(PGL_ERR_UNSUPPORTED, "L*D too large");
+    // enough blocks to fill the chip when the output is small: split each neuron's events
+    int echunks = (int)std::min<long long>(64, std::max<long long>(1, 4096 / (xb * nSel)));
+    HIPCHK(hipSetDevice(h->device));
+    DevBuf dstim, distim, deoff, dpart, dA;
+    auto cleanup = [&]() { release(dstim); release(distim); release(deoff); release(dpart); release(dA); };
+    int rc = ensure(dstim, (size_t)Tstim * D * 8);
+    if (!rc) rc = ensure(distim, (size_t)h->nT * D * 8);
+    if (!rc) rc = ensure(deoff, eoff.size() * sizeof(int));
+    if (!rc) rc = ensure(dpart, (size_t)echunks * nSel * LD * 8);
+    if (!rc) rc = ensure(dA, (size_t)nSel * LD * 8);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(dstim.p, stim, (size_t)Tstim * D * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(deoff.p, eoff.data(), eoff.size() * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const long long total = (long long)h->nT * D;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 65535);
+        hipLaunchKernelGGL(k_stim_project, dim3(blocks), dim3(256), 0, h->stream, (const double*)dstim.p,
+                           (long long)Tstim, D, dt_stim, h->dt, (const double*)nullptr, D,
+                           (double*)distim.p, (long long)h->nT);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sta, dim3((unsigned)xb, (unsigned)nSel, (unsigned)echunks), dim3(256), 0,
+                           h->stream, (const int2*)h->spk.p, (const int*)deoff.p, (const double*)distim.p,
+                           D, L, (double*)dpart.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sta_finish, dim3((unsigned)xb, (unsigned)nSel), dim3(256), 0, h->stream,
+                           (const double*)dpart.p, (const int2*)h->spk.p, (const int*)deoff.p, LD, echunks,
+                           h->dt / dt_stim, (double*)dA.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(A_out, dA.p, (size_t)nSel * LD * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_sta: ") + hipGetErrorString(e));
+    return PGL_OK;
+}
+
 int pgl_get_stim_features(pgl_handle h, double* fstim_out)
 {
     if (!h || !fstim_out) return fail(PGL_ERR_ARG, "null argument");

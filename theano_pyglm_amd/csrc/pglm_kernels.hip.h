@@ -1337,6 +1337,71 @@ __global__ __launch_bounds__(256) void k_stim_conv(const double* __restrict__ zx
     }
 }
 
+// ---------------------------------------------------------------------------
+// Spike-triggered average (pyglm/utils/sta.py:6-85) from the event lists:
+//   A[i,l,d] = sum_t S[t,n_i] * istim[t-l, d] / sum_t S[t,n_i],  l = 0..L-1 (t-l < 0 -> 0)
+// with istim the stimulus interpolated to the bin grid and divided by dt_stim/dt (sta.py:30-41).
+// The reference forms a dense (nT, L*D) lag matrix and a gemv per neuron; here only the bins that
+// hold spikes are touched.  grid = (ceil(L*D/256), nSel, echunks); block c of the z axis handles an
+// equal share of the neuron's events and writes a partial, summed in fixed order by k_sta_finish.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sta(const int2* __restrict__ spk, const int* __restrict__ eoff,
+                                             const double* __restrict__ istim, int D, int L,
+                                             double* __restrict__ part)
+{
+    __shared__ int2 ev[256];
+    const int i = blockIdx.y, c = blockIdx.z, nSel = gridDim.y, echunks = gridDim.z;
+    const long long LD = (long long)L * D;
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(o / D);
+    const int d = (int)(o - (long long)l * D);
+    const int e0 = eoff[2 * i], e1 = eoff[2 * i + 1];
+    const int per = (e1 - e0 + echunks - 1) / echunks;
+    const int a = e0 + c * per;
+    const int b = min(e1, a + per);
+    double acc = 0.0;
+    for (int base = a; base < b; base += 256) {
+        const int e = base + (int)threadIdx.x;
+        ev[threadIdx.x] = (e < b) ? spk[e] : make_int2(0, 0);
+        __syncthreads();
+        const int m = min(256, b - base);
+        if (o < LD) {
+            for (int j = 0; j < m; ++j) {
+                const int2 q = ev[j];
+                const long long tt = (long long)q.x - l;
+                if (tt >= 0) acc = fma((double)q.y, istim[tt * D + d], acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (o < LD) part[((size_t)c * nSel + i) * LD + o] = acc;
+}
+
+// A[i][o] = scale * sum_c part[c][i][o] / count_i, count_i = sum of the event counts of neuron i
+// (0/0 = NaN for a silent neuron, like the reference's division, sta.py:79-80)
+__global__ __launch_bounds__(256) void k_sta_finish(const double* __restrict__ part,
+                                                    const int2* __restrict__ spk,
+                                                    const int* __restrict__ eoff, long long LD,
+                                                    int echunks, double scale, double* __restrict__ A)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.y, nSel = gridDim.y;
+    double cnt = 0.0;
+    for (int e = eoff[2 * i] + (int)threadIdx.x; e < eoff[2 * i + 1]; e += 256) cnt += (double)spk[e].y;
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    cnt = red[0];
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= LD) return;
+    double acc = 0.0;
+    for (int c = 0; c < echunks; ++c) acc += part[((size_t)c * nSel + i) * LD + o];
+    A[(size_t)i * LD + o] = acc * scale / cnt;
+}
+
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
 __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restrict__ ST,
                                long long nT, int N)

@@ -1,0 +1,34 @@
+"""Spike-triggered average -- counterpart of pyglm/utils/sta.py:6-85, computed on the device
+from the resident spike event lists (pgl_sta) instead of a dense (nT, L*D) lag matrix."""
+import numpy as np
+
+from theano_pyglm_amd import _lib
+
+
+def sta(stim, data, L, Ns=None, handle=None):
+    """A[i,l,:] = sum_t S[t,Ns[i]] * istim[t-l,:] / sum_t S[t,Ns[i]]  (sta.py:43-80).
+
+    stim : (Tstim, D) stimulus at sampling interval data['dt_stim']
+    data : dict with 'S' (nT,N), 'dt', 'dt_stim' (a data set already added to a Population reuses
+           its resident handle; otherwise the spikes are uploaded for this call)
+    L    : number of lags in bins of data['dt'];  Ns: neuron indices (default all, int allowed)
+    """
+    stim = np.asarray(stim, dtype=float)
+    if stim.ndim != 2:
+        raise ValueError("stim must be (Tstim, D)")
+    S = np.asarray(data['S'])
+    nT, N = S.shape
+    if Ns is None:
+        Ns = np.arange(N)
+    if isinstance(Ns, (int, np.integer)):
+        Ns = [int(Ns)]
+    h = handle if handle is not None else data.get('_device_handle', None)
+    own = h is None
+    if own:
+        h = _lib.DeviceGlm(N, nT, 1, 1, 'exp', float(data['dt']))
+        h.set_spikes(S)
+    try:
+        return h.sta(stim, float(data['dt_stim']), int(L), Ns=Ns)
+    finally:
+        if own:
+            h.close()
