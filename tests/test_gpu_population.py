@@ -362,3 +362,26 @@ def test_initialize_with_sta():
     assert np.allclose(x0['glms'][1]['bkgd']['w_stim'],
                        O.sta_stim_weights(A0[0], 'basis', bk.ibasis)['w_stim'], rtol=1e-8, atol=1e-12)
     assert np.isfinite(popn.compute_log_p(x0))
+
+
+def test_map_with_cross_validation(std4):
+    """harness/synth_map_with_xv: group-lasso lam grid (synth_harness.py:76), three resident data
+    handles (train / held-out / all), hyper-parameters switched on the host only."""
+    from theano_pyglm_amd.harness.synth_map_with_xv import get_xv_models, run_xv
+    model, popn, data = std4
+    models = get_xv_models(make_model('standard_glm', N=4, dt=0.001))
+    assert [m['impulse']['prior']['lam'] for m in models] == [0.5, 1.0, 2.0, 3.0, 5.0, 7.5, 10.0]
+    assert len(get_xv_models({'impulse': {}})) == 1               # setting absent -> the model itself
+    popn2 = Population(make_model('standard_glm', N=4, dt=0.001))
+    popn2.add_data(data)
+    best_x, best_ind, tr, xv, tot = run_xv(popn2, data, models[:4], rng=np.random.RandomState(5), verbose=False)
+    assert 0 <= best_ind < 4 and np.all(np.isfinite(xv)) and np.all(np.isfinite(tr))
+    assert best_ind == int(np.argmax(xv))
+    assert popn2.data_sequences == [data] or popn2.data_sequences[0] is data
+    # held-out ll of every fitted model beats a prior draw; the prior scalar really changed
+    popn2.set_hyperparameters(models[best_ind])
+    assert popn2.glm.imp_model.prior.lam == models[best_ind]['impulse']['prior']['lam']
+    x_rand = popn2.sample(np.random.RandomState(6))
+    assert popn2.compute_ll(best_x) > popn2.compute_ll(x_rand)
+    assert len(popn2._handles) == 3                               # train / held-out / all, uploaded once
+    popn2.release_data()
