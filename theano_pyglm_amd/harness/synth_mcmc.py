@@ -1,21 +1,26 @@
 """
-Network-column Gibbs sweeps on synthetic data -- counterpart of test/synth_mcmc.py
-restricted to the hot path: the CollapsedGibbsNetworkColumnUpdate sweep over all
-columns (gibbs.py:2548-2551) with the model's other parameters held fixed (the HMC
-updates of bias / impulse weights depend on the un-vendored `hips` package and are
-out of scope).  Non-interactive (the reference prompts with raw_input).
+MCMC on synthetic data -- counterpart of test/synth_mcmc.py (non-interactive: the reference
+prompts with raw_input and calls gibbs_sample with a stale signature).
 
-    python -m theano_pyglm_amd.harness.synth_mcmc -d data.pkl [-n 10]
+    python -m theano_pyglm_amd.harness.synth_mcmc -d data.pkl [-m sparse_weighted_model] [-n 10]
+                                                  [-r out_dir] [--network-only]
+
+Full sweeps (gibbs.py:2548-2556): HMC on biases / stimulus weights / impulse parameters in lock
+step over neurons, then the collapsed Gibbs update of every network column.  With x0 absent the
+chain starts from a standard_glm MAP fit converted to the model (gibbs.py:2490-2507).
+--network-only keeps everything but A, W fixed (the "synth_mcmc inner ll" path alone).
 """
 import argparse
+import os
 import pickle
 import time
 
 import numpy as np
 
-from theano_pyglm_amd.inference.gibbs import CollapsedGibbsNetworkColumnUpdate
+from theano_pyglm_amd.inference.gibbs import CollapsedGibbsNetworkColumnUpdate, gibbs_sample
 from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity
 from theano_pyglm_amd.population import Population
+from theano_pyglm_amd.utils.io import load_data
 
 
 def gibbs_network_sweeps(popn, x0, N_samples=10, rng=None, callback=None):
@@ -39,22 +44,27 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('-m', '--model', default='sparse_weighted_model')
     ap.add_argument('-d', '--dataFile', required=True)
+    ap.add_argument('-r', '--resultsDir', default=None)
     ap.add_argument('-n', '--N_samples', type=int, default=10)
+    ap.add_argument('--network-only', action='store_true')
     args = ap.parse_args()
-    with open(args.dataFile, 'rb') as f:
-        data = pickle.load(f)
+    data = load_data(args.dataFile)
     model = make_model(args.model, N=data['N'], dt=0.001)
     stabilize_sparsity(model)
     popn = Population(model)
     popn.add_data(data)
     rng = np.random.RandomState(0)
-    # The reference initialises MCMC from a MAP fit converted to this model
-    # (gibbs.py:2490-2507); a raw prior draw of W ~ N(0,1) can drive every quadrature node to
-    # lam = 0 ("log_G not finie", gibbs.py:1024-1026).  Start from a prior draw with the weights
-    # shrunk towards zero instead.
-    x0 = popn.sample(rng)
-    x0['net']['weights']['W'] = 0.05 * x0['net']['weights']['W']
-    gibbs_network_sweeps(popn, x0, args.N_samples, rng)
+    if args.network_only:
+        # A raw prior draw of W ~ N(0,1) can drive every quadrature node to lam = 0
+        # ("log_G not finie", gibbs.py:1024-1026): start with the weights shrunk towards zero.
+        x0 = popn.sample(rng)
+        x0['net']['weights']['W'] = 0.05 * x0['net']['weights']['W']
+        gibbs_network_sweeps(popn, x0, args.N_samples, rng)
+        return
+    smpls = gibbs_sample(popn, N_samples=args.N_samples, x0=None, init_from_mle=True, rng=rng)
+    if args.resultsDir is not None:
+        with open(os.path.join(args.resultsDir, 'results.pkl'), 'wb') as f:      # synth_mcmc.py:97-101
+            pickle.dump(smpls, f, protocol=-1)
 
 
 if __name__ == '__main__':

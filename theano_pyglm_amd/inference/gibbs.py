@@ -1,25 +1,182 @@
 """
-Collapsed Gibbs update of one column (A[:,n], W[:,n]) of the network -- counterpart of
-pyglm/inference/gibbs.py:775-1250 (CollapsedGibbsNetworkColumnUpdate), i.e. the
-"synth_mcmc inner ll" path.
+MCMC over the population GLM -- counterpart of pyglm/inference/gibbs.py for the models on the hot
+path: the HMC updates of bias / stimulus / impulse parameters (gibbs.py:164-773), the collapsed
+Gibbs update of one column (A[:,n], W[:,n]) of the network (gibbs.py:775-1250, the "synth_mcmc
+inner ll" path), `initialize_updates` and `gibbs_sample` (gibbs.py:2413-2560).
+
+HMC blocks.  Given the network, neuron n's bias / stimulus / impulse parameters enter only ll_n,
+so the reference's per-neuron updates are conditionally independent across neurons.  Each block
+update therefore advances all N chains in lock step: one leapfrog step of every neuron is ONE
+batched population ll+grad evaluation on the device (the fused kernel) instead of N Theano calls.
+`update(x, n)` keeps the reference's per-neuron form.  HMC and ARS themselves are in-repo
+(inference/hmc.py, inference/ars.py) because the reference's come from the un-vendored `hips`.
+
+Collapsed network column update:
 
 What runs on the GPU: the impulse currents I_imp of all presynaptic neurons for the
 column's post-synaptic neuron (once per column, gibbs.py:812-833), the "other" current
 (a rank-1 downdate of the resident total I_net instead of the reference's full gemv per
 pair, gibbs.py:835-864) and the batched ll at the 10 Gauss-Hermite nodes + w=0
 (gibbs.py:910-937, 1002-1032).  What stays on the host: the Gauss-Hermite marginal,
-the Bernoulli draw of A and the draw of W.  The reference samples W with adaptive
-rejection sampling from the un-vendored `hips` package; here W is drawn by the
+the Bernoulli draw of A and the draw of W: adaptive rejection sampling started from the
+quadrature nodes (gibbs.py:1087-1126; each extra abscissa is one more device inner-ll call), or the
 inverse-CDF sampler the reference also carries (gibbs.py:1068-1084) on a refined grid.
 """
+import copy
+import time
+
 import numpy as np
 from scipy.special import logsumexp
 
+from theano_pyglm_amd.components.impulse import DirichletImpulses
+from theano_pyglm_amd.inference.ars import adaptive_rejection_sample
+from theano_pyglm_amd.inference.hmc import hmc_lockstep, adapt_step_size
 from theano_pyglm_amd.inference.log_sum_exp import log_sum_exp_sample
+from theano_pyglm_amd.utils.packvec import packdict, unpackdict, get_vars, set_vars
+
+
+def _columns(syms, prefix=()):
+    """{path: (lo, hi)} of every leaf of `syms` in the packed vector (sorted-key DFS order)."""
+    out, cur = {}, [0]
+
+    def walk(d, path):
+        for k in sorted(d):
+            v = d[k]
+            if isinstance(v, dict):
+                walk(v, path + (k,))
+            else:
+                size = int(np.prod(v.shape))
+                out[path + (k,)] = (cur[0], cur[0] + size)
+                cur[0] += size
+    walk(syms, prefix)
+    return out
+
+
+class _HmcBlockUpdate(object):
+    """HMC on one component's differentiable variables of every neuron (lock step)."""
+    key = None
+    n_steps = 2
+
+    def __init__(self, rng=None):
+        self.avg_accept_rate = 0.9
+        self.step_sz = 0.1
+        self.rng = np.random if rng is None else rng
+        self.n_evals = 0
+
+    def preprocess(self, population):
+        self.population = population
+        self.glm = population.glm
+        self.syms = population.glm_syms()
+        self.block_syms = self.syms.get(self.key, {})
+        cols = _columns(self.syms)
+        mine = [v for p, v in cols.items() if p[0] == self.key]
+        self.lo = min(v[0] for v in mine) if mine else 0
+        self.hi = max(v[1] for v in mine) if mine else 0
+        self.block_cols = dict((p[1:], v) for p, v in cols.items() if p[0] == self.key)
+
+    def _pack(self, xn):
+        return packdict(get_vars(self.block_syms, xn[self.key]))
+
+    def _adapt(self, accepted):
+        for a in accepted:                              # the reference's recursion, neuron by neuron
+            self.step_sz, self.avg_accept_rate = adapt_step_size(self.step_sz, self.avg_accept_rate, a)
+
+    def _neg_lp_grad(self, x, n_lo, n_hi):
+        lp, G = self.population.compute_lp_grad_packed(x, n_lo, n_hi)
+        self.n_evals += 1
+        U = np.where(np.isfinite(lp), -lp, np.inf)
+        return U, -np.nan_to_num(G, nan=0.0, posinf=0.0, neginf=0.0)
+
+    def update_range(self, x, n_lo, n_hi):
+        if self.hi == self.lo:
+            return x                                    # nothing to sample (e.g. NoStimulus)
+        glms = x['glms']
+        Q0, shapes = [], None
+        for n in range(n_lo, n_hi):
+            q, shapes = self._pack(glms[n])
+            Q0.append(q)
+        Q0 = np.array(Q0)
+
+        def UG(Q):
+            for i, n in enumerate(range(n_lo, n_hi)):
+                set_vars(self.block_syms, glms[n][self.key], unpackdict(Q[i].copy(), shapes))
+            U, G = self._neg_lp_grad(x, n_lo, n_hi)
+            return U, G[:, self.lo:self.hi]
+
+        Q1, acc, _ = hmc_lockstep(UG, self.step_sz, self.n_steps, Q0, rng=self.rng)
+        for i, n in enumerate(range(n_lo, n_hi)):
+            set_vars(self.block_syms, glms[n][self.key], unpackdict(Q1[i].copy(), shapes))
+        self._adapt(acc)
+        return x
+
+    def update(self, x, n):
+        """the reference's per-neuron form (gibbs.py:284-322 etc.)."""
+        return self.update_range(x, n, n + 1)
+
+    def update_all(self, x):
+        return self.update_range(x, 0, self.population.N)
+
+
+class HmcBiasUpdate(_HmcBlockUpdate):
+    """gibbs.py:164-322: 10 leapfrog steps on the bias."""
+    key = 'bias'
+    n_steps = 10
+
+
+class HmcBkgdUpdate(_HmcBlockUpdate):
+    """gibbs.py:324-447: 2 leapfrog steps on the stimulus weights; no-op without a stimulus."""
+    key = 'bkgd'
+    n_steps = 2
+
+
+class HmcImpulseUpdate(_HmcBlockUpdate):
+    """gibbs.py:449-567: 2 leapfrog steps on all basis weights w_ir of the neuron."""
+    key = 'imp'
+    n_steps = 2
+
+
+class HmcDirichletImpulseUpdate(_HmcBlockUpdate):
+    """gibbs.py:569-773: for every existing edge n_pre -> n_post, 2 leapfrog steps on g_{n_pre}
+    (one presynaptic neuron at a time, conditioning on the others); without an edge g is redrawn
+    from its Gamma(alpha, 1) prior.  Lock step: round r handles the r-th incoming edge of every
+    post-synaptic neuron at once; neurons with fewer edges sit the round out."""
+    key = 'imp'
+    n_steps = 2
+
+    def update_range(self, x, n_lo, n_hi):
+        N, imp = self.population.N, self.glm.imp_model
+        A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+        glms = x['glms']
+        posts = list(range(n_lo, n_hi))
+        edges = [np.nonzero(A[:, n])[0] for n in posts]
+        for n, e in zip(posts, edges):                              # gibbs.py:765-769
+            for n_pre in np.setdiff1d(np.arange(N), e):
+                glms[n]['imp']['g_%d' % n_pre] = self.rng.gamma(imp.alpha, np.ones(imp.B))
+        for r in range(max([len(e) for e in edges] + [0])):
+            active = np.array([r < len(e) for e in edges])
+            pre = [int(e[r]) if r < len(e) else 0 for e in edges]
+            names = ['g_%d' % k for k in pre]
+            cols = [self.block_cols[(nm,)] for nm in names]
+            Q0 = np.array([np.asarray(glms[n]['imp'][nm], dtype=float) for n, nm in zip(posts, names)])
+
+            def UG(Q):
+                for i, n in enumerate(posts):
+                    if active[i]:
+                        glms[n]['imp'][names[i]] = Q[i].copy()
+                U, G = self._neg_lp_grad(x, n_lo, n_hi)
+                return U, np.array([G[i, c[0]:c[1]] for i, c in enumerate(cols)])
+
+            Q1, acc, _ = hmc_lockstep(UG, self.step_sz, self.n_steps, Q0, active=active, rng=self.rng)
+            for i, n in enumerate(posts):
+                glms[n]['imp'][names[i]] = Q1[i].copy()
+            self._adapt(acc[active])
+        return x
 
 
 class CollapsedGibbsNetworkColumnUpdate(object):
-    def __init__(self, rng=None):
+    def __init__(self, rng=None, w_sampler='ars'):
+        self.w_sampler = w_sampler                      # 'ars' (gibbs.py:1054) | 'inverse_cdf' (:1053)
+        self.n_ars_evals = 0
         self.DEG_GAUSS_HERMITE = 10
         self.GAUSS_HERMITE_ABSCISSAE, self.GAUSS_HERMITE_WEIGHTS = \
             np.polynomial.hermite.hermgauss(self.DEG_GAUSS_HERMITE)     # gibbs.py:787-789
@@ -90,6 +247,27 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         F = F / F[-1]
         return float(np.interp(self.rng.random_sample(), F, ws))
 
+    def _adaptive_rejection_sample_w(self, h, n_pre, aw_cur, mu_w, sigma_w, ws, log_L):
+        """gibbs.py:1087-1126: ARS on log N(w; mu_w, sigma_w) + ll(w), started from the quadrature
+        nodes with finite, moderate values; the density is shifted by its maximum over the nodes."""
+        log_post = -0.5 / sigma_w ** 2 * (ws - mu_w) ** 2 + log_L
+        Z = np.amax(log_post[np.isfinite(log_post)])
+        valid = np.isfinite(log_post) & (log_post > -1e8) & (log_post < 1e8)
+
+        def f(w):
+            self.n_ars_evals += 1
+            ll = h.gibbs_ll(n_pre, aw_cur, np.array([w]))[0]
+            v = -0.5 / sigma_w ** 2 * (w - mu_w) ** 2 + ll - Z
+            return v if np.isfinite(v) else -np.inf
+
+        return float(adaptive_rejection_sample(f, ws[valid], log_post[valid] - Z, (-np.inf, np.inf),
+                                               stepsz=sigma_w / 2.0, rng=self.rng))
+
+    def update_all(self, x):
+        for n in range(self.population.N):
+            self.update(x, n)
+        return x
+
     def update(self, x, n_post):
         """gibbs.py:1229-1250 with the device-resident inner loop: resample column n_post."""
         pop = self.population
@@ -120,7 +298,9 @@ class CollapsedGibbsNetworkColumnUpdate(object):
             if np.isnan(log_pr_noA):
                 log_pr_noA = -np.inf
             a_new = log_sum_exp_sample([log_pr_noA, log_pr_A], self.rng)           # gibbs.py:1041
-            if a_new == 1:
+            if a_new == 1 and self.w_sampler == 'ars':
+                w_new = self._adaptive_rejection_sample_w(h, n_pre, aw_cur, mu_w, sigma_w, W_nns, log_L)
+            elif a_new == 1:
                 grid = mu_w + sigma_w * np.linspace(-4.0, 4.0, self.n_grid)
                 w_new = self._inverse_cdf_sample_w(mu_w, sigma_w, grid,
                                                    h.gibbs_ll(n_pre, aw_cur, grid))
@@ -133,3 +313,68 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         x['net']['graph']['A'] = A
         x['net']['weights']['W'] = W.ravel()
         return stats
+
+
+def initialize_updates(population, rng=None, w_sampler='ars'):
+    """gibbs.py:2413-2473: the latent-variable samplers of the reference are no-ops for models
+    without latent components (the only ones on this path); every population gets the bias,
+    stimulus, impulse and network-column updates, in this order."""
+    serial_updates = []
+    imp_cls = HmcDirichletImpulseUpdate if isinstance(population.glm.imp_model, DirichletImpulses) \
+        else HmcImpulseUpdate
+    parallel_updates = [HmcBiasUpdate(rng), HmcBkgdUpdate(rng), imp_cls(rng)]
+    g = population.network.graph
+    if hasattr(g, 'pA') and 'A' in population.get_variables()['net']['graph']:
+        parallel_updates.append(CollapsedGibbsNetworkColumnUpdate(rng, w_sampler=w_sampler))
+    for u in parallel_updates:
+        u.preprocess(population)
+    return serial_updates, parallel_updates
+
+
+def gibbs_sample(population, N_samples=1000, x0=None, init_from_mle=True, callback=None,
+                 lockstep=True, rng=None, verbose=True):
+    """gibbs.py:2475-2560.  Returns the list of sampled states (x0 first).
+
+    x0 None: prior draw, optionally replaced by a MAP fit of `standard_glm` on the same data
+    converted to this model (gibbs.py:2490-2507).  lockstep=False runs every update neuron by
+    neuron exactly in the reference's order."""
+    N = population.model['N']
+    dt = population.model['dt']
+    rng = np.random if rng is None else rng
+    if x0 is None:
+        x0 = population.sample(rng if rng is not np.random else None)
+        if init_from_mle and isinstance(population.glm.imp_model, DirichletImpulses):
+            from theano_pyglm_amd.inference.coord_descent import coord_descent
+            from theano_pyglm_amd.models.model_factory import make_model, convert_model
+            from theano_pyglm_amd.population import Population
+            if verbose:
+                print("Initializing with coordinate descent")
+            mle_model = make_model('standard_glm', N=N, dt=dt)
+            mle_popn = Population(mle_model, device=population.device)
+            for data in population.data_sequences:
+                mle_popn.add_data(data)          # own handle: the MAP model has its own impulse basis
+            mle_x0 = coord_descent(mle_popn, x0=mle_popn.sample(rng if rng is not np.random else None),
+                                   maxiter=1, batched='torch')
+            x0 = convert_model(mle_popn, mle_model, mle_x0, population, population.model, x0)
+    serial_updates, parallel_updates = initialize_updates(population, rng)
+    x = x0
+    x_smpls = [copy.deepcopy(x0)]      # (the reference stores x0 itself, which its in-place updates then overwrite)
+    start = time.time()
+    for smpl in range(N_samples):
+        if callback is not None:
+            callback(x)
+        lp = population.compute_log_p(x)
+        stop = time.time()
+        if verbose:
+            print("Gibbs iteration %d. Iter/s = %f. Log prob: %.3f" % (smpl, 1.0 / max(stop - start, 1e-9), lp))
+        start = stop
+        for upd in parallel_updates:
+            if lockstep:
+                upd.update_all(x)
+            else:
+                for n in range(N):
+                    upd.update(x, n)
+        for upd in serial_updates:
+            upd.update(x)
+        x_smpls.append(copy.deepcopy(x))
+    return x_smpls

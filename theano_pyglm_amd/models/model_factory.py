@@ -58,3 +58,43 @@ def check_stability(model, x, N):
         Weff = x['net']['graph']['A'] * np.reshape(x['net']['weights']['W'], (N, N))
         return bool(np.amax(np.real(np.linalg.eigvals(Weff))) < 1)
     return True
+
+
+def convert_model(from_popn, from_model, from_vars, to_popn, to_model, to_vars):
+    """model_factory.py:187-268 for the conversion the MCMC initialisation needs (gibbs.py:2490-2507):
+    a fitted basis-impulse model (standard_glm) -> a weighted network with normalised (Dirichlet)
+    impulse responses.  Every fitted impulse response is projected on the target basis by
+    non-negative least squares with either sign; the coefficient sum becomes the weight
+    W[n1,n2], the normalised coefficients (floored at 0.001) the impulse shape
+    g = alpha * B * beta, and A keeps the strongest 2*rho fraction of the off-diagonal weights.
+    Biases are copied.  Both populations must have data attached (eval_state)."""
+    from scipy.optimize import nnls
+    if from_model['impulse']['type'].lower() != 'basis' or \
+            to_model['impulse']['type'].lower() != 'dirichlet':
+        raise Exception("convert_model: only basis -> dirichlet impulse conversion is implemented")
+    N = from_popn.N
+    conv = copy.deepcopy(to_vars)
+    to_imp = to_popn.glm.imp_model
+    basis, alpha, B = to_imp.ibasis, to_imp.alpha, to_imp.B
+    W = np.zeros((N, N))
+    for n2 in range(N):
+        imp = from_popn.glm.imp_model.impulse(from_vars['glms'][n2]['imp'])       # (N,R)
+        for n1 in range(N):
+            wp, rp = nnls(basis, imp[n1, :])
+            wn, rn = nnls(basis, -1.0 * imp[n1, :])
+            sgn, w = (1.0, wp) if rp < rn else (-1.0, wn)
+            w = np.clip(w, 0.001, np.inf)
+            W[n1, n2] = sgn * np.sum(w)
+            conv['glms'][n2]['imp']['g_%d' % n1] = alpha * B * w / np.sum(w)
+    conv['net']['weights']['W'] = W.flatten()
+    graph = to_model['network']['graph']
+    if 'rho' in graph:
+        W_sorted = np.sort(np.abs(W.ravel()))
+        k = int(np.floor((1.0 - 2.0 * graph['rho']) * (N ** 2 - N) - N))
+        thresh = W_sorted[int(np.clip(k, 0, N * N - 1))]
+        conv['net']['graph']['A'] = (np.abs(W) >= thresh).astype(np.int8)
+    else:
+        conv['net']['graph']['A'] = np.ones((N, N), dtype=np.int8)
+    for n in range(N):
+        conv['glms'][n]['bias']['bias'] = np.array(from_vars['glms'][n]['bias']['bias'], dtype=float)
+    return conv
