@@ -113,7 +113,8 @@ __device__ __forceinline__ double pgl_rcp(const double b)
 }
 
 // exp(y): k = rint(y/ln2), r = y - k ln2 (hi/lo split), degree-13 Taylor in |r| <= 0.347, ldexp
-__device__ __forceinline__ double pgl_exp(const double y, const double* __restrict__ C)
+template <typename CP>
+__device__ __forceinline__ double pgl_exp(const double y, const CP C)
 {
     const double k = rint(y * C[0]);
     double r = fma(-k, C[1], y);
@@ -130,7 +131,8 @@ __device__ __forceinline__ double pgl_exp(const double y, const double* __restri
 
 // log(v) for v >= 0 (fdlibm e_log.c scheme: v = 2^e m, m in [sqrt(1/2), sqrt 2),
 // s = f/(2+f), 7-term polynomial in s^2); log(0) = -inf, inf/NaN pass through
-__device__ __forceinline__ double pgl_log(const double v, const double* __restrict__ C)
+template <typename CP>
+__device__ __forceinline__ double pgl_log(const double v, const CP C)
 {
     double m = __builtin_amdgcn_frexp_mant(v);    // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(v);
@@ -162,9 +164,10 @@ __device__ __forceinline__ double pgl_log(const double v, const double* __restri
 // log(lam) and 1/lam are only evaluated in waves where some lane has a spike (s > 0);
 // when every lane of the wave has exp(-|x|) < 9.6e-5 (|x| > 9.25, the operating regime of
 // standard_glm's bias ~ 20) log1p and 1/(1+e) come from their alternating series (error < e^6).
+template <typename CP>
 __device__ __forceinline__ void pgl_rate_terms(const double x, const double s, const int nlin,
                                                const double dt, double& term, double& res,
-                                               const double* __restrict__ C)
+                                               const CP C)
 {
     if (nlin == 1) {
         const double e = pgl_exp(-fabs(x), C);
@@ -480,6 +483,10 @@ __device__ __forceinline__ int2 pgl_decode_event(const int2 e, const int t0, con
     return make_int2(off, __float_as_int((float)e.y));
 }
 
+typedef const __attribute__((address_space(3))) double* pgl_lds_cdp;
+typedef double pgl_d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) pgl_d2* pgl_glb_cd2p;
+
 template <typename T> struct pgl_vec2;
 template <> struct pgl_vec2<double> { typedef double2 type; };
 template <> struct pgl_vec2<float> { typedef float2 type; };
@@ -567,10 +574,10 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
 // (f64 VALU work cannot hide under f64 MFMA on gfx950: both issue to the same DP
 // pipeline -- tools/ubench -- so the win is latency hiding, not FP overlap.)
 // ---------------------------------------------------------------------------
+template <typename CP>
 __device__ __forceinline__ void pgl_epilogue(const double x, const double s, const bool valid,
                                              const int nlin, const double dt, double& ll_acc,
-                                             double& gb_acc, double& res_out,
-                                             const double* __restrict__ C)
+                                             double& gb_acc, double& res_out, const CP C)
 {
     double term, res;
     pgl_rate_terms(x, s, nlin, dt, term, res, C);
@@ -751,8 +758,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             // [pt][ks/2][lane][2]); ring of PW2 loads = 2*PW2 MFMA steps ahead
             constexpr int PW2 = (KSW / 2 < PGL_PW / 2) ? KSW / 2 : PGL_PW / 2;
             constexpr int PA = (KSW < 4) ? KSW : 4;
-            const double2* wr2 = reinterpret_cast<const double2*>(wr_s);
-            double2 wr[PW2];
+            // explicit global address space: behind the opaque asm the compiler no longer knows
+            // the provenance and would emit flat loads (vmcnt AND lgkmcnt, 64-bit VALU addresses)
+            const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
+            pgl_d2 wr[PW2];
             double ar[PA];
 #pragma unroll
             for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
@@ -820,8 +829,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                     gb_acc += res;
                 } else {
                     // constants come from LDS through an opaque pointer: as literals or hoisted
-                    // scalar loads they pin ~50 registers for the whole kernel and spill
-                    const double* Cl = Cs;
+                    // scalar loads they pin ~50 registers for the whole kernel and spill.  The
+                    // pointer keeps its LDS address space (ds_read, lgkmcnt only); a generic
+                    // pointer would turn every constant into a flat load
+                    pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                     asm volatile("" : "+v"(Cl));
                     pgl_epilogue(x, sc[e], vt, p.nlin, p.dt, ll_acc, gb_acc, res, Cl);
                 }
