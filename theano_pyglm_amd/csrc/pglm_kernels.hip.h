@@ -28,6 +28,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifndef PGL_GEN_NIG
 #define PGL_GEN_NIG 1        // work items a thread advances in lock-step (A/B: >1 only adds register pressure; the loop is LDS-bandwidth bound)
 #endif
+#ifndef PGL_PD
+#define PGL_PD 4             // F^T fragment prefetch depth (MFMA steps) in the V2 backward pass
+#endif
 #ifndef PGL_PW
 #define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) in the V2 forward pass
 #endif
@@ -164,39 +167,80 @@ __device__ __forceinline__ double pgl_log(const double v, const CP C)
 // log(lam) and 1/lam are only evaluated in waves where some lane has a spike (s > 0);
 // when every lane of the wave has exp(-|x|) < 9.6e-5 (|x| > 9.25, the operating regime of
 // standard_glm's bias ~ 20) log1p and 1/(1+e) come from their alternating series (error < e^6).
+template <int NE, typename CP>
+__device__ __forceinline__ void pgl_rate_terms_n(const double (&x)[NE], const double (&s)[NE],
+                                                 const int nlin, const double dt, double (&term)[NE],
+                                                 double (&res)[NE], const CP C)
+{
+    // NE independent elements per lane are carried through every stage together: the Horner chains
+    // are latency bound (dependent f64 FMAs), two of them interleave in the same issue slots
+    if (nlin == 1) {
+        double e[NE], l1p[NE], inv[NE], lam[NE], sig[NE];
+        bool small = true, spike = false;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            e[i] = pgl_exp(-fabs(x[i]), C);
+            small = small && (e[i] < C[23]);
+            spike = spike || (s[i] > 0.0);
+        }
+        if (__all(small)) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const double ei = e[i];
+                l1p[i] = ei * fma(-ei, fma(-ei, fma(-ei, fma(-ei, 0.2, 0.25), C[22]), 0.5), 1.0);
+                inv[i] = fma(-ei, fma(-ei, fma(-ei, fma(-ei, fma(-ei, 1.0, 1.0), 1.0), 1.0), 1.0), 1.0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const double u = 1.0 + e[i];
+                inv[i] = pgl_rcp(u);
+                l1p[i] = pgl_log(u, C) + (e[i] - (u - 1.0)) * inv[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            lam[i] = fmax(x[i], 0.0) + l1p[i];
+            sig[i] = (x[i] >= 0.0) ? inv[i] : e[i] * inv[i];
+            term[i] = -dt * lam[i];
+            res[i] = -dt * sig[i];
+        }
+        if (spike) {                       // some lane of the wave holds a spike in one of its elements
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const double tl = fma(pgl_log(lam[i], C), s[i], term[i]);
+                const double rl = (-dt + s[i] * pgl_rcp(lam[i])) * sig[i];
+                term[i] = (s[i] > 0.0) ? tl : term[i];
+                res[i] = (s[i] > 0.0) ? rl : res[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52), and
+            // its derivative S*lam'/lam = 0/0 = NaN (callers zero NaN gradients, coord_descent.py:179)
+            term[i] = (lam[i] == 0.0) ? __builtin_nan("") : term[i];
+            res[i] = (lam[i] == 0.0 || x[i] != x[i]) ? __builtin_nan("") : res[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double lam = pgl_exp(x[i], C);
+            term[i] = fma(x[i], s[i], -dt * lam);
+            res[i] = fma(-dt, lam, s[i]);
+        }
+    }
+}
+
 template <typename CP>
 __device__ __forceinline__ void pgl_rate_terms(const double x, const double s, const int nlin,
                                                const double dt, double& term, double& res,
                                                const CP C)
 {
-    if (nlin == 1) {
-        const double e = pgl_exp(-fabs(x), C);
-        double l1p, inv;
-        if (__all(e < C[23])) {
-            l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), C[22]), 0.5), 1.0);
-            inv = fma(-e, fma(-e, fma(-e, fma(-e, fma(-e, 1.0, 1.0), 1.0), 1.0), 1.0), 1.0);
-        } else {
-            const double u = 1.0 + e;
-            inv = pgl_rcp(u);
-            l1p = pgl_log(u, C) + (e - (u - 1.0)) * inv;
-        }
-        const double lam = fmax(x, 0.0) + l1p;
-        const double sig = (x >= 0.0) ? inv : e * inv;
-        term = -dt * lam;
-        res = -dt * sig;
-        if (s > 0.0) {
-            term = fma(pgl_log(lam, C), s, term);
-            res = (-dt + s * pgl_rcp(lam)) * sig;
-        }
-        // reference semantics at lam == 0 (x < -745): log(0)*S = -inf*0 = NaN (glm.py:52), and
-        // its derivative S*lam'/lam = 0/0 = NaN (callers zero NaN gradients, coord_descent.py:179)
-        term = (lam == 0.0) ? __builtin_nan("") : term;
-        res = (lam == 0.0 || x != x) ? __builtin_nan("") : res;
-    } else {
-        const double lam = pgl_exp(x, C);
-        term = fma(x, s, -dt * lam);
-        res = fma(-dt, lam, s);
-    }
+    const double xa[1] = {x}, sa[1] = {s};
+    double ta[1], ra[1];
+    pgl_rate_terms_n<1>(xa, sa, nlin, dt, ta, ra, C);
+    term = ta[0];
+    res = ra[0];
 }
 
 __device__ __forceinline__ double pgl_softplus_parts(double x, double& sig, double& loglam)
@@ -574,18 +618,6 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
 // (f64 VALU work cannot hide under f64 MFMA on gfx950: both issue to the same DP
 // pipeline -- tools/ubench -- so the win is latency hiding, not FP overlap.)
 // ---------------------------------------------------------------------------
-template <typename CP>
-__device__ __forceinline__ void pgl_epilogue(const double x, const double s, const bool valid,
-                                             const int nlin, const double dt, double& ll_acc,
-                                             double& gb_acc, double& res_out, const CP C)
-{
-    double term, res;
-    pgl_rate_terms(x, s, nlin, dt, term, res, C);
-    ll_acc += valid ? term : 0.0;
-    res_out = valid ? res : 0.0;
-    gb_acc += res_out;
-}
-
 template <int KTW, int PTW, int NW, int CAP, typename FT>
 __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
 {
@@ -813,6 +845,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 if (emine && tg < p.nT) p.Xbuf[tg * p.xstride + pt * 16 + col] += x;
             }
         } else if (active && p.mode == 0) {
+            double xe[EPW], rese[EPW], terme[EPW];
+            bool vte[EPW];
 #pragma unroll
             for (int e = 0; e < EPW; ++e) {
                 const int r = er[e];
@@ -821,22 +855,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 for (int k2 = 0; k2 < KSPLIT; ++k2)
                     x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
                 const long long tg = (long long)t0 + grp + 4 * r;
-                const bool vt = valid_n && (tg < p.t_hi) && emine;
-                double res;
-                if (p.dbg & 4) {
-                    ll_acc += x * sc[e];
-                    res = vt ? x - sc[e] : 0.0;
-                    gb_acc += res;
-                } else {
-                    // constants come from LDS through an opaque pointer: as literals or hoisted
-                    // scalar loads they pin ~50 registers for the whole kernel and spill.  The
-                    // pointer keeps its LDS address space (ds_read, lgkmcnt only); a generic
-                    // pointer would turn every constant into a flat load
-                    pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
-                    asm volatile("" : "+v"(Cl));
-                    pgl_epilogue(x, sc[e], vt, p.nlin, p.dt, ll_acc, gb_acc, res, Cl);
+                vte[e] = valid_n && (tg < p.t_hi) && emine;
+                xe[e] = x;
+            }
+            if (p.dbg & 4) {
+#pragma unroll
+                for (int e = 0; e < EPW; ++e) {
+                    terme[e] = xe[e] * sc[e];
+                    rese[e] = xe[e] - sc[e];
                 }
-                if (emine) Rb[(size_t)ptl * 256 + r * 64 + lane] = res;
+            } else {
+                // constants come from LDS through an opaque pointer: as literals or hoisted
+                // scalar loads they pin ~50 registers for the whole kernel and spill.  The
+                // pointer keeps its LDS address space (ds_read, lgkmcnt only); a generic
+                // pointer would turn every constant into a flat load
+                pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                asm volatile("" : "+v"(Cl));
+                pgl_rate_terms_n<EPW>(xe, sc, p.nlin, p.dt, terme, rese, Cl);
+            }
+#pragma unroll
+            for (int e = 0; e < EPW; ++e) {
+                const double res = vte[e] ? rese[e] : 0.0;
+                ll_acc += vte[e] ? terme[e] : 0.0;
+                gb_acc += res;
+                if (emine) Rb[(size_t)ptl * 256 + er[e] * 64 + lane] = res;
             }
         }
         __syncthreads();
@@ -856,7 +898,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             }
             const FT* fb = Fs + grp * rsf + kcol0 + col;
             constexpr int NS = 4 * KTW;
-            constexpr int PD = (NS < 4) ? NS : 4;
+            constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
             double ar[PD];
 #pragma unroll
             for (int s = 0; s < PD; ++s) ar[s] = (double)fb[(4 * (s / KTW)) * rsf + 16 * (s % KTW)];
