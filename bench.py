@@ -62,7 +62,8 @@ def pmc_traffic(kernel_prefix):
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_bench.sh).
     FETCH_SIZE is taken at face value: on this access pattern (byte / 4-byte / 8-byte loads, no
     16-B streams) the guide's x2 correction does not apply -- calibrated on k_transpose_u8, whose
-    76.8 MB read is reported as 76.8 MB (profiles/r01_v1_pmc_hbm.json)."""
+    76.8 MB read is reported as 76.8 MB (profiles/history/r01_v1_pmc_hbm.json).
+    The newest top-level profiles/rNN_pmc.json wins (earlier iterations live in profiles/history/)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
