@@ -165,6 +165,20 @@ int pgl_simulate(int N, int64_t nT, int R, int nlin, double dt, double* X, const
  * fused + finalize).  For the _dev form call after pgl_sync. */
 int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms);
 
+/* Mean of the same two figures over the pgl_ll_grad[_dev] calls since the last reset (at most the
+ * 256 most recent ones; each call records its own HIP event set, so a caller can queue many
+ * evaluations without a host synchronisation in between).  Synchronises the stream; reset != 0
+ * starts a new window. */
+int pgl_timing_summary(pgl_handle h, int reset, int* n_launches, double* mean_fused_ms,
+                       double* mean_total_ms);
+
+/* Order all subsequent work of the handle on a caller-owned HIP stream (hipStream_t passed as
+ * void*; NULL = back to the handle's own stream).  A caller that runs collectives on its own
+ * stream (RCCL through torch.distributed) passes that stream here: evaluation and all-reduce are
+ * then ordered by the stream, with no host synchronisation between steps.  The reference has no
+ * counterpart (Theano's shared variables are synchronous). */
+int pgl_set_stream(pgl_handle h, void* stream);
+
 /* Launch geometry and algorithmic work of the fused kernel for [n_lo,n_hi):
  * info[0]=blocks, [1]=threads/block, [2]=time chunks, [3]=k-tiles(16 rows),
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),

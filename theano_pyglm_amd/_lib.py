@@ -26,6 +26,7 @@ SYMBOLS = [
     'pgl_set_stim_features', 'pgl_set_stimulus', 'pgl_get_stim_features', 'pgl_ll_grad', 'pgl_ll_grad_dev', 'pgl_sync', 'pgl_features',
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
+    'pgl_timing_summary', 'pgl_set_stream',
 ]
 
 
@@ -89,6 +90,8 @@ def load():
     lib.pgl_set_stimulus.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int,
                                      C.c_int, C.c_int]
     lib.pgl_get_stim_features.argtypes = [vp, vp]
+    lib.pgl_timing_summary.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.pgl_set_stream.argtypes = [vp, vp]
     lib.pgl_sta.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int, vp]
     lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -272,6 +275,17 @@ class DeviceGlm(object):
         a, b = C.c_double(), C.c_double()
         _chk(self.lib.pgl_last_timing(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def timing_summary(self, reset=True):
+        """(n_launches, mean fused-kernel ms, mean whole-call ms) since the last reset."""
+        n, a, b = C.c_int(), C.c_double(), C.c_double()
+        _chk(self.lib.pgl_timing_summary(self.h, 1 if reset else 0, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
+
+    def set_stream(self, stream_ptr):
+        """Order the handle's work on a caller-owned HIP stream (integer hipStream_t, e.g.
+        torch.cuda.current_stream().cuda_stream); None returns to the handle's own stream."""
+        _chk(self.lib.pgl_set_stream(self.h, None if not stream_ptr else C.c_void_p(int(stream_ptr))))
 
     def info(self, n_lo=0, n_hi=None):
         n_hi = self.N if n_hi is None else n_hi

@@ -34,8 +34,12 @@ struct pgl_context {
     double dt = 0;
     int Dstim = 0, Kimp = 0, Ktot = 0, nT16 = 0;
     int numCU = 256;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;        // stream every call of this handle is ordered on
+    hipStream_t own_stream = nullptr;    // the handle's own stream (stream == own_stream unless pgl_set_stream)
+    static constexpr int NEV = 256;      // ring of per-launch event sets {start, fused begin, fused end, end}
+    hipEvent_t evr[NEV][4] = {};
+    hipEvent_t* ev = evr[0];             // event set of the most recent pgl_ll_grad call
+    long long ev_launches = 0;           // launches recorded since the last timing reset
     bool have_spikes = false, have_basis = false;
     int64_t nnz = 0;
     DevBuf S, ST, spk, wlo, whi, phi, fstim;
@@ -297,12 +301,14 @@ int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
     h->t_lo = 0; h->t_hi = nT;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->numCU = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
-    for (int i = 0; i < 4; ++i) {
-        e = hipEventCreate(&h->ev[i]);
-        if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
-    }
+    h->stream = h->own_stream;
+    for (int s = 0; s < pgl_context::NEV; ++s)
+        for (int i = 0; i < 4; ++i) {
+            e = hipEventCreate(&h->evr[s][i]);
+            if (e != hipSuccess) { pgl_destroy(h); return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
+        }
     *out = h;
     return PGL_OK;
 }
@@ -317,9 +323,10 @@ int pgl_destroy(pgl_handle h)
                       &h->gbpart, &h->Xbuf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan};
     for (DevBuf* b : bufs) release(*b);
-    for (int i = 0; i < 4; ++i)
-        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int s = 0; s < pgl_context::NEV; ++s)
+        for (int i = 0; i < 4; ++i)
+            if (h->evr[s][i]) (void)hipEventDestroy(h->evr[s][i]);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PGL_OK;
 }
@@ -664,6 +671,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     if (d_grad) ENSURE(h->Gpart, maxG);
     const int P = 1 + h->Dstim + h->Kimp;
 
+    h->ev = h->evr[h->ev_launches % pgl_context::NEV];
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (!sliced) {
         const Plan& pl = plans[0];
@@ -737,6 +745,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     }
     HIPCHK(hipEventRecord(h->ev[3], h->stream));
     h->timing_valid = true;
+    ++h->ev_launches;
     return PGL_OK;
 }
 
@@ -796,6 +805,39 @@ int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms)
     HIPCHK(hipEventElapsedTime(&b, h->ev[0], h->ev[3]));
     if (fused_ms) *fused_ms = a;
     if (total_ms) *total_ms = b;
+    return PGL_OK;
+}
+
+int pgl_timing_summary(pgl_handle h, int reset, int* n_launches, double* mean_fused_ms, double* mean_total_ms)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const long long n = std::min<long long>(h->ev_launches, pgl_context::NEV);
+    double sa = 0, sb = 0;
+    for (long long i = 0; i < n; ++i) {
+        hipEvent_t* ev = h->evr[(h->ev_launches - 1 - i) % pgl_context::NEV];
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[1], ev[2]));
+        HIPCHK(hipEventElapsedTime(&b, ev[0], ev[3]));
+        sa += a;
+        sb += b;
+    }
+    if (n_launches) *n_launches = (int)n;
+    if (mean_fused_ms) *mean_fused_ms = n ? sa / n : 0.0;
+    if (mean_total_ms) *mean_total_ms = n ? sb / n : 0.0;
+    if (reset) h->ev_launches = 0;
+    return PGL_OK;
+}
+
+int pgl_set_stream(pgl_handle h, void* stream)
+{
+    if (!h) return fail(PGL_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));          // drain work queued on the previous stream
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    h->ev_launches = 0;
+    h->timing_valid = false;
     return PGL_OK;
 }
 
