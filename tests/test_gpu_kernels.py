@@ -336,3 +336,33 @@ def test_nonfinite_semantics_match_reference_expression():
     assert ll[2] == -np.inf and ll0[2] == -np.inf
     assert np.allclose(ll[:2], ll0[:2], rtol=LL_RTOL)
     dq.close()
+
+
+def test_external_stream_and_timing_window():
+    """pgl_set_stream orders the handle's work on a caller-owned stream (torch's current stream, the
+    one RCCL collectives are ordered against); every launch records its own event set and
+    pgl_timing_summary averages them without a host sync between launches."""
+    import torch
+    p = H.Problem(16, 4000, H.std_ibasis(), seed=70)
+    dev = p.device()
+    ll0, g0 = dev.ll_grad(p.theta, p.Weff)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        dev.set_stream(stream.cuda_stream)
+        d_theta = torch.from_numpy(p.theta).cuda()
+        d_W = torch.from_numpy(p.Weff).cuda()
+        d_ll = torch.zeros(16, dtype=torch.float64, device='cuda')
+        d_g = torch.zeros((16, p.theta.shape[1]), dtype=torch.float64, device='cuda')
+        for _ in range(5):                                   # queued back to back, no host sync
+            dev.ll_grad_dev(d_theta.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+        doubled = d_ll * 2.0                                 # torch op ordered after the evaluations
+        stream.synchronize()
+    n, fused, total = dev.timing_summary(reset=True)
+    assert n == 5 and 0 < fused <= total
+    assert dev.timing_summary()[0] == 0
+    assert np.array_equal(d_ll.cpu().numpy(), ll0) and np.array_equal(d_g.cpu().numpy(), g0)
+    assert np.array_equal(doubled.cpu().numpy(), 2.0 * ll0)
+    dev.set_stream(None)                                     # back to the handle's own stream
+    ll1, _ = dev.ll_grad(p.theta, p.Weff)
+    assert np.array_equal(ll1, ll0)
+    dev.close()
