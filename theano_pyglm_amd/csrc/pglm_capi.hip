@@ -190,6 +190,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     off += (size_t)sl.Ns * pl.cap * 8;
     if (pl.version >= 2) {
         off += 2 * ((((size_t)2 * sl.Ns * 4) + 15) & ~(size_t)15);
+        off += (((size_t)sl.Ns * 4) + 15) & ~(size_t)15;                   // ring-valid flags
         off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8 + 256;
     } else {
         off += 2 * ((((size_t)sl.Ns * 4) + 15) & ~(size_t)15);

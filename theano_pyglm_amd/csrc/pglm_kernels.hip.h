@@ -542,8 +542,12 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
                                           const int* __restrict__ s_lo,
                                           const int* __restrict__ s_cnt,
                                           const int2* __restrict__ spk, const int t0, const int B,
-                                          const int Kimp, const int tid, const int nthr)
+                                          const int Kimp, const int tid, const int nthr,
+                                          const int shift)
 {
+    // Staged events live in a per-neuron ring of CAP slots (slot = event index mod CAP) and are
+    // decoded once, relative to the first tile of the chunk; `shift` = byte offset of this tile's
+    // taps against that reference (16 bins per tile = the same even/odd table, 16 entries on).
     // item = (feature column, q): rows {2q, 2q+1, 8+2q, 9+2q}.  With this interleave the four
     // q-lanes of a column read one contiguous span of the 16-tap slice per LDS read (taps
     // 2q,2q+1 first, taps 8+2q,9+2q second) and the host picks RP so that the basis rows
@@ -565,14 +569,16 @@ __device__ __forceinline__ void gen_items(FT* __restrict__ Fs, const int rsf,
         FT a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         if (cnt <= CAP) {
             const int2* sp = s_dec + np * CAP;
+            const int start = s_lo[np];
+            const unsigned char* tbs = tb + shift;
             for (int j = 0; j < cnt; j += 2) {
-                const int2 e0 = sp[j];
-                int2 e1 = sp[j + 1 < CAP ? j + 1 : j];
-                if (j + 1 >= cnt) e1 = make_int2(0, 0);       // zero-weight dummy, valid offset
+                const int2 e0 = sp[(start + j) & (CAP - 1)];
+                int2 e1 = sp[(start + j + 1) & (CAP - 1)];
+                if (j + 1 >= cnt) e1 = make_int2(-shift, 0);  // zero-weight dummy, valid offset
                 const FT c0 = (FT)__int_as_float(e0.y);
                 const FT c1 = (FT)__int_as_float(e1.y);
-                const V2* p0 = reinterpret_cast<const V2*>(tb + e0.x);
-                const V2* p1 = reinterpret_cast<const V2*>(tb + e1.x);
+                const V2* p0 = reinterpret_cast<const V2*>(tbs + e0.x);
+                const V2* p1 = reinterpret_cast<const V2*>(tbs + e1.x);
                 const V2 u0 = p0[0], u1 = p0[4], w0 = p1[0], w1 = p1[4];
                 a0 = fma(c0, u0.x, a0);
                 a1 = fma(c0, u0.y, a1);
@@ -654,6 +660,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
     off += (((size_t)2 * N * 4) + 15) & ~(size_t)15;
     int* s_cnt = reinterpret_cast<int*>(smem + off);          // [2][N]
     off += (((size_t)2 * N * 4) + 15) & ~(size_t)15;
+    int* s_valid = reinterpret_cast<int*>(smem + off);        // [N] ring holds the neuron's current window
+    off += (((size_t)N * 4) + 15) & ~(size_t)15;
     double* Xp = reinterpret_cast<double*>(smem + off);       // [NW][4][64] partial X
     off += (size_t)NW * 256 * 8;
     double* Rb = reinterpret_cast<double*>(smem + off);       // [PTW][4][64] residuals r
@@ -708,37 +716,41 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         }
     }
     __syncthreads();
+    const int t0_ref = tile_beg * TT;             // staged events are decoded relative to this tile
     {
         const int pb0 = (tile_beg & 1) * N;
         for (int id = tid; id < N * CAP; id += nthr) {
             const int np = id / CAP, sl = id % CAP;
             const int cnt = s_cnt[pb0 + np];
-            if (cnt <= CAP && sl < cnt)
-                s_spk[id] = pgl_decode_event<ESZ>(p.spk[s_lo[pb0 + np] + sl], tile_beg * TT, B * RP * ESZ);
+            if (cnt <= CAP && sl < cnt) {
+                const int idx = s_lo[pb0 + np] + sl;
+                s_spk[np * CAP + (idx & (CAP - 1))] = pgl_decode_event<ESZ>(p.spk[idx], t0_ref, B * RP * ESZ);
+            }
         }
+        if (tid < N) s_valid[tid] = (s_cnt[pb0 + tid] <= CAP) ? 1 : 0;
     }
     __syncthreads();
 
-    constexpr int NPF = (128 * CAP + NW * 64 - 1) / (NW * 64);   // prefetched event slots per thread (N <= 128)
+    constexpr int NPF = 3;                        // new events per neuron and tile taken on the fast path
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         const int t0 = tile * TT;
         const int cur = (tile & 1) * N;
         const int nxt = ((tile + 1) & 1) * N;
-        // ---- prefetch (registers): events of tile+1, windows of tile+2 ----
+        // ---- prefetch (registers): the events that ENTER neuron tid's window with tile+1 (the
+        // window slides by 16 bins: ~0.3 new events per neuron), windows of tile+2 ----
         int2 pf[NPF];
-        bool pfv[NPF];
+        int pf_new = -1;                           // -1: nothing to do; > NPF: restage at commit time
 #pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int id = tid + q * nthr;
-            pfv[q] = false;
-            pf[q] = make_int2(0, 0);
-            if (id < N * CAP && tile + 1 < tile_end && !(p.dbg & 2)) {
-                const int np = id / CAP, sl = id % CAP;
-                const int cnt = s_cnt[nxt + np];
-                if (cnt <= CAP && sl < cnt) {
-                    pf[q] = p.spk[s_lo[nxt + np] + sl];
-                    pfv[q] = true;
-                }
+        for (int q = 0; q < NPF; ++q) pf[q] = make_int2(0, 0);
+        if (tid < N && tile + 1 < tile_end && !(p.dbg & 2)) {
+            const int hi = s_lo[cur + tid] + s_cnt[cur + tid];
+            const int cnt_n = s_cnt[nxt + tid];
+            pf_new = s_lo[nxt + tid] + cnt_n - hi;
+            if (!s_valid[tid]) pf_new = NPF + 1;
+            if (cnt_n <= CAP && pf_new <= NPF) {
+#pragma unroll
+                for (int q = 0; q < NPF; ++q)
+                    if (q < pf_new) pf[q] = p.spk[hi + q];
             }
         }
         int w2lo = 0, w2cnt = 0;
@@ -760,13 +772,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             const unsigned char* phiBytes = reinterpret_cast<const unsigned char*>(phiE);
             if (B == 5)
                 gen_items<5, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
-                                    p.Kimp, tid, nthr);
+                                    p.Kimp, tid, nthr, (t0 - t0_ref) * ESZ);
             else if (B == 3)
                 gen_items<3, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
-                                    p.Kimp, tid, nthr);
+                                    p.Kimp, tid, nthr, (t0 - t0_ref) * ESZ);
             else
                 gen_items<0, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
-                                    p.Kimp, tid, nthr);
+                                    p.Kimp, tid, nthr, (t0 - t0_ref) * ESZ);
         }
         __syncthreads();
 
@@ -820,10 +832,22 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         // ---- commit the prefetched staging for the next tile: the event slots and the
         // window buffer of `tile` were last read by gen(tile), i.e. before the barrier above;
         // committing here keeps the prefetch registers dead during epilogue and backward ----
+        if (pf_new >= 0) {                        // tid < N and there is a next tile
+            int2* ring = s_spk + tid * CAP;
+            const int hi = s_lo[cur + tid] + s_cnt[cur + tid];
+            const int lo_n = s_lo[nxt + tid], cnt_n = s_cnt[nxt + tid];
+            if (cnt_n > CAP) {
+                s_valid[tid] = 0;                 // gen takes the overflow path for this neuron
+            } else if (pf_new <= NPF) {
 #pragma unroll
-        for (int q = 0; q < NPF; ++q) {
-            const int id = tid + q * nthr;
-            if (pfv[q]) s_spk[id] = pgl_decode_event<ESZ>(pf[q], t0 + TT, B * RP * ESZ);
+                for (int q = 0; q < NPF; ++q)
+                    if (q < pf_new)
+                        ring[(hi + q) & (CAP - 1)] = pgl_decode_event<ESZ>(pf[q], t0_ref, B * RP * ESZ);
+            } else {                              // burst or ring lost during an overflow: restage
+                for (int idx = lo_n; idx < lo_n + cnt_n; ++idx)
+                    ring[idx & (CAP - 1)] = pgl_decode_event<ESZ>(p.spk[idx], t0_ref, B * RP * ESZ);
+                s_valid[tid] = 1;
+            }
         }
         if (tid < N) {                            // windows of tile+2 go to the buffer of `tile`
             s_lo[cur + tid] = w2lo;
