@@ -44,6 +44,9 @@ struct pgl_context {
     int64_t nnz = 0;
     DevBuf S, ST, spk, wlo, whi, phi, fstim;
     std::vector<int> h_ptr;              // host copy of the event-list row pointers (N+1)
+    std::vector<int2> h_ev;              // host copy of the event lists (window tables are rebuilt
+                                         // when the basis support changes)
+    int Rk = 0;                          // taps the kernels use: R minus trailing all-zero basis rows
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
@@ -126,7 +129,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     // version 3: the same kernel with f32 features / basis taps (PGL_OPT_FEATURE_F32)
     // version 1: the 4-wave kernel of the first round (PGL_OPT_KERNEL = 1)
     pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
-    pl.RP = h->R + 32;
+    pl.RP = h->Rk + 32;
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
     } else {
@@ -297,7 +300,7 @@ int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
     if (device < 0 || device >= ndev) return fail(PGL_ERR_ARG, "device index out of range");
     HIPCHK(hipSetDevice(device));
     pgl_context* h = new pgl_context();
-    h->N = N; h->nT = nT; h->B = B; h->R = R; h->nlin = nlin; h->dt = dt; h->device = device;
+    h->N = N; h->nT = nT; h->B = B; h->R = R; h->Rk = R; h->nlin = nlin; h->dt = dt; h->device = device;
     h->Kimp = N * B; h->Ktot = h->Kimp; h->nT16 = (int)((nT + 15) / 16);
     h->t_lo = 0; h->t_hi = nT;
     hipDeviceProp_t prop;
@@ -355,6 +358,34 @@ int pgl_set_option(pgl_handle h, int option, int value)
     return fail(PGL_ERR_ARG, "unknown option");
 }
 
+// per 16-row tile event windows of every neuron: lo = first event with s >= 16*tile - Rk,
+// hi = first event with s >= 16*tile + 15 (events are sorted by time within a neuron)
+static int upload_windows(pgl_handle h)
+{
+    const int N = h->N, nT16 = h->nT16;
+    const std::vector<int>& ptr = h->h_ptr;
+    const std::vector<int2>& ev = h->h_ev;
+    std::vector<int> wlo((size_t)nT16 * N), whi((size_t)nT16 * N);
+    for (int n = 0; n < N; ++n) {
+        int lo = ptr[n], hi = ptr[n];
+        const int end = ptr[n + 1];
+        for (int tile = 0; tile < nT16; ++tile) {
+            const int64_t klo = (int64_t)16 * tile - h->Rk;
+            const int64_t khi = (int64_t)16 * tile + 15;
+            while (lo < end && ev[(size_t)lo].x < klo) ++lo;
+            while (hi < end && ev[(size_t)hi].x < khi) ++hi;
+            wlo[(size_t)tile * N + n] = lo;
+            whi[(size_t)tile * N + n] = hi;
+        }
+    }
+    ENSURE(h->wlo, wlo.size() * 4);
+    ENSURE(h->whi, whi.size() * 4);
+    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), wlo.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), whi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));          // the host vectors die with this frame
+    return PGL_OK;
+}
+
 // Build the spike-event index from the dense count matrix and upload everything.
 static int upload_spikes(pgl_handle h, const uint8_t* S)
 {
@@ -377,37 +408,24 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
                 if (row[n]) ev[(size_t)cur[n]++] = make_int2((int)t, (int)row[n]);
         }
     }
-    // per 16-row tile event windows: lo = first s >= 16*tile - R, hi = first s >= 16*tile + 15
-    const int nT16 = h->nT16;
-    std::vector<int> wlo((size_t)nT16 * N), whi((size_t)nT16 * N);
-    for (int n = 0; n < N; ++n) {
-        int lo = cnt[n], hi = cnt[n];
-        const int end = cnt[n + 1];
-        for (int tile = 0; tile < nT16; ++tile) {
-            const int64_t klo = (int64_t)16 * tile - h->R;
-            const int64_t khi = (int64_t)16 * tile + 15;
-            while (lo < end && ev[(size_t)lo].x < klo) ++lo;
-            while (hi < end && ev[(size_t)hi].x < khi) ++hi;
-            wlo[(size_t)tile * N + n] = lo;
-            whi[(size_t)tile * N + n] = hi;
-        }
-    }
+    h->h_ptr = cnt;
+    h->h_ev.swap(ev);
+    const std::vector<int2>& evr = h->h_ev;
     ENSURE(h->S, (size_t)nT * N);
     ENSURE(h->ST, (size_t)nT * N);
-    ENSURE(h->spk, ev.size() * sizeof(int2));
-    ENSURE(h->wlo, wlo.size() * 4);
-    ENSURE(h->whi, whi.size() * 4);
+    ENSURE(h->spk, evr.size() * sizeof(int2));
     HIPCHK(hipMemcpyAsync(h->S.p, S, (size_t)nT * N, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->spk.p, ev.data(), ev.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->wlo.p, wlo.data(), wlo.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->whi.p, whi.data(), whi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->spk.p, evr.data(), evr.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    {
+        const int rc = upload_windows(h);
+        if (rc) return rc;
+    }
     dim3 grid((unsigned)((nT + 63) / 64), (unsigned)((N + 63) / 64));
     hipLaunchKernelGGL(k_transpose_u8, grid, dim3(256), 0, h->stream, (const uint8_t*)h->S.p,
                        (uint8_t*)h->ST.p, (long long)nT, N);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->nnz = nnz;
-    h->h_ptr = cnt;
     h->have_spikes = true;
     h->gibbs_npost = -1;
     return PGL_OK;
@@ -437,12 +455,27 @@ int pgl_set_basis(pgl_handle h, const double* ibasis)
 {
     if (!h || !ibasis) return fail(PGL_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    std::vector<double> ph((size_t)h->B * h->R);
+    // Trailing taps that are zero in every basis column contribute nothing (the raised-cosine
+    // bases of the reference end before dt_max: basis.py:56-106 leaves the last ~10 % of the
+    // 100-point grid at zero): the kernels run with Rk <= R taps and correspondingly shorter
+    // event windows -- same sums, fewer events per tile.
+    int Rk = 1;
     for (int d = 0; d < h->R; ++d)
-        for (int b = 0; b < h->B; ++b) ph[(size_t)b * h->R + d] = ibasis[(size_t)d * h->B + b];
+        for (int b = 0; b < h->B; ++b)
+            if (ibasis[(size_t)d * h->B + b] != 0.0) Rk = d + 1;
+    std::vector<double> ph((size_t)h->B * Rk);
+    for (int d = 0; d < Rk; ++d)
+        for (int b = 0; b < h->B; ++b) ph[(size_t)b * Rk + d] = ibasis[(size_t)d * h->B + b];
     ENSURE(h->phi, ph.size() * 8);
     HIPCHK(hipMemcpyAsync(h->phi.p, ph.data(), ph.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (Rk != h->Rk) {
+        h->Rk = Rk;
+        if (h->have_spikes) {
+            const int rc = upload_windows(h);
+            if (rc) return rc;
+        }
+    }
     h->have_basis = true;
     h->gibbs_npost = -1;
     return PGL_OK;
@@ -592,7 +625,7 @@ static int check_ready(pgl_handle h)
 static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, bool want_grad,
                         int mode, FusedParams& fp)
 {
-    fp.nT = h->nT; fp.N = sl.Ns; fp.B = h->B; fp.R = h->R; fp.nlin = h->nlin;
+    fp.nT = h->nT; fp.N = sl.Ns; fp.B = h->B; fp.R = h->Rk; fp.nlin = h->nlin;
     fp.Dstim = sl.Ds; fp.Kimp = sl.Ns * h->B; fp.Ktot = fp.Kimp + sl.Ds; fp.dt = h->dt;
     fp.Nall = h->N; fp.np0 = sl.np0; fp.DsAll = h->Dstim; fp.ds0 = sl.ds0;
     fp.mode = mode; fp.Xbuf = (double*)h->Xbuf.p; fp.xstride = pl.nPT * 16;
@@ -871,9 +904,9 @@ int pgl_features(pgl_handle h, double* fS_out)
     HIPCHK(hipSetDevice(h->device));
     const size_t bytes = (size_t)h->nT * h->Kimp * 8;
     ENSURE(h->tmpA, bytes);
-    hipLaunchKernelGGL(k_features, dim3(h->nT16), dim3(256), (size_t)h->B * h->R * 8, h->stream,
+    hipLaunchKernelGGL(k_features, dim3(h->nT16), dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
-                       (const double*)h->phi.p, (double*)h->tmpA.p, (long long)h->nT, h->N, h->B, h->R);
+                       (const double*)h->phi.p, (double*)h->tmpA.p, (long long)h->nT, h->N, h->B, h->Rk);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(fS_out, h->tmpA.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -885,10 +918,10 @@ static int enqueue_impulse_T(pgl_handle h, const double* d_w)
 {
     ENSURE(h->IimpT, (size_t)h->N * h->nT * 8);
     const int blocks = (int)((h->nT + 63) / 64);
-    const size_t lds = ((size_t)h->B * h->R + (size_t)h->N * h->B) * 8;
+    const size_t lds = ((size_t)h->B * h->Rk + (size_t)h->N * h->B) * 8;
     hipLaunchKernelGGL(k_impulse_T, dim3(blocks), dim3(256), lds, h->stream, (const int2*)h->spk.p,
                        (const int*)h->wlo.p, (const int*)h->whi.p, (const double*)h->phi.p, d_w,
-                       (double*)h->IimpT.p, (long long)h->nT, h->nT16, h->N, h->B, h->R);
+                       (double*)h->IimpT.p, (long long)h->nT, h->nT16, h->N, h->B, h->Rk);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
