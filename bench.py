@@ -57,13 +57,14 @@ def standard_ibasis(R=200):
     return ib
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per evaluation of the dominant kernel(s) from the committed rocprofv3 PMC summary
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_bench.sh).
     FETCH_SIZE is taken at face value: on this access pattern (byte / 4-byte / 8-byte loads, no
     16-B streams) the guide's x2 correction does not apply -- calibrated on k_transpose_u8, whose
     76.8 MB read is reported as 76.8 MB (profiles/history/r01_v1_pmc_hbm.json).
-    The newest top-level profiles/rNN_pmc.json wins (earlier iterations live in profiles/history/)."""
+    The newest top-level profiles/rNN_pmc.json wins (earlier iterations live in profiles/history/).
+    The hot path is two launches of one kernel template (pass 1 / pass 2): their bytes are summed."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
@@ -71,9 +72,15 @@ def pmc_traffic(kernel_prefix):
             d = json.load(open(f))
         except Exception:
             continue
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
-                best = (f, (v['FETCH_SIZE']['avg'] + v['WRITE_SIZE']['avg']) * 1024.0)
+        tot, found = 0.0, 0
+        for pref in kernel_prefixes:
+            for k, v in d.items():
+                if k.startswith(pref) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+                    tot += (v['FETCH_SIZE']['avg'] + v['WRITE_SIZE']['avg']) * 1024.0
+                    found += 1
+                    break
+        if found == len(kernel_prefixes):
+            best = (f, tot)
     return best
 
 
@@ -286,7 +293,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_fused2 (rank 0 shard: %d neurons x %d bins)" % (n_hi - n_lo, t_hi - t_lo),
+                "kernel": "k_fused3 pass 1 + pass 2 (rank 0 shard: %d neurons x %d bins)" % (n_hi - n_lo, t_hi - t_lo),
                 "achieved": achieved,
                 "peak": F64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -298,7 +305,7 @@ def main():
             },
         }
         if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
-            tr = pmc_traffic('void k_fused2<20, 4, 8, 16, double>')
+            tr = pmc_traffic(['void k_fused3<20, 16, 1>', 'void k_fused3<20, 16, 2>'])
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)

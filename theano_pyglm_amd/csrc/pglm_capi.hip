@@ -117,7 +117,8 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 static const int kKT[] = {2, 4, 10, 13, 20, 40};
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 
-static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl)
+static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
+                     bool single_slice = true)
 {
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
@@ -128,17 +129,33 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     // version 2: f64 features, 8 waves (2 per SIMD), one workgroup per CU
     // version 3: the same kernel with f32 features / basis taps (PGL_OPT_FEATURE_F32)
     // version 1: the 4-wave kernel of the first round (PGL_OPT_KERNEL = 1)
+    // version 4: the two-pass kernel (one workgroup = 8 post tiles, no K split; PGL_OPT_KERNEL 0 = auto
+    //            for >= 5 post tiles, 3 = force, 2 = force version 2); f64 features, one slice only
     pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
+    if (pl.version == 2 && single_slice && need >= 2 &&
+        (h->opt_kernel == 3 || (h->opt_kernel == 0 && pl.nPT >= 5)))
+        pl.version = 4;
     pl.RP = h->Rk + 32;
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
     } else {
         // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
         // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
-        while (pl.RP % 32 != (pl.version == 2 ? 8 : 6)) ++pl.RP;
+        while (pl.RP % 32 != (pl.version == 1 ? 6 : 8)) ++pl.RP;
     }
     pl.cap = PGL_CAP;
-    if (pl.version >= 2) {
+    if (pl.version == 4) {
+        const int needh = (need + 1) / 2;
+        int kth = 0;
+        for (int k : kKTW)
+            if (k >= needh) {
+                kth = k;
+                break;
+            }
+        if (kth == 0) return fail(PGL_ERR_UNSUPPORTED, "slice exceeds 640 feature columns");
+        pl.PTW = 8; pl.KSPLIT = 1; pl.KTW = kth; pl.KT = 2 * kth; pl.wpb = 8;
+        pl.nPB = (pl.nPT + 7) / 8;
+    } else if (pl.version >= 2) {
         const int nw = 8;
         const int maxptw = 4;
         pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
@@ -186,6 +203,19 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.threads = 64 * pl.wpb;
     const size_t esz = pl.f32 ? 4 : 8;
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
+    if (pl.version == 4) {
+        const int c0 = pl.KTW * 16;
+        const int rsfh = c0 + ((c0 % 32 == 0) ? 16 : 32);
+        off = std::max(off, (((size_t)2 * 16 * rsfh * 8) + 15) & ~(size_t)15);
+        off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;
+        off += (size_t)sl.Ns * pl.cap * 8;
+        off += 2 * ((((size_t)2 * sl.Ns * 4) + 15) & ~(size_t)15);
+        off += (((size_t)sl.Ns * 4) + 15) & ~(size_t)15;
+        off += 256;
+        pl.lds = off;
+        if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
+        return PGL_OK;
+    }
     if (pl.version == 1 && pl.f32)
         off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;       // V1 keeps f64 tables
     else
@@ -255,8 +285,41 @@ static hipError_t launch_fused2_k(const Plan& pl, const FusedParams& fp, hipStre
     return hipErrorInvalidValue;
 }
 
+template <int KTH>
+static hipError_t launch_fused3_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    auto k1 = k_fused3<KTH, PGL_CAP, 1>;
+    auto k2 = k_fused3<KTH, PGL_CAP, 2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    e = hipGetLastError();
+    if (e != hipSuccess || !fp.want_grad) return e;
+    hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), pl.lds, s, fp);   // second pass: other half of G
+    return hipGetLastError();
+}
+
+static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KTW) {
+    case 1: return launch_fused3_t<1>(pl, fp, s);
+    case 2: return launch_fused3_t<2>(pl, fp, s);
+    case 3: return launch_fused3_t<3>(pl, fp, s);
+    case 5: return launch_fused3_t<5>(pl, fp, s);
+    case 7: return launch_fused3_t<7>(pl, fp, s);
+    case 10: return launch_fused3_t<10>(pl, fp, s);
+    case 20: return launch_fused3_t<20>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.version == 4) return launch_fused3(pl, fp, s);
     if (pl.version == 3) {
         switch (pl.PTW) {
         case 1: return launch_fused2_k<1, 8, PGL_CAP, float>(pl, fp, s);
@@ -689,7 +752,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     const std::vector<Slice> slices = make_slices(h);
     std::vector<Plan> plans(slices.size());
     for (size_t i = 0; i < slices.size(); ++i) {
-        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i]);
+        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1);
         if (rc) return rc;
     }
     const bool sliced = slices.size() > 1;
@@ -711,6 +774,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         const Plan& pl = plans[0];
         int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
+        if (pl.version == 4 && d_grad)                          // residual slab of the two-pass kernel
+            ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -880,7 +945,7 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
     const std::vector<Slice> slices = make_slices(h);
     Plan pl;
-    int rc = make_plan(h, n_lo, n_hi, slices[0], pl);
+    int rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1);
     if (rc) return rc;
     const double P = 1.0 + h->Dstim + h->Kimp;
     double v[9];
