@@ -45,7 +45,9 @@ typedef struct pgl_context* pgl_handle;
 /* flags for pgl_set_option */
 #define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
 #define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
-#define PGL_OPT_KERNEL 3       /* 0 = auto (8-wave K-split kernel), 1 = 4-wave kernel of round 1 */
+#define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel for >= 80 post-synaptic neurons per call,
+                                * 8-wave K-split kernel otherwise; 1 = 4-wave kernel of the first version;
+                                * 2 = force the K-split kernel; 3 = force the two-pass kernel */
 
 const char* pgl_last_error(void);
 int pgl_version(void);

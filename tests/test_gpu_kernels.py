@@ -366,3 +366,39 @@ def test_external_stream_and_timing_window():
     ll1, _ = dev.ll_grad(p.theta, p.Weff)
     assert np.array_equal(ll1, ll0)
     dev.close()
+
+
+def test_two_pass_kernel_shapes_and_agreement():
+    """The two-pass kernel (k_fused3: default from 5 post tiles = 65 neurons on) against the oracle
+    and against the K-split kernel on shapes that stress its column split: odd k-tile counts, stimulus
+    columns in the second half, ragged neuron counts, a time range off the tile grid, ll only."""
+    from theano_pyglm_amd import _lib
+    # N=80, B=5: 400 columns = 25 k-tiles -> halves of 13 (padded); N=96, B=3 + 9 stimulus columns
+    for p in (H.Problem(80, 1800, H.std_ibasis(), seed=80, w_scale=0.5),
+              H.Problem(96, 1500, H.st_ibasis(), kind='exp', Dstim=9, seed=81, w_scale=0.02),
+              H.Problem(70, 1000, H.std_ibasis(), seed=82, weighted=True, w_scale=0.5),
+              H.Problem(128, 700, H.std_ibasis(), seed=83, Dstim=0, w_scale=0.5)):
+        ll, g = _check(p)
+        d2 = p.device()
+        d2.set_option(_lib.OPT_KERNEL, 2)                 # K-split kernel on the same problem
+        ll2, g2 = d2.ll_grad(p.theta, p.Weff)
+        assert np.allclose(ll2, ll, rtol=1e-12) and H.rel_err(g2, g) < 1e-12
+        info3, info2 = p.device().info(), d2.info()
+        assert info3['blocks'] != info2['blocks'] or info3['lds_bytes'] != info2['lds_bytes']
+        d2.close()
+    # forced on a small population (2 post tiles, 6 idle waves) and with a restricted time range
+    p = H.Problem(24, 3000, H.std_ibasis(), seed=84, weighted=True)
+    d3 = p.device()
+    d3.set_option(_lib.OPT_KERNEL, 3)
+    ll3, g3 = d3.ll_grad(p.theta, p.Weff)
+    ll0, g0 = p.oracle_ll_grad()
+    assert np.allclose(ll3, ll0, rtol=LL_RTOL) and H.rel_err(g3, g0) < G_RTOL
+    d3.set_time_range(1008, 2501)                          # t_hi off the 16-bin tile grid
+    lla, ga = d3.ll_grad(p.theta, p.Weff)
+    d2 = p.device()
+    d2.set_option(_lib.OPT_KERNEL, 2)
+    d2.set_time_range(1008, 2501)
+    llb, gb = d2.ll_grad(p.theta, p.Weff)
+    assert np.allclose(lla, llb, rtol=1e-12) and H.rel_err(ga, gb) < 1e-12
+    d3.close()
+    d2.close()

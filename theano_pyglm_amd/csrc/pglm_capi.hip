@@ -116,6 +116,7 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 
 static const int kKT[] = {2, 4, 10, 13, 20, 40};
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
+static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
                      bool single_slice = true)
@@ -147,7 +148,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     if (pl.version == 4) {
         const int needh = (need + 1) / 2;
         int kth = 0;
-        for (int k : kKTW)
+        for (int k : kKTH)
             if (k >= needh) {
                 kth = k;
                 break;
@@ -312,6 +313,8 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
     case 5: return launch_fused3_t<5>(pl, fp, s);
     case 7: return launch_fused3_t<7>(pl, fp, s);
     case 10: return launch_fused3_t<10>(pl, fp, s);
+    case 13: return launch_fused3_t<13>(pl, fp, s);
+    case 16: return launch_fused3_t<16>(pl, fp, s);
     case 20: return launch_fused3_t<20>(pl, fp, s);
     }
     return hipErrorInvalidValue;
