@@ -48,6 +48,8 @@ struct pgl_context {
                                          // when the basis support changes)
     int Rk = 0;                          // taps the kernels use: R minus trailing all-zero basis rows
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
+    DevBuf fimg;                         // resident feature tiles (k_fused5)
+    int fimg_kth = 0;                    // half width (k-tiles) the images were built for; 0 = stale
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -133,9 +135,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     // version 4: the two-pass kernel (one workgroup = 8 post tiles, no K split; PGL_OPT_KERNEL 0 = auto
     //            for >= 5 post tiles, 3 = force, 2 = force version 2); f64 features, one slice only
     pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
-    if (pl.version == 2 && single_slice && need >= 2 &&
-        (h->opt_kernel == 3 || (h->opt_kernel == 0 && pl.nPT >= 5)))
-        pl.version = 4;
+    if (pl.version == 2 && single_slice && need >= 2) {
+        if (h->opt_kernel == 3) pl.version = 4;
+        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && pl.nPT >= 5)) pl.version = 5;
+    }
     pl.RP = h->Rk + 32;
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
@@ -145,7 +148,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         while (pl.RP % 32 != (pl.version == 1 ? 6 : 8)) ++pl.RP;
     }
     pl.cap = PGL_CAP;
-    if (pl.version == 4) {
+    if (pl.version == 4 || pl.version == 5) {
         const int needh = (need + 1) / 2;
         int kth = 0;
         for (int k : kKTH)
@@ -204,6 +207,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.threads = 64 * pl.wpb;
     const size_t esz = pl.f32 ? 4 : 8;
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
+    if (pl.version == 5) {
+        pl.lds = (size_t)3 * pgl_img_bytes(pl.KTW) + 256;
+        if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
+        return PGL_OK;
+    }
     if (pl.version == 4) {
         const int c0 = pl.KTW * 16;
         const int rsfh = c0 + ((c0 % 32 == 0) ? 16 : 32);
@@ -320,8 +328,43 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
     return hipErrorInvalidValue;
 }
 
+template <int KTH>
+static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    auto k1 = k_fused5<KTH, 1>;
+    auto k2 = k_fused5<KTH, 2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    e = hipGetLastError();
+    if (e != hipSuccess || !fp.want_grad) return e;
+    hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), (size_t)2 * pgl_img_bytes(KTH) + 256, s, fp);
+    return hipGetLastError();
+}
+
+static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KTW) {
+    case 1: return launch_fused5_t<1>(pl, fp, s);
+    case 2: return launch_fused5_t<2>(pl, fp, s);
+    case 3: return launch_fused5_t<3>(pl, fp, s);
+    case 5: return launch_fused5_t<5>(pl, fp, s);
+    case 7: return launch_fused5_t<7>(pl, fp, s);
+    case 10: return launch_fused5_t<10>(pl, fp, s);
+    case 13: return launch_fused5_t<13>(pl, fp, s);
+    case 16: return launch_fused5_t<16>(pl, fp, s);
+    case 20: return launch_fused5_t<20>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.version == 5) return launch_fused5(pl, fp, s);
     if (pl.version == 4) return launch_fused3(pl, fp, s);
     if (pl.version == 3) {
         switch (pl.PTW) {
@@ -390,7 +433,7 @@ int pgl_destroy(pgl_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
-                      &h->gbpart, &h->Xbuf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
+                      &h->gbpart, &h->Xbuf, &h->fimg, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
@@ -494,6 +537,7 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     h->nnz = nnz;
     h->have_spikes = true;
     h->gibbs_npost = -1;
+    h->fimg_kth = 0;
     return PGL_OK;
 }
 
@@ -544,6 +588,7 @@ int pgl_set_basis(pgl_handle h, const double* ibasis)
     }
     h->have_basis = true;
     h->gibbs_npost = -1;
+    h->fimg_kth = 0;
     return PGL_OK;
 }
 
@@ -555,6 +600,7 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     h->Dstim = Dstim;
     h->Ktot = h->Kimp + Dstim;
     h->gibbs_npost = -1;
+    h->fimg_kth = 0;
     if (Dstim > 0) {
         const size_t bytes = (size_t)h->nT * Dstim * 8;
         ENSURE(h->fstim, bytes);
@@ -607,6 +653,7 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
     h->Dstim = Dstim;
     h->Ktot = h->Kimp + Dstim;
     h->gibbs_npost = -1;
+    h->fimg_kth = 0;
     return PGL_OK;
 }
 
@@ -707,6 +754,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.t_hi = h->t_hi;
     fp.want_grad = want_grad ? 1 : 0;
     fp.dbg = h->opt_dbg;
+    fp.Fimg = (const unsigned char*)h->fimg.p;
 }
 
 static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
@@ -744,6 +792,23 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
                              : launch_fused_kt<double>(pl, fp, s);
 }
 
+// Resident feature tiles of the whole recording for half width `kth` k-tiles (k_build_fimg):
+// built on first use and after every change of spikes / basis / stimulus features.
+static int ensure_feature_images(pgl_handle h, int kth)
+{
+    if (h->fimg_kth == kth && h->fimg.p) return PGL_OK;
+    const size_t bytes = (size_t)h->nT16 * 2 * (size_t)pgl_img_bytes(kth);
+    ENSURE(h->fimg, bytes);
+    dim3 grid((unsigned)h->nT16, 2);
+    hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
+                       (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
+                       (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
+                       h->Rk, h->Dstim, kth, (unsigned char*)h->fimg.p);
+    HIPCHK(hipGetLastError());
+    h->fimg_kth = kth;
+    return PGL_OK;
+}
+
 // Enqueue one evaluation on the handle's stream.  All pointers are device pointers.
 //  * one slice (N <= 128 and N*B + Dstim <= 640): prep + fused kernel + finalize;
 //  * otherwise the 3-phase path: per slice a forward-only launch accumulating the currents in
@@ -777,8 +842,12 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         const Plan& pl = plans[0];
         int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
-        if (pl.version == 4 && d_grad)                          // residual slab of the two-pass kernel
+        if (pl.version >= 4 && d_grad)                          // residual slab of the two-pass kernels
             ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
+        if (pl.version == 5) {
+            rc = ensure_feature_images(h, pl.KTW);
+            if (rc) return rc;
+        }
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
         HIPCHK(hipEventRecord(h->ev[1], h->stream));

@@ -70,6 +70,7 @@ struct FusedParams {
     long long t_hi;                      // rows >= t_hi are excluded from ll / gradient
     int want_grad;
     int dbg;                             // timing ablation bits (results invalid when != 0)
+    const unsigned char* __restrict__ Fimg;   // resident feature tiles (k_fused5), else null
 };
 
 // ---------------------------------------------------------------------------
@@ -1228,8 +1229,10 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
         // ---- residuals to HBM for pass 2, backward for the first half of the columns ----
         if (active && p.want_grad && !(p.dbg & 16)) {
             double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
+            if (!(p.dbg & 512)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
+                for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
+            }
             const FT* fb = Fs + grp * rsf + col;
             constexpr int NS = 4 * KTH;
             constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
@@ -1379,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
         // while its SIMD neighbour still generates).  Forcing that overlap -- waves 0-3 generate
         // first, 4-7 multiply first -- measured 5 % slower: one MFMA wave per SIMD does not fill
         // the pipe.
-        if (active) {
+        if (active && !(p.dbg & 512)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) rv[r] = rslab[(size_t)(tile - p.tile0) * rstride + r * 64];
         }
@@ -1396,6 +1399,313 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
             for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
         }
     }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Resident feature tiles.  The basis-convolved spike history fS does not depend on the
+// parameters: the reference builds it once per data set (LinearBasisImpulses.preprocess_data,
+// impulse.py:114-130, data['fS']) and so does this path -- k_build_fimg writes, for every 16-bin
+// time tile, the two half-width F tiles (columns [0,C0) and [C0,2*C0), stimulus columns
+// included) as ready-made LDS images.  k_fused5 then streams them with LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, no ds_write) instead of regenerating F from the spike
+// events in every evaluation: 3.1 GB of HBM reads per C3 evaluation (0.4 ms of HBM time, hidden
+// under 2.5 ms of f64 MFMA) replace ~0.7 ms of LDS/VALU-bound generation.
+//   image = [16 rows][RSH doubles], RSH = C0 + 2 (bank spread of the forward A reads), padded to
+//   a multiple of 1 KiB (one DMA instruction moves 64 lanes x 16 B, lane-linear).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double conv_one(const int2* __restrict__ spk, int lo, int hi, int tg,
+                                           int R, const double* __restrict__ phi_b)
+{
+    double a = 0.0;
+    for (int j = lo; j < hi; ++j) {
+        const int2 e = spk[j];
+        const int d = tg - e.x - 1;
+        if (d >= 0 && d < R) a = fma((double)e.y, phi_b[d], a);
+    }
+    return a;
+}
+
+__host__ __device__ constexpr int pgl_img_rsh(int kth) { return kth * 16 + 2; }
+__host__ __device__ constexpr int pgl_img_bytes(int kth) { return ((16 * pgl_img_rsh(kth) * 8 + 1023) / 1024) * 1024; }
+
+// grid = (nT16, 2); block = 256.  One block builds one half image.
+__global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk,
+                                                    const int* __restrict__ wlo,
+                                                    const int* __restrict__ whi,
+                                                    const double* __restrict__ phi,
+                                                    const double* __restrict__ fstim, long long nT,
+                                                    int N, int B, int R, int Dstim, int kth,
+                                                    unsigned char* __restrict__ Fimg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* phiS = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < B * R; i += blockDim.x) phiS[i] = phi[i];
+    __syncthreads();
+    const int tile = blockIdx.x, half = blockIdx.y;
+    const int rsh = pgl_img_rsh(kth), c0 = kth * 16, Kimp = N * B;
+    const size_t img = (size_t)pgl_img_bytes(kth);
+    double* dst = reinterpret_cast<double*>(Fimg + ((size_t)tile * 2 + half) * img);
+    const int nel = (int)(img / 8);
+    for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+        const int t = i / rsh, c = i - t * rsh;
+        double v = 0.0;
+        if (t < 16 && c < c0) {
+            const int col = half * c0 + c;
+            const long long tg = (long long)tile * 16 + t;
+            if (col < Kimp) {
+                const int np = col / B, b = col - np * B;
+                v = conv_one(spk, wlo[(size_t)tile * N + np], whi[(size_t)tile * N + np], (int)tg, R, phiS + b * R);
+            } else if (col < Kimp + Dstim) {
+                v = (tg < nT) ? fstim[tg * Dstim + (col - Kimp)] : 0.0;
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+template <int KTH>
+__device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
+                                             const int wave, const int lane)
+{
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int NCH = pgl_img_bytes(KTH) / 1024;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += 8) {
+        const int c = c0 + wave;
+        if (c < NCH)
+            __builtin_amdgcn_global_load_lds((gvoid*)(gimg + (size_t)c * 1024 + lane * 16),
+                                             (lvoid*)(lds_dst + (size_t)c * 1024), 16, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused ll + grad kernel, version 5: the two-pass structure of k_fused3 on resident feature tiles.
+//   pass 1, per tile: [L_i | H_i in LDS] forward over both halves | barrier | DMA of L_{i+1} (third
+//           buffer) and H_{i+1} (over H_i) | epilogue on the accumulator registers | r to HBM |
+//           backward for the first half from L_i | wait for the DMA | barrier.
+//   pass 2, per tile: wait for H_i | barrier | DMA of H_{i+1} into the other buffer | backward
+//           for the second half with r read back.
+// No event windows, no basis tables, no staging: the waves only issue DMA, LDS reads and MFMAs.
+// ---------------------------------------------------------------------------
+template <int KTH, int PASS>
+__global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
+{
+    constexpr int TT = 16, NW = 8;
+    constexpr int KT_ALL = 2 * KTH;
+    constexpr int KS_ALL = 4 * KT_ALL;
+    constexpr int KSH = 4 * KTH;                 // k-steps per half
+    constexpr int RSH = pgl_img_rsh(KTH);
+    constexpr int IMG = pgl_img_bytes(KTH);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nPB = (p.nPT + NW - 1) / NW;
+    const int pb = blockIdx.x % nPB;
+    const int chunk = blockIdx.x / nPB;
+    const int pt = pb * NW + wave;
+    const bool active = pt < p.nPT;
+
+    unsigned char* buf0 = smem;
+    unsigned char* buf1 = smem + IMG;
+    unsigned char* buf2 = smem + 2 * IMG;        // pass 1 only
+    double* Cs = reinterpret_cast<double*>(smem + (PASS == 1 ? 3 : 2) * IMG);
+    if (tid < 32) Cs[tid] = PGL_C[tid];
+
+    d4_t G[KTH];
+#pragma unroll
+    for (int kt = 0; kt < KTH; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    const int col = lane & 15;
+    const int grp = lane >> 4;
+    const int nloc = pt * 16 + col;
+    const bool valid_n = active && (nloc < p.npost);
+    const int nglob = p.n_lo + (valid_n ? nloc : 0);
+
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
+    int tile_end = tile_beg + p.tilesPerChunk;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
+    double* const rslab = p.Xbuf + ((size_t)(active ? pt : 0)) * 256 + lane;
+    const size_t rstride = (size_t)p.nPT * 256;
+    const unsigned char* __restrict__ fimg = p.Fimg;
+
+    auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4]) {
+        const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSH + col;
+        constexpr int NS = 4 * KTH;
+        constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
+        double ar[PD];
+#pragma unroll
+        for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTH)) * RSH + 16 * (s % KTH)];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double a = ar[s % PD];
+            if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTH)) * RSH + 16 * ((s + PD) % KTH)];
+            G[s % KTH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTH], G[s % KTH], 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if constexpr (PASS == 1) {
+        double ll_acc = 0.0, gb_acc = 0.0;
+        const double bias_l = valid_n ? p.bias[nloc] : 0.0;
+        const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS_ALL * 64;
+        // prologue: L and H of the first tile
+        if (tile_beg < tile_end) {
+            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 0) * IMG, buf0, wave, lane);
+            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 1) * IMG, buf1, wave, lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
+        __syncthreads();
+        for (int tile = tile_beg; tile < tile_end; ++tile) {
+            const int t0 = tile * TT;
+            const int par = (tile - tile_beg) & 1;
+            const unsigned char* Lb = par ? buf2 : buf0;     // L alternates buf0 / buf2, H lives in buf1
+            unsigned char* Ln = par ? buf0 : buf2;
+            unsigned scb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long tg = (long long)t0 + grp + 4 * r;
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+                scb[r] = p.S[tc * p.Nall + nglob];
+            }
+            // ---- forward over both halves ----
+            d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
+            d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+            if (active && !(p.dbg & 8)) {
+                const double* faL = reinterpret_cast<const double*>(Lb) + col * RSH + grp;
+                const double* faH = reinterpret_cast<const double*>(buf1) + col * RSH + grp;
+                const double* wr_s = wrow;
+                asm volatile("" : "+s"(wr_s));
+                constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
+                constexpr int PA = 4;
+                const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
+                pgl_d2 wr[PW2];
+                double ar[PA];
+#pragma unroll
+                for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+#pragma unroll
+                for (int s = 0; s < PA; ++s) ar[s] = (s < KSH) ? faL[4 * s] : faH[4 * (s - KSH)];
+#pragma unroll
+                for (int s = 0; s < KS_ALL; ++s) {
+                    const double a = ar[s % PA];
+                    const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
+                    if (s + PA < KS_ALL)
+                        ar[s % PA] = (s + PA < KSH) ? faL[4 * (s + PA)] : faH[4 * (s + PA - KSH)];
+                    if ((s & 1) && (s / 2 + PW2 < KS_ALL / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
+                    if (s & 1)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the spike counts are consumed here, before the DMAs are issued: behind an LDS-DMA in
+            // flight the compiler's wait for an earlier ordinary load is vmcnt(0) and would drain it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(scb[r]));
+            __syncthreads();                              // every wave is done with H_i (buf1)
+            if (tile + 1 < tile_end) {                    // tile+1 arrives under epilogue + backward
+                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln, wave, lane);
+                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, wave, lane);
+            }
+            // ---- epilogue on the accumulator registers, two elements at a time ----
+            double rr[4];
+            if (active) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    double xe[2], se[2], terme[2], rese[2];
+                    bool vte[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * h2 + e;
+                        xe[e] = bias_l + (acc0[r] + acc1[r]);
+                        se[e] = (double)scb[r];
+                        const long long tg = (long long)t0 + grp + 4 * r;
+                        vte[e] = valid_n && (tg < p.t_hi);
+                    }
+                    if (p.dbg & 4) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            terme[e] = xe[e] * se[e];
+                            rese[e] = xe[e] - se[e];
+                        }
+                    } else {
+                        pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                        asm volatile("" : "+v"(Cl));
+                        pgl_rate_terms_n<2>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double res = vte[e] ? rese[e] : 0.0;
+                        rr[2 * h2 + e] = res;
+                        ll_acc += vte[e] ? terme[e] : 0.0;
+                        gb_acc += res;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rr[r] = 0.0;
+            }
+            if (active && p.want_grad && !(p.dbg & 16)) {
+                double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
+                bwd_half(Lb, rr);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
+            __syncthreads();
+        }
+        if (active) {
+            const size_t slot = (size_t)chunk * p.nPT + pt;
+            p.llpart[slot * 64 + lane] = ll_acc;
+            p.gbpart[slot * 64 + lane] = gb_acc;
+        }
+        if (active && p.want_grad) {
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL) * 256 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KTH; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            }
+        }
+    } else {
+        // =============================== pass 2 ===============================
+        double rv[4] = {0.0, 0.0, 0.0, 0.0}, rn[4] = {0.0, 0.0, 0.0, 0.0};
+        if (tile_beg < tile_end) {
+            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 1) * IMG, buf0, wave, lane);
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
+            }
+        }
+        for (int tile = tile_beg; tile < tile_end; ++tile) {
+            const int par = (tile - tile_beg) & 1;
+            const unsigned char* Hb = par ? buf1 : buf0;
+            unsigned char* Hn = par ? buf0 : buf1;
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): H_i and r_i are here
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = rn[r];
+            __syncthreads();                              // ... for every wave; H_{i-1}'s buffer is free
+            if (tile + 1 < tile_end) {
+                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, wave, lane);
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
+                }
+            }
+            if (active && !(p.dbg & 16)) bwd_half(Hb, rv);
+        }
+        if (active) {
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTH) * 256 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KTH; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            }
+        }
     }
 }
 
@@ -1574,18 +1884,6 @@ __global__ __launch_bounds__(64) void k_rows_reduce(const double* __restrict__ l
 // ---------------------------------------------------------------------------
 // direct-form helpers (not MFMA): features, impulse currents, state, MCMC inner ll
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double conv_one(const int2* __restrict__ spk, int lo, int hi, int tg,
-                                           int R, const double* __restrict__ phi_b)
-{
-    double a = 0.0;
-    for (int j = lo; j < hi; ++j) {
-        const int2 e = spk[j];
-        const int d = tg - e.x - 1;
-        if (d >= 0 && d < R) a = fma((double)e.y, phi_b[d], a);
-    }
-    return a;
-}
-
 // fS[t][n'][b]  (basis.py:201-236).  One block per 16-row tile.
 __global__ void k_features(const int2* __restrict__ spk, const int* __restrict__ wlo,
                            const int* __restrict__ whi, const double* __restrict__ phi,
