@@ -57,14 +57,17 @@ def standard_ibasis(R=200):
     return ib
 
 
-def pmc_traffic(kernel_prefixes):
+def pmc_traffic(kernel_prefixes, fetch_scale=2.0):
     """HBM bytes per evaluation of the dominant kernel(s) from the committed rocprofv3 PMC summary
     (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_bench.sh).
-    FETCH_SIZE is taken at face value: on this access pattern (byte / 4-byte / 8-byte loads, no
-    16-B streams) the guide's x2 correction does not apply -- calibrated on k_transpose_u8, whose
-    76.8 MB read is reported as 76.8 MB (profiles/history/r01_v1_pmc_hbm.json).
-    The newest top-level profiles/rNN_pmc.json wins (earlier iterations live in profiles/history/).
-    The hot path is two launches of one kernel template (pass 1 / pass 2): their bytes are summed."""
+    The hot path is two launches of one kernel template (pass 1 / pass 2): their bytes are summed.
+    gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half of the
+    bytes of wide coalesced streaming reads (16 B per lane, global_load and LDS-DMA alike); the
+    reads of k_fused5 are such streams (feature tiles by global_load_lds_dwordx4, Wmat fragments by
+    global_load_dwordx4), so FETCH_SIZE is doubled -- cross-check: pass 2 then reads 2.14 GB against
+    1.57 GB of feature tiles + 0.61 GB of residuals.  WRITE_SIZE is taken at face value (8-byte
+    stores; pass 1 writes 0.69 GB = 0.61 GB residual slab + 0.08 GB of G partials).
+    The newest top-level profiles/rNN_pmc.json wins (earlier iterations live in profiles/history/)."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
@@ -76,7 +79,7 @@ def pmc_traffic(kernel_prefixes):
         for pref in kernel_prefixes:
             for k, v in d.items():
                 if k.startswith(pref) and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
-                    tot += (v['FETCH_SIZE']['avg'] + v['WRITE_SIZE']['avg']) * 1024.0
+                    tot += (fetch_scale * v['FETCH_SIZE']['avg'] + v['WRITE_SIZE']['avg']) * 1024.0
                     found += 1
                     break
         if found == len(kernel_prefixes):
@@ -289,11 +292,16 @@ def main():
                             ("post-synaptic neurons block-partitioned over %d rank(s); S replicated; "
                              "all-gather of ll per step" % world),
                 "feature_staging": "f32" if args.f32_features else "f64",
+                "features": ("resident f64 tiles built once per data set (the reference's data['fS'], "
+                             "impulse.py:114-130): %.2f GB in HBM, streamed by LDS-DMA"
+                             % (info['resident_feature_bytes'] / 1e9))
+                if info['kernel_version'] == 5 else "regenerated from the spike events in every evaluation",
                 "spike_events": int(info['events']),
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_fused3 pass 1 + pass 2 (rank 0 shard: %d neurons x %d bins)" % (n_hi - n_lo, t_hi - t_lo),
+                "kernel": "k_fused5 pass 1 + pass 2 on resident feature tiles (rank 0 shard: %d neurons x %d bins)"
+                          % (n_hi - n_lo, t_hi - t_lo),
                 "achieved": achieved,
                 "peak": F64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -302,10 +310,11 @@ def main():
                 "kernel_ms": kern_ms,
                 "algorithmic_flops_per_launch": info['flops'],
                 "algorithmic_bytes_per_launch": info['bytes'],
+                "streamed_bytes_per_launch": info['streamed_bytes'],
             },
         }
         if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
-            tr = pmc_traffic(['void k_fused3<20, 16, 1>', 'void k_fused3<20, 16, 2>'])
+            tr = pmc_traffic(['void k_fused5<20, 1>', 'void k_fused5<20, 2>'])
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)

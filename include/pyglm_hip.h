@@ -45,9 +45,13 @@ typedef struct pgl_context* pgl_handle;
 /* flags for pgl_set_option */
 #define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
 #define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
-#define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel for >= 80 post-synaptic neurons per call,
+#define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel for >= 65 post-synaptic neurons per call,
                                 * 8-wave K-split kernel otherwise; 1 = 4-wave kernel of the first version;
-                                * 2 = force the K-split kernel; 3 = force the two-pass kernel */
+                                * 2 = force the K-split kernel; 3 = force the two-pass kernel with
+                                * on-the-fly features; 4 = force the two-pass kernel on resident feature
+                                * tiles.  Auto uses 4's kernel (k_fused5) when the call covers >= 65
+                                * post-synaptic neurons and the device can hold the tiles
+                                * (nT/16 * 2 * ~41 KB at K = 640: 3.1 GB for nT = 600 000) */
 
 const char* pgl_last_error(void);
 int pgl_version(void);
@@ -184,7 +188,10 @@ int pgl_set_stream(pgl_handle h, void* stream);
 /* Launch geometry and algorithmic work of the fused kernel for [n_lo,n_hi):
  * info[0]=blocks, [1]=threads/block, [2]=time chunks, [3]=k-tiles(16 rows),
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),
- * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins). */
+ * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins), [9]=kernel the call would use
+ * (1 4-wave, 2 K-split, 3 K-split with f32 features, 4 two-pass, 5 two-pass on resident feature
+ * tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
+ * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab). */
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info);
 
 #ifdef __cplusplus

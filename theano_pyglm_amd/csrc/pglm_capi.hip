@@ -139,6 +139,21 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (h->opt_kernel == 3) pl.version = 4;
         else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && pl.nPT >= 5)) pl.version = 5;
     }
+    if (pl.version == 5 && h->opt_kernel == 0 && h->fimg_kth == 0) {
+        // resident feature tiles need nT16 * 2 * image bytes of HBM (3.1 GB at C3); in auto mode fall
+        // back to on-the-fly generation (version 4) when the device cannot spare them
+        int kth = 0;
+        for (int k : kKTH)
+            if (k >= (need + 1) / 2) {
+                kth = k;
+                break;
+            }
+        size_t free_b = 0, total_b = 0;
+        if (kth > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t want = (size_t)h->nT16 * 2 * (size_t)pgl_img_bytes(kth) + h->fimg.cap * 0;
+            if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) pl.version = 4;
+        }
+    }
     pl.RP = h->Rk + 32;
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
@@ -1020,7 +1035,13 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     int rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1);
     if (rc) return rc;
     const double P = 1.0 + h->Dstim + h->Kimp;
-    double v[9];
+    double v[12];
+    v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
+    v[10] = (pl.version == 5) ? (double)h->nT16 * 2.0 * pgl_img_bytes(pl.KTW) : 0.0;   // resident feature bytes
+    // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
+    // pass 1 and half of them again in pass 2, residual slab written and read)
+    v[11] = (pl.version == 5) ? 1.5 * v[10] + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
+            : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0 : 0.0;
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;
     const double nrows = (double)(h->t_hi - h->t_lo);
@@ -1029,7 +1050,7 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     v[7] = nrows * h->N + nrows * h->Dstim * 8.0 + 8.0 * pl.npost * P +
            8.0 * pl.npost * (1.0 + P);
     v[8] = (double)h->nnz;
-    for (int i = 0; i < n_info && i < 9; ++i) info[i] = v[i];
+    for (int i = 0; i < n_info && i < 12; ++i) info[i] = v[i];
     return PGL_OK;
 }
 
