@@ -369,8 +369,9 @@ def test_external_stream_and_timing_window():
 
 
 def test_two_pass_kernel_shapes_and_agreement():
-    """The two-pass kernel (k_fused3: default from 5 post tiles = 65 neurons on) against the oracle
-    and against the K-split kernel on shapes that stress its column split: odd k-tile counts, stimulus
+    """The two-pass kernels (default from 5 post tiles = 65 neurons on: k_fused5 on resident feature
+    tiles; k_fused3 with on-the-fly features) against the oracle and against the K-split kernel on
+    shapes that stress the column split: odd k-tile counts, stimulus
     columns in the second half, ragged neuron counts, a time range off the tile grid, ll only."""
     from theano_pyglm_amd import _lib
     # N=80, B=5: 400 columns = 25 k-tiles -> halves of 13 (padded); N=96, B=3 + 9 stimulus columns
@@ -378,14 +379,24 @@ def test_two_pass_kernel_shapes_and_agreement():
               H.Problem(96, 1500, H.st_ibasis(), kind='exp', Dstim=9, seed=81, w_scale=0.02),
               H.Problem(70, 1000, H.std_ibasis(), seed=82, weighted=True, w_scale=0.5),
               H.Problem(128, 700, H.std_ibasis(), seed=83, Dstim=0, w_scale=0.5)):
-        ll, g = _check(p)
-        d2 = p.device()
-        d2.set_option(_lib.OPT_KERNEL, 2)                 # K-split kernel on the same problem
-        ll2, g2 = d2.ll_grad(p.theta, p.Weff)
-        assert np.allclose(ll2, ll, rtol=1e-12) and H.rel_err(g2, g) < 1e-12
-        info3, info2 = p.device().info(), d2.info()
-        assert info3['blocks'] != info2['blocks'] or info3['lds_bytes'] != info2['lds_bytes']
-        d2.close()
+        ll, g = _check(p)                                  # default: resident feature tiles (k_fused5)
+        assert p.device().info()['kernel_version'] == 5
+        for kern, ver in ((2, 2), (3, 4), (4, 5)):         # K-split, two-pass on the fly, two-pass resident
+            dk = p.device()
+            dk.set_option(_lib.OPT_KERNEL, kern)
+            assert dk.info()['kernel_version'] == ver
+            llk, gk = dk.ll_grad(p.theta, p.Weff)
+            assert np.allclose(llk, ll, rtol=1e-12) and H.rel_err(gk, g) < 1e-12
+            # new spikes / basis invalidate the resident tiles: same answer after a re-upload
+            if kern == 4:
+                dk.set_spikes(p.S)
+                dk.set_basis(p.ibasis)
+                if p.Dstim:
+                    dk.set_stim_features(p.fstim)
+                ll5, g5 = dk.ll_grad(p.theta, p.Weff)
+                assert np.array_equal(ll5, llk) and np.array_equal(g5, gk)
+                assert dk.info()['resident_feature_bytes'] > 0
+            dk.close()
     # forced on a small population (2 post tiles, 6 idle waves) and with a restricted time range
     p = H.Problem(24, 3000, H.std_ibasis(), seed=84, weighted=True)
     d3 = p.device()
