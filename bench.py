@@ -100,12 +100,15 @@ def map_wall_clock(S, N, dt):
     popn.add_data({'S': S, 'N': N, 'dt': dt, 'T': S.shape[0] * dt, 'stim': None, 'dt_stim': 0.1})
     x0 = popn.sample(np.random.RandomState(0))
     lp0 = popn.compute_log_p(x0)
-    t0 = time.perf_counter()
-    x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
-    wall = time.perf_counter() - t0
+    walls = []
+    for rep in range(2):        # the first sweep also pays torch's lazy rocBLAS / kernel loading
+        t0 = time.perf_counter()
+        x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+        walls.append(time.perf_counter() - t0)
     lp1 = popn.compute_log_p(x)
     popn.release_data()
-    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": wall,
+    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": walls[1],
+            "first_call_s": walls[0],
             "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
             "bfgs_iterations": getattr(popn, 'last_fit_stats', {}).get('iterations'),
             "ll_grad_evaluations": getattr(popn, 'last_fit_stats', {}).get('evaluations'),
