@@ -87,6 +87,30 @@ def pmc_traffic(kernel_prefixes, fetch_scale=2.0):
     return best
 
 
+def pmc_mfma_busy(kernel_prefixes, n_xcd=8, n_simd=1024):
+    """MFMA pipe utilisation of the hot kernels from the committed PMC summary (the definition of
+    rocprofv3's derived MfmaUtil): sum SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x SIMDs).
+    GRBM_GUI_ACTIVE is reported summed over the 8 XCDs."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        busy, act, found = 0.0, 0.0, 0
+        for pref in kernel_prefixes:
+            for k, v in d.items():
+                if k.startswith(pref) and 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v:
+                    busy += v['SQ_VALU_MFMA_BUSY_CYCLES']['avg']
+                    act += v['GRBM_GUI_ACTIVE']['avg']
+                    found += 1
+                    break
+        if found == len(kernel_prefixes) and act > 0:
+            best = busy / (act / n_xcd * n_simd)
+    return best
+
+
 def map_wall_clock(S, N, dt):
     """Secondary metric (BASELINE.json "MAP wall-clock"): one
     coord_descent(maxiter=1) sweep of standard_glm on the same spike matrix = all N per-neuron
@@ -321,6 +345,9 @@ def main():
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
+            mb = pmc_mfma_busy(['void k_fused5<20, 1>', 'void k_fused5<20, 2>'])
+            if mb is not None:
+                out["roofline"]["mfma_busy_pmc"] = mb
         if world == 1 and not args.no_map and not args.f32_features:
             out["secondary"] = map_wall_clock(S, N, dt)
         if world == 1 and not args.no_cpu_baseline:
