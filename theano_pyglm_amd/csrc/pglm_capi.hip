@@ -857,8 +857,13 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         const Plan& pl = plans[0];
         int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
-        if (pl.version >= 4 && d_grad)                          // residual slab of the two-pass kernels
-            ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
+        if (pl.version >= 4 && d_grad) {                        // residual slab of the two-pass kernels
+            const size_t need = (size_t)pl.nTiles * pl.nPT * 256 * 8;
+            const bool fresh = need > h->Xbuf.cap || !h->Xbuf.p;
+            ENSURE(h->Xbuf, need);
+            // first touch of a fresh allocation costs ~8 % of an evaluation: pay it here, once
+            if (fresh) HIPCHK(hipMemsetAsync(h->Xbuf.p, 0, need, h->stream));
+        }
         if (pl.version == 5) {
             rc = ensure_feature_images(h, pl.KTW);
             if (rc) return rc;
