@@ -46,7 +46,7 @@ typedef struct pgl_context* pgl_handle;
 #define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
 #define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
 #define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel for >= 65 post-synaptic neurons per call,
-                                * 8-wave K-split kernel otherwise; 1 = 4-wave kernel of the first version;
+                                * 8-wave K-split kernel otherwise;
                                 * 2 = force the K-split kernel; 3 = force the two-pass kernel with
                                 * on-the-fly features; 4 = force the two-pass kernel on resident feature
                                 * tiles.  Auto uses 4's kernel (k_fused5) when the call covers >= 65

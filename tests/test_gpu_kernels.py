@@ -295,22 +295,26 @@ def test_unsupported_shapes_fail_loudly():
     dq.close()
 
 
-def test_legacy_and_f32_kernels_agree():
-    """PGL_OPT_KERNEL=1 (4-wave kernel of the first version) and PGL_OPT_FEATURE_F32 against
-    the default path."""
+def test_f32_feature_kernel_agrees():
+    """PGL_OPT_FEATURE_F32 (f32 feature tile / basis taps in the K-split kernel) against the default
+    f64 path, and the forced two-pass kernels on a population of 3 post tiles."""
     from theano_pyglm_amd import _lib
     p = H.Problem(48, 3000, H.std_ibasis(), seed=21, weighted=True)
     d0 = p.device()
     ll0, g0 = d0.ll_grad(p.theta, p.Weff)
-    d1 = p.device()
-    d1.set_option(_lib.OPT_KERNEL, 1)
-    ll1, g1 = d1.ll_grad(p.theta, p.Weff)
-    assert np.allclose(ll1, ll0, rtol=1e-12) and H.rel_err(g1, g0) < 1e-12
+    assert d0.info()['kernel_version'] == 2
+    for kern in (3, 4):
+        d1 = p.device()
+        d1.set_option(_lib.OPT_KERNEL, kern)
+        ll1, g1 = d1.ll_grad(p.theta, p.Weff)
+        assert np.allclose(ll1, ll0, rtol=1e-12) and H.rel_err(g1, g0) < 1e-12
+        d1.close()
     d2 = p.device(f32=True)
     ll2, g2 = d2.ll_grad(p.theta, p.Weff)
+    assert d2.info()['kernel_version'] == 3
     assert np.allclose(ll2, ll0, rtol=1e-8) and H.rel_err(g2, g0) < 1e-6
-    for d in (d0, d1, d2):
-        d.close()
+    d0.close()
+    d2.close()
 
 
 def test_nonfinite_semantics_match_reference_expression():

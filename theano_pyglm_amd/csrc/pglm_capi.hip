@@ -116,7 +116,6 @@ static std::vector<Slice> make_slices(const pgl_context* h)
     return out;
 }
 
-static const int kKT[] = {2, 4, 10, 13, 20, 40};
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel
 
@@ -134,7 +133,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     // version 1: the 4-wave kernel of the first round (PGL_OPT_KERNEL = 1)
     // version 4: the two-pass kernel (one workgroup = 8 post tiles, no K split; PGL_OPT_KERNEL 0 = auto
     //            for >= 5 post tiles, 3 = force, 2 = force version 2); f64 features, one slice only
-    pl.version = (h->opt_kernel == 1) ? 1 : (pl.f32 ? 3 : 2);
+    pl.version = pl.f32 ? 3 : 2;
     if (pl.version == 2 && single_slice && need >= 2) {
         if (h->opt_kernel == 3) pl.version = 4;
         else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && pl.nPT >= 5)) pl.version = 5;
@@ -160,7 +159,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     } else {
         // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
         // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
-        while (pl.RP % 32 != (pl.version == 1 ? 6 : 8)) ++pl.RP;
+        while (pl.RP % 32 != 8) ++pl.RP;
     }
     pl.cap = PGL_CAP;
     if (pl.version == 4 || pl.version == 5) {
@@ -174,7 +173,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (kth == 0) return fail(PGL_ERR_UNSUPPORTED, "slice exceeds 640 feature columns");
         pl.PTW = 8; pl.KSPLIT = 1; pl.KTW = kth; pl.KT = 2 * kth; pl.wpb = 8;
         pl.nPB = (pl.nPT + 7) / 8;
-    } else if (pl.version >= 2) {
+    } else {
         const int nw = 8;
         const int maxptw = 4;
         pl.PTW = (pl.nPT >= 3) ? 4 : pl.nPT;
@@ -194,19 +193,6 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         pl.KT = pl.KTW * pl.KSPLIT;
         pl.wpb = nw;
         pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
-    } else {
-        pl.PTW = 0; pl.KTW = 0; pl.KSPLIT = 1;
-        pl.wpb = std::min(4, pl.nPT);
-        pl.nPB = (pl.nPT + pl.wpb - 1) / pl.wpb;
-        pl.KT = 0;
-        for (int kt : kKT)
-            if (kt >= need) {
-                pl.KT = kt;
-                break;
-            }
-        if (pl.KT == 0)
-            return fail(PGL_ERR_UNSUPPORTED,
-                        "N*B + Dstim = " + std::to_string(h->Ktot) + " exceeds 640 feature columns");
     }
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
@@ -240,46 +226,14 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }
-    if (pl.version == 1 && pl.f32)
-        off += (((size_t)2 * h->B * pl.RP * 8) + 15) & ~(size_t)15;       // V1 keeps f64 tables
-    else
-        off += (((size_t)2 * h->B * pl.RP * esz) + 15) & ~(size_t)15;
+    off += (((size_t)2 * h->B * pl.RP * esz) + 15) & ~(size_t)15;
     off += (size_t)sl.Ns * pl.cap * 8;
-    if (pl.version >= 2) {
-        off += 2 * ((((size_t)2 * sl.Ns * 4) + 15) & ~(size_t)15);
-        off += (((size_t)sl.Ns * 4) + 15) & ~(size_t)15;                   // ring-valid flags
-        off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8 + 256;
-    } else {
-        off += 2 * ((((size_t)sl.Ns * 4) + 15) & ~(size_t)15);
-    }
+    off += 2 * ((((size_t)2 * sl.Ns * 4) + 15) & ~(size_t)15);
+    off += (((size_t)sl.Ns * 4) + 15) & ~(size_t)15;                       // ring-valid flags
+    off += (size_t)pl.wpb * 256 * 8 + (size_t)pl.PTW * 256 * 8 + 256;
     pl.lds = off;
     if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
     return PGL_OK;
-}
-
-template <int KT, typename FT>
-static hipError_t launch_fused_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
-{
-    auto kern = k_fused_ll_grad<KT, FT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(pl.threads), pl.lds, s, fp);
-    return hipGetLastError();
-}
-
-template <typename FT>
-static hipError_t launch_fused_kt(const Plan& pl, const FusedParams& fp, hipStream_t s)
-{
-    switch (pl.KT) {
-    case 2: return launch_fused_t<2, FT>(pl, fp, s);
-    case 4: return launch_fused_t<4, FT>(pl, fp, s);
-    case 10: return launch_fused_t<10, FT>(pl, fp, s);
-    case 13: return launch_fused_t<13, FT>(pl, fp, s);
-    case 20: return launch_fused_t<20, FT>(pl, fp, s);
-    case 40: return launch_fused_t<40, FT>(pl, fp, s);
-    }
-    return hipErrorInvalidValue;
 }
 
 template <int KTW, int PTW, int NW, int CAP, typename FT>
@@ -781,7 +735,7 @@ static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, 
     const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
     hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
                        (double*)h->Wfrag.p, (double*)h->bias.p, sl.Ns, h->B, sl.Ds, sl.Ns * h->B,
-                       sl.Ns * h->B + sl.Ds, pl.KS, n_lo, pl.npost, pl.nPT, pl.version >= 2 ? 1 : 0,
+                       sl.Ns * h->B + sl.Ds, pl.KS, n_lo, pl.npost, pl.nPT, 1,
                        h->N, sl.np0, h->Dstim, sl.ds0);
     HIPCHK(hipGetLastError());
     return PGL_OK;
@@ -802,9 +756,7 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
 
 static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
-    return (pl.version >= 2) ? launch_fused2(pl, fp, s)
-           : pl.f32          ? launch_fused_kt<float>(pl, fp, s)
-                             : launch_fused_kt<double>(pl, fp, s);
+    return launch_fused2(pl, fp, s);
 }
 
 // Resident feature tiles of the whole recording for half width `kth` k-tiles (k_build_fimg):
@@ -839,8 +791,6 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         if (rc) return rc;
     }
     const bool sliced = slices.size() > 1;
-    if (sliced && plans[0].version < 2)
-        return fail(PGL_ERR_UNSUPPORTED, "PGL_OPT_KERNEL=1 supports N <= 128 and <= 640 feature columns");
     size_t maxG = 0, maxLL = 0;
     for (const Plan& pl : plans) {
         maxG = std::max(maxG, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);

@@ -256,264 +256,7 @@ __device__ __forceinline__ double pgl_softplus_parts(double x, double& sig, doub
 }
 
 // ---------------------------------------------------------------------------
-// Feature generation for one 16-row time tile: F[t][n'*B+b], t in [t0,t0+16).
-// One thread owns a feature column (n',b) and keeps its 16 rows in registers; every
-// event (s,c) of n' in the tile's window adds c*phi_b[t0+t-s-1] to row t.  The basis
-// table is zero-padded by 16 taps on both sides, so no per-row validity test is
-// needed (the window table only admits events with s in [t0-R, t0+14]); an even- and
-// an odd-shifted copy keep every 16-tap slice 16-byte aligned for ds_read_b128.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void gen_accum16(double (&acc)[16], const int2 e, const int t0,
-                                            const double* __restrict__ phiE,
-                                            const double* __restrict__ phiO, const int boff)
-{
-    const int base = t0 - e.x - 1 + 16;               // padded index of row 0's lag, >= 1
-    const double c = (double)e.y;
-    const double* tab = (base & 1) ? (phiO + boff + base - 1) : (phiE + boff + base);
-    const double2* t2 = reinterpret_cast<const double2*>(tab);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const double2 v = t2[q];
-        acc[2 * q] = fma(c, v.x, acc[2 * q]);
-        acc[2 * q + 1] = fma(c, v.y, acc[2 * q + 1]);
-    }
-}
-
-template <typename FT>
-__device__ __forceinline__ void gen_cols(FT* __restrict__ Fs, const int rsf,
-                                         const double* __restrict__ phiE,
-                                         const double* __restrict__ phiO, const int RP,
-                                         const int2* __restrict__ s_spk,
-                                         const int* __restrict__ s_lo,
-                                         const int* __restrict__ s_cnt,
-                                         const int2* __restrict__ spk, const int t0, const int B,
-                                         const int Kimp, const int tid, const int nthr)
-{
-    for (int col = tid; col < Kimp; col += nthr) {
-        const int np = col / B;
-        const int b = col - np * B;
-        const int cnt = s_cnt[np];
-        const int boff = b * RP;
-        double acc[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.0;
-        // two events per trip (the second is a zero-weight dummy when cnt is odd) so that
-        // 16 independent ds_read_b128 are in flight before the FMAs
-        const int2 dummy = make_int2(t0, 0);
-        if (cnt <= PGL_CAP) {
-            const int2* sp = s_spk + np * PGL_CAP;
-            for (int j = 0; j < cnt; j += 2) {
-                const int2 e0 = sp[j];
-                const int2 e1 = (j + 1 < cnt) ? sp[j + 1] : dummy;
-                gen_accum16(acc, e0, t0, phiE, phiO, boff);
-                gen_accum16(acc, e1, t0, phiE, phiO, boff);
-            }
-        } else {
-            const int2* sp = spk + s_lo[np];
-            for (int j = 0; j < cnt; ++j) gen_accum16(acc, sp[j], t0, phiE, phiO, boff);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) Fs[t * rsf + col] = (FT)acc[t];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The fused ll + grad kernel.  One wave = one 16-wide post-synaptic tile.
-// ---------------------------------------------------------------------------
-template <int KT, typename FT>
-__global__ __launch_bounds__(256, 1) void k_fused_ll_grad(const FusedParams p)
-{
-    constexpr int TT = 16;
-    constexpr int KS = KT * 4;            // k-steps of 4 in the forward pass
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
-    const int wpb = nthr >> 6;
-    const int nPB = (p.nPT + wpb - 1) / wpb;
-    const int pb = blockIdx.x % nPB;
-    const int chunk = blockIdx.x / nPB;
-    const int pt = pb * wpb + wave;
-    const bool active = pt < p.nPT;
-
-    const int N = p.N, B = p.B, R = p.R, rsf = p.rsf;
-    // LDS carve (all offsets multiples of 16)
-    FT* Fs = reinterpret_cast<FT*>(smem);
-    size_t off = ((size_t)TT * rsf * sizeof(FT) + 15) & ~(size_t)15;
-    const int RP = p.RP;
-    double* phiE = reinterpret_cast<double*>(smem + off);
-    double* phiO = phiE + (size_t)B * RP;
-    off += (((size_t)2 * B * RP * 8) + 15) & ~(size_t)15;
-    int2* s_spk = reinterpret_cast<int2*>(smem + off);
-    off += (size_t)N * PGL_CAP * 8;
-    int* s_lo = reinterpret_cast<int*>(smem + off);
-    off += (((size_t)N * 4) + 15) & ~(size_t)15;
-    int* s_cnt = reinterpret_cast<int*>(smem + off);
-
-    // one-time: basis table, zero the F tile (padding columns stay zero forever)
-    for (int i = tid; i < B * RP; i += nthr) {
-        const int b = i / RP, k = i - b * RP;
-        phiE[i] = (k >= 16 && k < 16 + R) ? p.phi[b * R + k - 16] : 0.0;
-        phiO[i] = (k + 1 >= 16 && k + 1 < 16 + R) ? p.phi[b * R + k + 1 - 16] : 0.0;
-    }
-    for (int i = tid; i < TT * rsf; i += nthr) Fs[i] = (FT)0;
-
-    d4_t G[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    double ll_acc = 0.0, gb_acc = 0.0;
-
-    const int col = lane & 15;
-    const int grp = lane >> 4;
-    const int nloc = pt * 16 + col;                     // neuron index inside [n_lo,n_hi)
-    const bool valid_n = active && (nloc < p.npost);
-    const int nglob = p.n_lo + (valid_n ? nloc : 0);
-    const double bias_l = valid_n ? p.bias[nloc] : 0.0;
-    // wave-uniform base (SGPR pair) + lane offset: global_load saddr form, no per-step VGPR addresses
-    const double* __restrict__ wrow = p.Wfrag + ((size_t)(active ? pt : 0) * KS) * 64;
-
-    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
-    int tile_end = tile_beg + p.tilesPerChunk;
-    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
-
-    __syncthreads();
-
-    for (int tile = tile_beg; tile < tile_end; ++tile) {
-        const int t0 = tile * TT;
-        // ---- phase A: event window of every presynaptic neuron, staged to LDS ----
-        if (tid < N && !(p.dbg & 32)) {
-            const int lo = p.wlo[(size_t)tile * N + tid];
-            const int hi = p.whi[(size_t)tile * N + tid];
-            s_lo[tid] = lo;
-            s_cnt[tid] = hi - lo;
-        }
-        __syncthreads();
-        if (!(p.dbg & 2))
-        for (int id = tid; id < N * PGL_CAP; id += nthr) {
-            const int np = id / PGL_CAP;
-            const int sl = id % PGL_CAP;
-            const int cnt = s_cnt[np];
-            if (cnt <= PGL_CAP && sl < cnt) s_spk[id] = p.spk[s_lo[np] + sl];
-        }
-        // dense stimulus feature columns
-        if (p.Dstim > 0) {
-            for (int id = tid; id < TT * p.Dstim; id += nthr) {
-                const int t = id / p.Dstim;
-                const int j = id % p.Dstim;
-                const long long tg = (long long)t0 + t;
-                Fs[t * rsf + p.Kimp + j] = (FT)((tg < p.nT) ? p.fstim[tg * p.Dstim + j] : 0.0);
-            }
-        }
-        __syncthreads();
-        // ---- phase B: F tile from events ----
-        if (!(p.dbg & 1))
-            gen_cols<FT>(Fs, rsf, phiE, phiO, RP, s_spk, s_lo, s_cnt, p.spk, t0, B, p.Kimp, tid, nthr);
-        __syncthreads();
-
-        if (active) {
-            // post-synaptic counts for the epilogue (issued early, used after the MFMAs)
-            double sc[4];
-            bool vt[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long tg = (long long)t0 + grp + 4 * r;
-                vt[r] = valid_n && (tg < p.t_hi);
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);      // clamped: branch-free load
-                sc[r] = (double)p.S[tc * N + nglob];
-            }
-            // ---- forward: X(16x16) = F(16xK) . Wmat(Kx16) ----
-            // Flat list of KS MFMAs.  The Wmat fragments (L2 -> VGPR) are fetched PW steps
-            // ahead and the F fragments (LDS -> VGPR) PA steps ahead through register rings
-            // whose indices are static after unrolling; two accumulators break the
-            // dependent-accumulate chain.
-            d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
-            d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-            {
-                const FT* fa = Fs + col * rsf + grp;  // A[i=t=lane&15][k=lane>>4]
-                // opaque SGPR copy of the wave-uniform fragment base: keeps the compiler from
-                // hoisting 160 per-step VGPR addresses out of the tile loop (they spill) and
-                // selects the saddr form  global_load_dwordx2 v, v_lane8, s[base] offset:imm
-                const double* wr_s = wrow;
-                asm volatile("" : "+s"(wr_s));
-                constexpr int PW = (KS < 12) ? KS : 12;
-                constexpr int PA = 4;
-                double wr[PW], ar[PA];
-#pragma unroll
-                for (int s = 0; s < PW; ++s) wr[s] = wr_s[s * 64 + lane];
-#pragma unroll
-                for (int s = 0; s < PA; ++s) ar[s] = (double)fa[4 * s];
-                if (!(p.dbg & 8))
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const double a = ar[s % PA];
-                    const double b = wr[s % PW];
-                    if (s + PA < KS) ar[s % PA] = (double)fa[4 * (s + PA)];
-                    if (s + PW < KS) wr[s % PW] = wr_s[(s + PW) * 64 + lane];
-                    if (s & 1)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
-                    else
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
-                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // ---- epilogue: x -> (ll, r).  D layout: row t = grp + 4r, col = lane&15 ----
-            double rr[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double x = acc0[r] + acc1[r] + bias_l;
-                double term, res;
-                if (p.dbg & 4) {
-                    term = x * sc[r];
-                    res = x - sc[r];
-                } else {
-                    pgl_rate_terms(x, sc[r], p.nlin, p.dt, term, res, PGL_C);
-                }
-                ll_acc += vt[r] ? term : 0.0;
-                rr[r] = vt[r] ? res : 0.0;
-                gb_acc += rr[r];
-            }
-            // ---- backward: G(Kx16) += F^T(Kx16) . r(16x16);  B operand of k-step j is rr[j] ----
-            // Flat list of 4*KT MFMAs (step s: time k-step j = s / KT, feature tile kt = s % KT),
-            // F^T fragments fetched from LDS PD steps ahead.
-            if (p.want_grad && !(p.dbg & 16)) {
-                const FT* fb = Fs + grp * rsf + col;  // A[i=k=lane&15][kk=lane>>4] = F[4j+kk][16kt+i]
-                constexpr int PD = 4;
-                constexpr int NS = 4 * KT;
-                double ar[PD];
-#pragma unroll
-                for (int s = 0; s < PD; ++s) ar[s] = (double)fb[(4 * (s / KT)) * rsf + 16 * (s % KT)];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double a = ar[s % PD];
-                    if (s + PD < NS)
-                        ar[s % PD] = (double)fb[(4 * ((s + PD) / KT)) * rsf + 16 * ((s + PD) % KT)];
-                    G[s % KT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KT], G[s % KT], 0, 0, 0);
-                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    if (active) {
-        const size_t slot = (size_t)chunk * p.nPT + pt;
-        p.llpart[slot * 64 + lane] = ll_acc;
-        p.gbpart[slot * 64 + lane] = gb_acc;
-        if (p.want_grad) {
-            double* gp = p.Gpart + slot * (size_t)KT * 256 + lane;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Feature generation, version 2 kernel: work item = (feature column, block of ROWS rows)
+// Feature generation (on-the-fly kernels): work item = (feature column, block of ROWS rows)
 // so that all 512 threads are busy (640 columns x 4 row blocks = 5 items per thread at C3)
 // and a wave spans few presynaptic neurons (less trip-count divergence).  Events are
 // staged in LDS already decoded for this tile: {byte offset of row 0's 16-tap slice in the
