@@ -1,0 +1,84 @@
+// Forward-pass MFMA loop of k_fused5 in isolation (dev tool): per 16-bin tile 160 MFMAs per wave,
+// A fragments from two LDS half tiles, B = Wmat fragments streamed from global memory (L2) through
+// the same register rings; NACC independent accumulators.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) d2* g_cd2p;
+
+template <int NACC, int PW>
+__global__ __launch_bounds__(512, 2) void k(const double* W, double* out, int tiles, double seed)
+{
+    constexpr int KTH = 20, RSH = 322, KSH = 80, KS_ALL = 160;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* F = reinterpret_cast<double*>(smem);
+    for (int i = threadIdx.x; i < 2 * 16 * RSH; i += 512) F[i] = seed + 1e-9 * i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+    const double* faL = F + col * RSH + grp;
+    const double* faH = F + 16 * RSH + col * RSH + grp;
+    const double* wrow = W + (size_t)wave * KS_ALL * 64;
+    d4 acc[NACC];
+    double tot = 0;
+    for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+        const double* wr_s = wrow;
+        asm volatile("" : "+s"(wr_s));
+        constexpr int PW2 = PW / 2, PA = 4;
+        const g_cd2p wr2 = (g_cd2p)wr_s;
+        d2 wr[PW2];
+        double ar[PA];
+#pragma unroll
+        for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < PA; ++s) ar[s] = faL[4 * s];
+#pragma unroll
+        for (int s = 0; s < KS_ALL; ++s) {
+            const double a = ar[s % PA];
+            const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
+            if (s + PA < KS_ALL) ar[s % PA] = (s + PA < KSH) ? faL[4 * (s + PA)] : faH[4 * (s + PA - KSH)];
+            if ((s & 1) && (s / 2 + PW2 < KS_ALL / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
+            acc[s % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s % NACC], 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) tot += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = tot;
+}
+
+template <int NACC, int PW>
+void run(const char* name, const double* W, double* d)
+{
+    const int blocks = 256, tiles = 1000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const size_t lds = 2 * 16 * 322 * 8;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k<NACC, PW>), dim3(blocks), dim3(512), lds, 0, W, d, tiles, 1.0);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double fl = (double)blocks * 8 * tiles * 160 * 2048.0;
+        if (rep == 2) printf("%-40s %8.3f ms  %6.1f TFLOP/s\n", name, ms, fl / ms / 1e9);
+    }
+}
+
+int main()
+{
+    double *W, *d;
+    (void)hipMalloc(&W, 8 * 160 * 64 * 8);
+    (void)hipMemset(W, 0, 8 * 160 * 64 * 8);
+    (void)hipMalloc(&d, sizeof(double) * 256 * 512);
+    run<2, 8>("2 accumulators, W ring 8", W, d);
+    run<4, 8>("4 accumulators, W ring 8", W, d);
+    run<2, 16>("2 accumulators, W ring 16", W, d);
+    run<4, 16>("4 accumulators, W ring 16", W, d);
+    return 0;
+}
