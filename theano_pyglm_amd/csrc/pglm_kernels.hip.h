@@ -1300,6 +1300,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 0) * IMG, buf0, wave, lane);
             pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 1) * IMG, buf1, wave, lane);
         }
+        // spike counts of this lane's four elements (rows grp + 4r of neuron nglob): requested one tile
+        // ahead, together with the DMAs -- issued at the head of a tile these byte loads (HBM misses)
+        // sit in front of the Wmat ring in the in-order vmcnt queue and delay every forward pass
+        unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
+        auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long tg = (long long)tile * TT + grp + 4 * r;
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+                dst[r] = p.S[tc * p.Nall + nglob];
+            }
+        };
+        if (tile_beg < tile_end) load_counts(tile_beg, scn);
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
         __syncthreads();
         for (int tile = tile_beg; tile < tile_end; ++tile) {
@@ -1307,13 +1320,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             const int par = (tile - tile_beg) & 1;
             const unsigned char* Lb = par ? buf2 : buf0;     // L alternates buf0 / buf2, H lives in buf1
             unsigned char* Ln = par ? buf0 : buf2;
-            unsigned scb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long tg = (long long)t0 + grp + 4 * r;
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                scb[r] = p.S[tc * p.Nall + nglob];
-            }
+            for (int r = 0; r < 4; ++r) scb[r] = scn[r];
             // ---- forward over both halves ----
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -1345,14 +1353,11 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // the spike counts are consumed here, before the DMAs are issued: behind an LDS-DMA in
-            // flight the compiler's wait for an earlier ordinary load is vmcnt(0) and would drain it
-#pragma unroll
-            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(scb[r]));
             __syncthreads();                              // every wave is done with H_i (buf1)
             if (tile + 1 < tile_end) {                    // tile+1 arrives under epilogue + backward
                 pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln, wave, lane);
                 pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, wave, lane);
+                load_counts(tile + 1, scn);               // retired by the closing vmcnt(0) of this tile
             }
             // ---- epilogue on the accumulator registers, two elements at a time ----
             double rr[4];
