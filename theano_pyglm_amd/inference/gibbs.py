@@ -117,10 +117,50 @@ class _HmcBlockUpdate(object):
         return self.update_range(x, 0, self.population.N)
 
 
+def _single_handle(population):
+    """(handle, data) when the population holds exactly one data sequence, else (None, None)."""
+    if len(population.data_sequences) != 1:
+        return None, None
+    data = population.data_sequences[0]
+    population.set_data(data)
+    return population._handle(data), data
+
+
 class HmcBiasUpdate(_HmcBlockUpdate):
-    """gibbs.py:164-322: 10 leapfrog steps on the bias."""
+    """gibbs.py:164-322: 10 leapfrog steps on the bias.
+
+    Fast path (one data sequence): the flat feature-weight matrix is built once per update and only
+    its bias column changes between leapfrog steps; the prior -0.5/sigma^2 (b-mu)^2 (bias.py:33) and
+    its derivative are two numpy expressions.  Same energies as the generic path, without packing
+    128 state dicts per evaluation."""
     key = 'bias'
     n_steps = 10
+
+    def update_range(self, x, n_lo, n_hi):
+        pop = self.population
+        h, _ = _single_handle(pop)
+        if h is None:
+            return _HmcBlockUpdate.update_range(self, x, n_lo, n_hi)
+        glms = x['glms']
+        theta = pop.theta_matrix(x, n_lo, n_hi)
+        Weff = pop.W_eff(x)
+        mu, sg = float(self.glm.bias_model.mu_bias), float(self.glm.bias_model.sig_bias)
+
+        def UG(Q):
+            theta[:, 0] = Q[:, 0]
+            ll, g = h.ll_grad(theta, Weff, n_lo, n_hi)
+            self.n_evals += 1
+            lp = ll - 0.5 / sg ** 2 * (Q[:, 0] - mu) ** 2
+            dlp = g[:, 0] - (Q[:, 0] - mu) / sg ** 2
+            U = np.where(np.isfinite(lp), -lp, np.inf)
+            return U, -np.nan_to_num(dlp, nan=0.0, posinf=0.0, neginf=0.0)[:, None]
+
+        Q0 = theta[:, :1].copy()
+        Q1, acc, _ = hmc_lockstep(UG, self.step_sz, self.n_steps, Q0, rng=self.rng)
+        for i, n in enumerate(range(n_lo, n_hi)):
+            glms[n]['bias']['bias'] = Q1[i].copy()
+        self._adapt(acc)
+        return x
 
 
 class HmcBkgdUpdate(_HmcBlockUpdate):
@@ -152,23 +192,54 @@ class HmcDirichletImpulseUpdate(_HmcBlockUpdate):
         for n, e in zip(posts, edges):                              # gibbs.py:765-769
             for n_pre in np.setdiff1d(np.arange(N), e):
                 glms[n]['imp']['g_%d' % n_pre] = self.rng.gamma(imp.alpha, np.ones(imp.B))
+        h, _ = _single_handle(self.population)
+        fast = h is not None
+        if fast:
+            theta = self.population.theta_matrix(x, n_lo, n_hi)      # after the prior redraws above
+            Weff = self.population.W_eff(x)
+            D = self.glm.Dstim
         for r in range(max([len(e) for e in edges] + [0])):
             active = np.array([r < len(e) for e in edges])
             pre = [int(e[r]) if r < len(e) else 0 for e in edges]
             names = ['g_%d' % k for k in pre]
-            cols = [self.block_cols[(nm,)] for nm in names]
             Q0 = np.array([np.asarray(glms[n]['imp'][nm], dtype=float) for n, nm in zip(posts, names)])
+            if fast:
+                # only the B flat weights beta = |g|/sum|g| of (n_pre -> n_post) change: update that
+                # block of the resident theta matrix, chain the device gradient through the
+                # normalisation (impulse.py:286-291) and add the Gamma prior (impulse.py:320-322)
+                c0 = np.array([1 + D + k * imp.B for k in pre])
+                rows = np.arange(len(posts))[:, None]
+                colsb = c0[:, None] + np.arange(imp.B)[None, :]
 
-            def UG(Q):
-                for i, n in enumerate(posts):
-                    if active[i]:
-                        glms[n]['imp'][names[i]] = Q[i].copy()
-                U, G = self._neg_lp_grad(x, n_lo, n_hi)
-                return U, np.array([G[i, c[0]:c[1]] for i, c in enumerate(cols)])
+                def UG(Q):
+                    ga = np.abs(Q)
+                    sm = ga.sum(axis=1, keepdims=True)
+                    theta[rows, colsb] = np.where(active[:, None], ga / sm, theta[rows, colsb])
+                    ll, g = h.ll_grad(theta, Weff, n_lo, n_hi)
+                    self.n_evals += 1
+                    gb = g[rows, colsb]
+                    dg = np.sign(Q) * (gb * sm - np.sum(gb * ga, axis=1, keepdims=True)) / sm ** 2
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        lp = ll + np.sum((imp.alpha - 1.0) * np.log(ga) - ga, axis=1)
+                        dlp = dg + (imp.alpha - 1.0) / Q - np.sign(Q)
+                    U = np.where(np.isfinite(lp), -lp, np.inf)
+                    return U, -np.nan_to_num(dlp, nan=0.0, posinf=0.0, neginf=0.0)
+            else:
+                cols = [self.block_cols[(nm,)] for nm in names]
+
+                def UG(Q):
+                    for i, n in enumerate(posts):
+                        if active[i]:
+                            glms[n]['imp'][names[i]] = Q[i].copy()
+                    U, G = self._neg_lp_grad(x, n_lo, n_hi)
+                    return U, np.array([G[i, c[0]:c[1]] for i, c in enumerate(cols)])
 
             Q1, acc, _ = hmc_lockstep(UG, self.step_sz, self.n_steps, Q0, active=active, rng=self.rng)
             for i, n in enumerate(posts):
                 glms[n]['imp'][names[i]] = Q1[i].copy()
+            if fast:                                  # leave theta at the accepted state
+                ga = np.abs(Q1)
+                theta[rows, colsb] = ga / ga.sum(axis=1, keepdims=True)
             self._adapt(acc[active])
         return x
 
@@ -269,7 +340,8 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         return x
 
     def update(self, x, n_post):
-        """gibbs.py:1229-1250 with the device-resident inner loop: resample column n_post."""
+        """gibbs.py:1229-1250 with the device-resident inner loop: resample column n_post.
+        The per-pair host work is kept to scalar arithmetic (16 384 pairs per sweep at N = 128)."""
         pop = self.population
         N = pop.N
         if len(pop.data_sequences) != 1:
@@ -280,24 +352,38 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         W = np.asarray(x['net']['weights']['W'], dtype=float).reshape(N, N)
         xn = x['glms'][n_post]
         h.gibbs_prepare(n_post, self.glm.theta_row(xn), (A * W)[:, n_post])
-        p_A = self.network.graph.pA
+        with np.errstate(divide='ignore'):
+            log_pA = np.log(np.asarray(self.network.graph.pA, dtype=float)[:, n_post])
+            log_pnA = np.log(1.0 - np.asarray(self.network.graph.pA, dtype=float)[:, n_post])
+        log_gh = np.log(self.GAUSS_HERMITE_WEIGHTS / np.sqrt(np.pi))
+        # quadrature nodes + the w = 0 probe, for off-diagonal and refractory (diagonal) priors
+        nodes = {}
+        for key, (m, sg) in (('off', (self.mu_w, self.sigma_w)), ('ref', (self.mu_w_ref, self.sigma_w_ref))):
+            W_nns = np.sqrt(2) * sg * self.GAUSS_HERMITE_ABSCISSAE + m                  # gibbs.py:1004
+            nodes[key] = (m, sg, W_nns, np.concatenate((W_nns, [0.0])))
+        rnd = self.rng.random_sample
         stats = []
         for n_pre in self.rng.permutation(N):
-            mu_w, sigma_w = (self.mu_w_ref, self.sigma_w_ref) if n_pre == n_post \
-                else (self.mu_w, self.sigma_w)
+            mu_w, sigma_w, W_nns, probes = nodes['ref' if n_pre == n_post else 'off']
             aw_cur = float(A[n_pre, n_post] * W[n_pre, n_post])
-            W_nns = np.sqrt(2) * sigma_w * self.GAUSS_HERMITE_ABSCISSAE + mu_w      # gibbs.py:1004
-            ll = h.gibbs_ll(n_pre, aw_cur, np.concatenate((W_nns, [0.0])))
-            log_L, ll_noA = ll[:-1], ll[-1]
-            log_G = self._marginal(log_L)
-            if not np.isfinite(log_G):
+            ll = h.gibbs_ll(n_pre, aw_cur, probes)
+            log_L, ll_noA = ll[:-1], float(ll[-1])
+            wl = log_L + log_gh                                      # gibbs.py:1015-1022
+            wl[np.isnan(wl)] = -np.inf
+            mx = wl.max()
+            if not np.isfinite(mx):
                 raise Exception("log_G not finie")
-            with np.errstate(divide='ignore'):
-                log_pr_A = np.log(p_A[n_pre, n_post]) + log_G
-                log_pr_noA = np.log(1.0 - p_A[n_pre, n_post]) + ll_noA
-            if np.isnan(log_pr_noA):
+            log_G = float(mx + np.log(np.exp(wl - mx).sum()))
+            log_pr_A = log_pA[n_pre] + log_G
+            log_pr_noA = log_pnA[n_pre] + ll_noA
+            if log_pr_noA != log_pr_noA:                             # NaN (lam underflow at w = 0)
                 log_pr_noA = -np.inf
-            a_new = log_sum_exp_sample([log_pr_noA, log_pr_A], self.rng)           # gibbs.py:1041
+            # log_sum_exp_sample over {no edge, edge} (gibbs.py:1041, log_sum_exp.py:4-37)
+            m2 = max(log_pr_noA, log_pr_A)
+            if not np.isfinite(m2):
+                raise Exception("log_sum_exp_sample: no finite entry")
+            p0 = np.exp(log_pr_noA - m2)
+            a_new = 0 if rnd() * (p0 + np.exp(log_pr_A - m2)) < p0 else 1
             if a_new == 1 and self.w_sampler == 'ars':
                 w_new = self._adaptive_rejection_sample_w(h, n_pre, aw_cur, mu_w, sigma_w, W_nns, log_L)
             elif a_new == 1:
@@ -309,7 +395,7 @@ class CollapsedGibbsNetworkColumnUpdate(object):
             h.gibbs_update(n_pre, a_new * w_new - aw_cur)
             A[n_pre, n_post] = a_new
             W[n_pre, n_post] = w_new
-            stats.append((int(n_pre), float(log_G), float(ll_noA)))
+            stats.append((int(n_pre), log_G, ll_noA))
         x['net']['graph']['A'] = A
         x['net']['weights']['W'] = W.ravel()
         return stats
