@@ -49,6 +49,7 @@ struct pgl_context {
     int Rk = 0;                          // taps the kernels use: R minus trailing all-zero basis rows
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
     DevBuf fimg;                         // resident feature tiles (k_fused5)
+    double* pin_out = nullptr;           // pinned host buffer for small results (PGL_KMAX doubles)
     int fimg_kth = 0;                    // half width (k-tiles) the images were built for; 0 = stale
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
@@ -408,6 +409,7 @@ int pgl_destroy(pgl_handle h)
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
             if (h->evr[s][i]) (void)hipEventDestroy(h->evr[s][i]);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PGL_OK;
@@ -1095,24 +1097,29 @@ static int run_ll_current(pgl_handle h, const double* d_base, const double* d_st
     const int sblocks = std::max(1, std::min(256, (e_hi - e_lo + 255) / 256));
     ENSURE(h->part, (size_t)(nblocks + sblocks) * PGL_KMAX * 8);
     ENSURE(h->outK, PGL_KMAX * 8);
-    ENSURE(h->wsmall, std::max<size_t>((size_t)h->Kimp, PGL_KMAX) * 8);
+    if (!h->pin_out) HIPCHK(hipHostMalloc((void**)&h->pin_out, PGL_KMAX * 8, hipHostMallocDefault));
     for (int k0 = 0; k0 < K; k0 += PGL_KMAX) {
         const int kk = std::min(PGL_KMAX, K - k0);
-        HIPCHK(hipMemcpyAsync(h->wsmall.p, w + k0, (size_t)kk * 8, hipMemcpyHostToDevice, h->stream));
+        PglWeights wv;
+        for (int k = 0; k < PGL_KMAX; ++k) wv.w[k] = (k < kk) ? w[k0 + k] : 0.0;
         hipLaunchKernelGGL(k_ll_current, dim3(nblocks), dim3(256), 0, h->stream, d_base, d_stim,
-                           d_col, bias, aw_cur, (const double*)h->wsmall.p, kk, h->nlin, h->dt,
+                           d_col, bias, aw_cur, wv, kk, h->nlin, h->dt,
                            (long long)h->nT, (double*)h->part.p);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_ll_current_spikes, dim3(sblocks), dim3(256), 0, h->stream,
                            (const int2*)h->spk.p, e_lo, e_hi, d_base, d_stim, d_col, bias, aw_cur,
-                           (const double*)h->wsmall.p, kk, h->nlin,
+                           wv, kk, h->nlin,
                            (double*)h->part.p + (size_t)nblocks * PGL_KMAX);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_reduce_parts, dim3(kk), dim3(64), 0, h->stream, (const double*)h->part.p,
                            nblocks + sblocks, kk, (double*)h->outK.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ll_out + k0, h->outK.p, (size_t)kk * 8, hipMemcpyDeviceToHost, h->stream));
+        // results through a pinned buffer: a pageable destination makes the copy a staged, slower one
+        // (a single launch with a last-ticket reduction into host memory measured the same 56 us:
+        // its agent-scope fences cost what the two launches do)
+        HIPCHK(hipMemcpyAsync(h->pin_out, h->outK.p, (size_t)kk * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        std::memcpy(ll_out + k0, h->pin_out, (size_t)kk * 8);
     }
     return PGL_OK;
 }

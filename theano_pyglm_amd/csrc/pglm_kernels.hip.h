@@ -1751,10 +1751,15 @@ __device__ __forceinline__ double pgl_lambda_only(const double x, const int nlin
     return fmax(x, 0.0) + l1p;
 }
 
+// candidate weights travel as a kernel argument (<= 16 doubles): no host-to-device copy per batch
+struct PglWeights {
+    double w[PGL_KMAX];
+};
+
 __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ base,
                                                     const double* __restrict__ stim,
                                                     const double* __restrict__ colv, double bias,
-                                                    double aw_cur, const double* __restrict__ w,
+                                                    double aw_cur, const PglWeights wv,
                                                     int K, int nlin, double dt, long long nT,
                                                     double* __restrict__ part)
 {
@@ -1762,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ b
     double wk[PGL_KMAX], acc[PGL_KMAX];
 #pragma unroll
     for (int k = 0; k < PGL_KMAX; ++k) {
-        wk[k] = (k < K) ? w[k] : 0.0;
+        wk[k] = (k < K) ? wv.w[k] : 0.0;
         acc[k] = 0.0;
     }
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nT;
@@ -1798,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_ll_current_spikes(const int2* __restric
                                                            const double* __restrict__ stim,
                                                            const double* __restrict__ colv,
                                                            double bias, double aw_cur,
-                                                           const double* __restrict__ w, int K,
+                                                           const PglWeights wv, int K,
                                                            int nlin, double* __restrict__ part)
 {
     __shared__ double red[4][PGL_KMAX];
@@ -1812,7 +1817,7 @@ __global__ __launch_bounds__(256) void k_ll_current_spikes(const int2* __restric
         const double x0 = bias + (stim ? stim[t] : 0.0) + base[t] - aw_cur * c;
         const double s = (double)e.y;
         for (int k = 0; k < K; ++k) {
-            const double x = fma(w[k], c, x0);
+            const double x = fma(wv.w[k], c, x0);
             const double loglam = (nlin == 1) ? pgl_log(pgl_lambda_only(x, nlin, PGL_C), PGL_C) : x;
             acc[k] = fma(s, loglam, acc[k]);
         }
