@@ -158,8 +158,8 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
     } else {
-        // bank spread of the per-basis table rows for ds_read_b128: V2 (row-interleaved items)
-        // wants rows 4 slots (64 B) apart, V1 (whole-column items) 3 slots
+        // bank spread of the per-basis table rows for ds_read_b128: the row-interleaved items of
+        // gen_items want the rows of b = 0..3 four 16-byte slots (64 B) apart
         while (pl.RP % 32 != 8) ++pl.RP;
     }
     pl.cap = PGL_CAP;

@@ -7,14 +7,17 @@
 //   likelihood ll_n = sum_t ( -dt*lam + log(lam)*S[t,n] ),  lam = nlin(x)   pyglm/glm.py:52, nlin.py:25,43
 //   gradient   T.grad(glm.ll, [bias, w_stim, w_ir])                        pyglm/inference/coord_descent.py:27-30
 //
-// Design: the feature matrix F (nT x K, K = N*B + Dstim) is never
-// materialised in HBM.  A workgroup walks a chunk of 16-row time tiles; for each
-// tile it rebuilds the F tile in LDS from the sparse spike-event list (CSR per
-// presynaptic neuron) and the LDS-resident basis table, then every wave (one 16-wide
-// post-synaptic tile each) runs  X = F.Wmat  with v_mfma_f64_16x16x4_f64, turns X
-// into (ll, r = dll/dx) in registers, and immediately accumulates  G += F^T.r  with a
-// second MFMA pass whose B operand IS the forward accumulator layout (no shuffle).
-// G (K x 16 per wave) stays in registers for the whole chunk.
+// Design.  The likelihood and its gradient are two dense contractions around an
+// elementwise rate epilogue:  X = F.Wmat  (forward), r = dll/dx, G += F^T.r  (backward), all on
+// v_mfma_f64_16x16x4_f64; the forward accumulator layout IS the B-operand layout of the backward
+// MFMA, so r never leaves its registers in between.  Work is cut into 16-row time tiles; a
+// workgroup walks a chunk of tiles with G in registers.  Three kernel families share that scheme:
+//   k_build_fimg + k_fused5  F resident in HBM as LDS-shaped tiles (built once per data set, like the
+//                            reference's data['fS']) and streamed with LDS-DMA; two passes over the
+//                            chunk because G of 128 post neurons (655 KB) exceeds one CU's registers
+//   k_fused3                 the same two passes, F tile regenerated in LDS from the spike events
+//   k_fused2                 one pass, post tiles x K slices across the 8 waves (small post blocks,
+//                            the sliced path for N > 128, optional f32 feature tile)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,17 +25,11 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 #define PGL_CAP 16          // staged spike events per presynaptic neuron and tile
-#ifndef PGL_GEN_ROWS
-#define PGL_GEN_ROWS 4       // rows per feature-generation work item (V2 kernel)
-#endif
-#ifndef PGL_GEN_NIG
-#define PGL_GEN_NIG 1        // work items a thread advances in lock-step (A/B: >1 only adds register pressure; the loop is LDS-bandwidth bound)
-#endif
 #ifndef PGL_PD
-#define PGL_PD 4             // F^T fragment prefetch depth (MFMA steps) in the V2 backward pass
+#define PGL_PD 4             // F^T fragment prefetch depth (MFMA steps) of the backward passes
 #endif
 #ifndef PGL_PW
-#define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) in the V2 forward pass
+#define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) of the forward passes
 #endif
 #define PGL_MAXB 8
 
@@ -55,7 +52,7 @@ struct FusedParams {
     int n_lo, npost, nPT;
     int nT16, tilesPerChunk, nChunks, nTiles;
     int rsf;                             // F row stride in elements
-    int RP;                              // padded basis-table length (>= R+32, RP % 32 == 6)
+    int RP;                              // padded basis-table length (>= R+32, RP % 32 == 8)
     double* __restrict__ Gpart;          // [nChunks][nPT][KT][4][64]
     double* __restrict__ llpart;         // [nChunks][nPT][64]
     double* __restrict__ gbpart;         // [nChunks][nPT][64]
