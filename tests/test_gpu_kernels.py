@@ -417,3 +417,23 @@ def test_two_pass_kernel_shapes_and_agreement():
     assert np.allclose(lla, llb, rtol=1e-12) and H.rel_err(ga, gb) < 1e-12
     d3.close()
     d2.close()
+
+
+def test_forced_kernels_on_tiny_shapes():
+    """Forcing the two-pass kernels on tiny problems (one k-tile per half, a single time tile, one
+    neuron) must either run correctly or fall back to the K-split kernel -- never misbehave."""
+    from theano_pyglm_amd import _lib
+    for p in (H.Problem(4, 300, H.std_ibasis(), seed=90),             # K = 20: halves of one k-tile
+              H.Problem(1, 40, H.std_ibasis(), seed=91, rate_hz=100.0),    # K = 5: stays on the K-split kernel
+              H.Problem(7, 16, H.std_ibasis(), seed=92, rate_hz=200.0),    # exactly one time tile
+              H.Problem(33, 17, H.st_ibasis(), kind='exp', Dstim=2, seed=93, rate_hz=100.0, w_scale=0.01)):
+        ll0, g0 = p.oracle_ll_grad()
+        for kern in (2, 3, 4):
+            d = p.device()
+            d.set_option(_lib.OPT_KERNEL, kern)
+            ll, g = d.ll_grad(p.theta, p.Weff)
+            assert np.allclose(ll, ll0, rtol=LL_RTOL, atol=1e-12), (kern, p.N)
+            assert H.rel_err(g, g0) < G_RTOL, (kern, p.N)
+            ll2, _ = d.ll_grad(p.theta, p.Weff, want_grad=False)
+            assert np.array_equal(ll, ll2)
+            d.close()
