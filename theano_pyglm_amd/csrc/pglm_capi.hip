@@ -744,14 +744,15 @@ static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, 
 }
 
 static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
-                                const double* d_Weff, double* d_ll, double* d_grad)
+                                const double* d_Weff, double* d_ll, double* d_grad, bool with_ll = false)
 {
     const long long nfrag = (long long)pl.nPT * pl.KT * 256;
-    const int blocks = (int)((nfrag + 255) / 256);
+    int blocks = (int)((nfrag + 255) / 256);
+    if (with_ll) blocks += (pl.npost + 3) / 4;            // trailing blocks reduce ll and d ll / d bias
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->Gpart.p,
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
                        sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
-                       pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0);
+                       pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -826,14 +827,15 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         hipError_t e = launch_any(pl, fp, h->stream);
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
         HIPCHK(hipEventRecord(h->ev[2], h->stream));
-        if (d_grad) {
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad);
+        if (d_grad) {                       // one launch: G reduction + (trailing blocks) ll reduction
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
             if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(64), 0, h->stream,
+                               (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
+                               pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
+            HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(64), 0, h->stream,
-                           (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
-                           pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
-        HIPCHK(hipGetLastError());
     } else {
         const Plan& p0 = plans[0];
         const int xs = p0.nPT * 16;

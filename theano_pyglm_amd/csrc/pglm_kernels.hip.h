@@ -1498,10 +1498,38 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
                            const double* __restrict__ gbpart, const double* __restrict__ Weff,
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
-                           int nChunks, int Nall, int np0, int DsAll, int ds0)
+                           int nChunks, int Nall, int np0, int DsAll, int ds0, int nsub)
 {
     const int P = 1 + DsAll + Nall * B;
     const long long nfrag = (long long)nPT * KT * 256;
+    const int gblocks = (int)((nfrag + 255) / 256);
+    if ((int)blockIdx.x >= gblocks) {
+        // trailing blocks: ll_n and d ll_n / d bias (one wave per neuron), when the caller folded the
+        // ll reduction into this launch (nsub > 0) -- it then runs beside the G reduction
+        if (nsub <= 0) return;
+        const int n = ((int)blockIdx.x - gblocks) * 4 + (int)(threadIdx.x >> 6);
+        if (n >= npost) return;
+        const int lane = threadIdx.x & 63;
+        const int pt = n >> 4, col = n & 15;
+        const int per = 4 * nsub;
+        const int total = nChunks * per;
+        double sl = 0.0, sg = 0.0;
+        for (int i = lane; i < total; i += 64) {
+            const int c = i / per, g = i - c * per;
+            const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
+            sl += llpart[idx];
+            sg += gbpart[idx];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sl += __shfl_xor(sl, o, 64);
+            sg += __shfl_xor(sg, o, 64);
+        }
+        if (lane == 0) {
+            ll_out[n] = sl;
+            if (grad_out != nullptr) grad_out[(size_t)n * P] = sg;
+        }
+        return;
+    }
     const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (grad_out != nullptr && gid < nfrag) {
         const int lane = (int)(gid & 63);
