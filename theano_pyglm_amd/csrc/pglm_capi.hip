@@ -36,6 +36,8 @@ struct pgl_context {
     int numCU = 256;
     hipStream_t stream = nullptr;        // stream every call of this handle is ordered on
     hipStream_t own_stream = nullptr;    // the handle's own stream (stream == own_stream unless pgl_set_stream)
+    hipStream_t aux_stream = nullptr;    // side stream: reduction of the first G half beside pass 2
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr int NEV = 256;      // ring of per-launch event sets {start, fused begin, fused end, end}
     hipEvent_t evr[NEV][4] = {};
     hipEvent_t* ev = evr[0];             // event set of the most recent pgl_ll_grad call
@@ -298,8 +300,9 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
     return hipErrorInvalidValue;
 }
 
+// passes: 1, 2, or 0 = both back to back
 template <int KTH>
-static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
     auto k1 = k_fused5<KTH, 1>;
     auto k2 = k_fused5<KTH, 2>;
@@ -309,25 +312,30 @@ static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStre
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
-    e = hipGetLastError();
-    if (e != hipSuccess || !fp.want_grad) return e;
-    hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), (size_t)2 * pgl_img_bytes(KTH) + 256, s, fp);
-    return hipGetLastError();
+    if (pass != 2) {
+        hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (pass != 1 && fp.want_grad) {
+        hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), (size_t)2 * pgl_img_bytes(KTH) + 256, s, fp);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
-static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass = 0)
 {
     switch (pl.KTW) {
-    case 1: return launch_fused5_t<1>(pl, fp, s);
-    case 2: return launch_fused5_t<2>(pl, fp, s);
-    case 3: return launch_fused5_t<3>(pl, fp, s);
-    case 5: return launch_fused5_t<5>(pl, fp, s);
-    case 7: return launch_fused5_t<7>(pl, fp, s);
-    case 10: return launch_fused5_t<10>(pl, fp, s);
-    case 13: return launch_fused5_t<13>(pl, fp, s);
-    case 16: return launch_fused5_t<16>(pl, fp, s);
-    case 20: return launch_fused5_t<20>(pl, fp, s);
+    case 1: return launch_fused5_t<1>(pl, fp, s, pass);
+    case 2: return launch_fused5_t<2>(pl, fp, s, pass);
+    case 3: return launch_fused5_t<3>(pl, fp, s, pass);
+    case 5: return launch_fused5_t<5>(pl, fp, s, pass);
+    case 7: return launch_fused5_t<7>(pl, fp, s, pass);
+    case 10: return launch_fused5_t<10>(pl, fp, s, pass);
+    case 13: return launch_fused5_t<13>(pl, fp, s, pass);
+    case 16: return launch_fused5_t<16>(pl, fp, s, pass);
+    case 20: return launch_fused5_t<20>(pl, fp, s, pass);
     }
     return hipErrorInvalidValue;
 }
@@ -387,6 +395,10 @@ int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
     h->stream = h->own_stream;
+    e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { pgl_destroy(h); return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i) {
             e = hipEventCreate(&h->evr[s][i]);
@@ -410,6 +422,9 @@ int pgl_destroy(pgl_handle h)
         for (int i = 0; i < 4; ++i)
             if (h->evr[s][i]) (void)hipEventDestroy(h->evr[s][i]);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PGL_OK;
@@ -744,15 +759,19 @@ static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, 
 }
 
 static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
-                                const double* d_Weff, double* d_ll, double* d_grad, bool with_ll = false)
+                                const double* d_Weff, double* d_ll, double* d_grad, bool with_ll = false,
+                                int kt0 = 0, int nkt = -1, hipStream_t stream = nullptr)
 {
-    const long long nfrag = (long long)pl.nPT * pl.KT * 256;
+    if (nkt < 0) nkt = pl.KT;
+    if (!stream) stream = h->stream;
+    const long long nfrag = (long long)pl.nPT * nkt * 256;
     int blocks = (int)((nfrag + 255) / 256);
     if (with_ll) blocks += (pl.npost + 3) / 4;            // trailing blocks reduce ll and d ll / d bias
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->Gpart.p,
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, (const double*)h->Gpart.p,
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
                        sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
-                       pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0);
+                       pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0, kt0,
+                       nkt);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -824,6 +843,28 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        if (pl.version == 5 && d_grad) {
+            // pass 1 | fork: the side stream reduces the first G half and ll while pass 2 runs (it is
+            // MFMA bound and leaves HBM and wave slots free) | pass 2 | join | second half
+            hipError_t e = launch_fused5(pl, fp, h->stream, 1);
+            if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 1 launch: ") + hipGetErrorString(e));
+            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true, 0, pl.KTW,
+                                      h->aux_stream);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+            e = launch_fused5(pl, fp, h->stream, 2);
+            if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 2 launch: ") + hipGetErrorString(e));
+            HIPCHK(hipEventRecord(h->ev[2], h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, false, pl.KTW, pl.KTW);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(h->ev[3], h->stream));
+            h->timing_valid = true;
+            ++h->ev_launches;
+            return PGL_OK;
+        }
         hipError_t e = launch_any(pl, fp, h->stream);
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
         HIPCHK(hipEventRecord(h->ev[2], h->stream));

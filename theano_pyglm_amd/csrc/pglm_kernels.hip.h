@@ -1498,10 +1498,13 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
                            const double* __restrict__ gbpart, const double* __restrict__ Weff,
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
-                           int nChunks, int Nall, int np0, int DsAll, int ds0, int nsub)
+                           int nChunks, int Nall, int np0, int DsAll, int ds0, int nsub, int kt0,
+                           int nkt)
 {
+    // reduces the k-tiles [kt0, kt0 + nkt) of every post tile (the two halves of the two-pass
+    // kernels are reduced by separate launches: the first one runs beside pass 2)
     const int P = 1 + DsAll + Nall * B;
-    const long long nfrag = (long long)nPT * KT * 256;
+    const long long nfrag = (long long)nPT * nkt * 256;
     const int gblocks = (int)((nfrag + 255) / 256);
     if ((int)blockIdx.x >= gblocks) {
         // trailing blocks: ll_n and d ll_n / d bias (one wave per neuron), when the caller folded the
@@ -1534,8 +1537,8 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
     if (grad_out != nullptr && gid < nfrag) {
         const int lane = (int)(gid & 63);
         const int r = (int)((gid >> 6) & 3);
-        const int kt = (int)((gid >> 8) % KT);
-        const int pt = (int)((gid >> 8) / KT);
+        const int kt = kt0 + (int)((gid >> 8) % nkt);
+        const int pt = (int)((gid >> 8) / nkt);
         const int k = 16 * kt + (lane >> 4) + 4 * r;
         const int n = 16 * pt + (lane & 15);
         if (n < npost && k < Ktot) {
