@@ -1312,3 +1312,14 @@ int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col
 }
 
 }  // extern "C"
+
+#ifdef PGL_PROF
+// dev builds only (tools/phase_profile.py): copy out the per-wave phase cycle sums of k_fused5
+extern "C" int pgl_debug_prof(long long* out, int n_ll)
+{
+    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 2 * 4096 * 8 * 8);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pgl_prof), bytes, 0, hipMemcpyDeviceToHost));
+    return PGL_OK;
+}
+#endif

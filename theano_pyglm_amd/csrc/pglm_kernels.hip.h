@@ -32,6 +32,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) of the forward passes
 #endif
 #define PGL_MAXB 8
+#ifndef PGL_ENE
+#define PGL_ENE 2            // elements a lane carries through the rate epilogue together (k_fused5)
+#endif
 
 struct FusedParams {
     // problem
@@ -1220,6 +1223,20 @@ __device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ g
     }
 }
 
+// one round of a half-image DMA: round j moves the 1 KiB pieces 8j .. 8j+7, one per wave
+template <int KTH>
+__device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
+                                              const int round, const int wave, const int lane)
+{
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int NCH = pgl_img_bytes(KTH) / 1024;
+    const int c = round * 8 + wave;
+    if (c < NCH)
+        __builtin_amdgcn_global_load_lds((gvoid*)(gimg + (size_t)c * 1024 + lane * 16),
+                                         (lvoid*)(lds_dst + (size_t)c * 1024), 16, 0, 0);
+}
+
 // ---------------------------------------------------------------------------
 // Fused ll + grad kernel, version 5: the two-pass structure of k_fused3 on resident feature tiles.
 //   pass 1, per tile: [L_i | H_i in LDS] forward over both halves | barrier | DMA of L_{i+1} (third
@@ -1229,6 +1246,28 @@ __device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ g
 //           for the second half with r read back.
 // No event windows, no basis tables, no staging: the waves only issue DMA, LDS reads and MFMAs.
 // ---------------------------------------------------------------------------
+// Phase timeline instrumentation (dev builds only: hipcc -DPGL_PROF, tools/phase_profile.py):
+// per wave, cycles between the phase boundaries of a tile summed over the chunk.
+#ifdef PGL_PROF
+__device__ long long g_pgl_prof[2][4096][8][8];          // [pass-1][workgroup][wave][phase]
+#define PGL_PROF_DECL long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t = __builtin_amdgcn_s_memtime();
+#define PGL_PROF_MARK(i)                                           \
+    do {                                                           \
+        const long long t_ = __builtin_amdgcn_s_memtime();         \
+        prof_acc[i] += t_ - prof_t;                                \
+        prof_t = t_;                                               \
+    } while (0)
+#define PGL_PROF_STORE(pass)                                                                  \
+    do {                                                                                      \
+        if (lane == 0 && blockIdx.x < 4096)                                                   \
+            for (int i_ = 0; i_ < 8; ++i_) g_pgl_prof[pass - 1][blockIdx.x][wave][i_] = prof_acc[i_]; \
+    } while (0)
+#else
+#define PGL_PROF_DECL
+#define PGL_PROF_MARK(i)
+#define PGL_PROF_STORE(pass)
+#endif
+
 template <int KTH, int PASS>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
@@ -1272,19 +1311,45 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const size_t rstride = (size_t)p.nPT * 256;
     const unsigned char* __restrict__ fimg = p.Fimg;
 
-    auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4]) {
+    // backward over one half image.  The DMA rounds of up to two half images of the next tile
+    // (g0 -> l0, then g1 -> l1; null = none) go out between the MFMAs: the loop has no register
+    // loads, so the in-order vmcnt queue holds nothing a DMA in flight could delay.  One piece costs
+    // ~32 cycles of the CU's address path and blocks the issuing wave meanwhile; waves 0-3 and their
+    // SIMD partners 4-7 issue half a period apart, so a SIMD always has one wave feeding the MFMA pipe.
+    constexpr int NR = (IMG / 1024 + 7) / 8;
+    auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
+                        unsigned char* l0, const unsigned char* g1, unsigned char* l1, const int nrounds) {
         const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSH + col;
         constexpr int NS = 4 * KTH;
         constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
+        constexpr int DSTEP = (PASS == 1) ? ((NS >= 4 * NR) ? NS / (2 * NR) : 0)
+                                          : ((NS >= 2 * NR) ? NS / NR : 0);     // MFMAs between rounds
         double ar[PD];
 #pragma unroll
         for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTH)) * RSH + 16 * (s % KTH)];
+        if (DSTEP == 0) {
+#pragma unroll
+            for (int j = 0; j < 2 * NR; ++j)
+                if (j < nrounds) pgl_dma_round<KTH>(j < NR ? g0 : g1, j < NR ? l0 : l1, j % NR, wave, lane);
+        }
+        const int phase = (wave < 4) ? ((DSTEP > 1) ? DSTEP / 2 - 1 : 0) : DSTEP - 1;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const double a = ar[s % PD];
             if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTH)) * RSH + 16 * ((s + PD) % KTH)];
             G[s % KTH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTH], G[s % KTH], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if (DSTEP > 0) {
+                constexpr int DS = (DSTEP > 0) ? DSTEP : 1;
+                const int j = s / DS;
+                const int ph = s % DS;
+                if ((ph == DS - 1 || (DS > 1 && ph == DS / 2 - 1)) && j < 2 * NR) {
+                    if (ph == phase && j < nrounds) {
+                        pgl_dma_round<KTH>(j < NR ? g0 : g1, j < NR ? l0 : l1, j % NR, wave, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
 
@@ -1312,22 +1377,24 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         if (tile_beg < tile_end) load_counts(tile_beg, scn);
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
         __syncthreads();
+        PGL_PROF_DECL
         for (int tile = tile_beg; tile < tile_end; ++tile) {
             const int t0 = tile * TT;
             const int par = (tile - tile_beg) & 1;
             const unsigned char* Lb = par ? buf2 : buf0;     // L alternates buf0 / buf2, H lives in buf1
             unsigned char* Ln = par ? buf0 : buf2;
+            const bool more = tile + 1 < tile_end;
 #pragma unroll
             for (int r = 0; r < 4; ++r) scb[r] = scn[r];
             // ---- forward over both halves ----
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+            constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
             if (active && !(p.dbg & 8)) {
                 const double* faL = reinterpret_cast<const double*>(Lb) + col * RSH + grp;
                 const double* faH = reinterpret_cast<const double*>(buf1) + col * RSH + grp;
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
-                constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
                 constexpr int PA = 4;
                 const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
@@ -1350,22 +1417,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();                              // every wave is done with H_i (buf1)
-            if (tile + 1 < tile_end) {                    // tile+1 arrives under epilogue + backward
-                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln, wave, lane);
-                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, wave, lane);
-                load_counts(tile + 1, scn);               // retired by the closing vmcnt(0) of this tile
-            }
-            // ---- epilogue on the accumulator registers, two elements at a time ----
+            PGL_PROF_MARK(0);
+            const bool do_bwd = active && p.want_grad && !(p.dbg & 16);
+            // ---- epilogue on the accumulator registers, PGL_ENE elements at a time ----
             double rr[4];
             if (active) {
+                constexpr int ENE = PGL_ENE;
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    double xe[2], se[2], terme[2], rese[2];
-                    bool vte[2];
+                for (int h2 = 0; h2 < 4 / ENE; ++h2) {
+                    double xe[ENE], se[ENE], terme[ENE], rese[ENE];
+                    bool vte[ENE];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int r = 2 * h2 + e;
+                    for (int e = 0; e < ENE; ++e) {
+                        const int r = ENE * h2 + e;
                         xe[e] = bias_l + (acc0[r] + acc1[r]);
                         se[e] = (double)scb[r];
                         const long long tg = (long long)t0 + grp + 4 * r;
@@ -1373,19 +1437,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     }
                     if (p.dbg & 4) {
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
+                        for (int e = 0; e < ENE; ++e) {
                             terme[e] = xe[e] * se[e];
                             rese[e] = xe[e] - se[e];
                         }
                     } else {
                         pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                         asm volatile("" : "+v"(Cl));
-                        pgl_rate_terms_n<2>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                        pgl_rate_terms_n<ENE>(xe, se, p.nlin, p.dt, terme, rese, Cl);
                     }
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < ENE; ++e) {
                         const double res = vte[e] ? rese[e] : 0.0;
-                        rr[2 * h2 + e] = res;
+                        rr[ENE * h2 + e] = res;
                         ll_acc += vte[e] ? terme[e] : 0.0;
                         gb_acc += res;
                     }
@@ -1394,15 +1458,33 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rr[r] = 0.0;
             }
-            if (active && p.want_grad && !(p.dbg & 16)) {
+            PGL_PROF_MARK(1);
+            // The barrier that frees H_i (buf1) for the next tile's DMA sits behind the epilogue, not
+            // in front of it: the epilogue touches no feature buffer, and the older wave of a SIMD
+            // (which wins the MFMA arbitration and leaves the forward loop first) then runs its VALU
+            // chains in the gaps of its partner's last forward MFMAs instead of idling at the barrier.
+            __syncthreads();                              // every wave is done with H_i (buf1)
+            PGL_PROF_MARK(2);
+            if (more) load_counts(tile + 1, scn);         // retired by the closing vmcnt(0) of this tile
+            if (more && !do_bwd) {
+                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln, wave, lane);
+                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, wave, lane);
+            }
+            PGL_PROF_MARK(3);
+            if (do_bwd) {                                 // H_{i+1} (over H_i) goes out between the MFMAs
                 double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
-                bwd_half(Lb, rr);
+                bwd_half(Lb, rr, fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln,
+                         fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, more ? 2 * NR : 0);
             }
+            PGL_PROF_MARK(4);
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
+            PGL_PROF_MARK(5);
             __syncthreads();
+            PGL_PROF_MARK(6);
         }
+        PGL_PROF_STORE(1);
         if (active) {
             const size_t slot = (size_t)chunk * p.nPT + pt;
             p.llpart[slot * 64 + lane] = ll_acc;
@@ -1426,23 +1508,31 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
             }
         }
+        PGL_PROF_DECL
         for (int tile = tile_beg; tile < tile_end; ++tile) {
             const int par = (tile - tile_beg) & 1;
             const unsigned char* Hb = par ? buf1 : buf0;
             unsigned char* Hn = par ? buf0 : buf1;
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): H_i and r_i are here
+            PGL_PROF_MARK(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) rv[r] = rn[r];
             __syncthreads();                              // ... for every wave; H_{i-1}'s buffer is free
-            if (tile + 1 < tile_end) {
-                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, wave, lane);
+            PGL_PROF_MARK(1);
+            const bool more = tile + 1 < tile_end;
+            const bool do_bwd = active && !(p.dbg & 16);
+            if (more) {
+                if (!do_bwd) pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, wave, lane);
                 if (active) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
                 }
             }
-            if (active && !(p.dbg & 16)) bwd_half(Hb, rv);
+            PGL_PROF_MARK(2);
+            if (do_bwd) bwd_half(Hb, rv, fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, nullptr, nullptr, more ? NR : 0);
+            PGL_PROF_MARK(3);
         }
+        PGL_PROF_STORE(2);
         if (active) {
             double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTH) * 256 + lane;
 #pragma unroll
