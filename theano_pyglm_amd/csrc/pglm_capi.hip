@@ -52,7 +52,8 @@ struct pgl_context {
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
     DevBuf fimg;                         // resident feature tiles (k_fused5)
     double* pin_out = nullptr;           // pinned host buffer for small results (PGL_KMAX doubles)
-    int fimg_kth = 0;                    // half width (k-tiles) the images were built for; 0 = stale
+    int fimg_kth = 0;                    // widths (ktl << 8 | kth, k-tiles) the images were built for; 0 = stale
+    int fimg_tile0 = 0, fimg_ntiles = 0; // 16-bin tiles the images cover (the evaluated time range)
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -88,6 +89,7 @@ struct Plan {
     int npost, nPT, wpb, nPB, KT, KS, rsf, RP, nTiles, nChunks, tilesPerChunk, blocks, threads;
     int tile0;
     int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
+    int ktl, kth;                       // version 5: k-tiles of the L / H column parts
     size_t lds;
     bool f32;
 };
@@ -120,7 +122,20 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 }
 
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
-static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel
+static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel (on the fly)
+// resident-tile kernel: (L, H) k-tile pairs; pass 1 (forward + L columns of G) gets the smaller share
+static const int kKTP[][2] = {{1, 1}, {2, 2}, {3, 3}, {5, 5}, {7, 7}, {9, 11}, {12, 14}, {14, 18}, {18, 22}};
+static bool pick_pair(int need, int& ktl, int& kth)
+{
+    for (const auto& pr : kKTP)
+        if (pr[0] + pr[1] >= need) {
+            ktl = pr[0];
+            kth = pr[1];
+            return true;
+        }
+    return false;
+}
+static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(ktl) + pgl_img_bytes(kth); }
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
                      bool single_slice = true)
@@ -141,18 +156,17 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (h->opt_kernel == 3) pl.version = 4;
         else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && pl.nPT >= 5)) pl.version = 5;
     }
-    if (pl.version == 5 && h->opt_kernel == 0 && h->fimg_kth == 0) {
-        // resident feature tiles need nT16 * 2 * image bytes of HBM (3.1 GB at C3); in auto mode fall
-        // back to on-the-fly generation (version 4) when the device cannot spare them
-        int kth = 0;
-        for (int k : kKTH)
-            if (k >= (need + 1) / 2) {
-                kth = k;
-                break;
-            }
+    pl.tile0 = (int)(h->t_lo / 16);
+    pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
+    pl.ktl = pl.kth = 0;
+    if (pl.version == 5 && !pick_pair(need, pl.ktl, pl.kth)) pl.version = 4;
+    if (pl.version == 5 && h->opt_kernel == 0 &&
+        !(h->fimg_kth == (pl.ktl << 8 | pl.kth) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
+        // resident feature tiles need nTiles * (L + H image bytes) of HBM (3.1 GB at C3); in auto mode
+        // fall back to on-the-fly generation (version 4) when the device cannot spare them
         size_t free_b = 0, total_b = 0;
-        if (kth > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t want = (size_t)h->nT16 * 2 * (size_t)pgl_img_bytes(kth) + h->fimg.cap * 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t want = (size_t)pl.nTiles * img_pair_bytes(pl.ktl, pl.kth);
             if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) pl.version = 4;
         }
     }
@@ -165,7 +179,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         while (pl.RP % 32 != 8) ++pl.RP;
     }
     pl.cap = PGL_CAP;
-    if (pl.version == 4 || pl.version == 5) {
+    if (pl.version == 5) {
+        pl.PTW = 8; pl.KSPLIT = 1; pl.KTW = pl.kth; pl.KT = pl.ktl + pl.kth; pl.wpb = 8;
+        pl.nPB = (pl.nPT + 7) / 8;
+    } else if (pl.version == 4) {
         const int needh = (need + 1) / 2;
         int kth = 0;
         for (int k : kKTH)
@@ -200,8 +217,6 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
-    pl.tile0 = (int)(h->t_lo / 16);
-    pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
     const int wgPerCU = 1;
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
@@ -212,7 +227,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     const size_t esz = pl.f32 ? 4 : 8;
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
     if (pl.version == 5) {
-        pl.lds = (size_t)3 * pgl_img_bytes(pl.KTW) + 256;
+        pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8;   // + per-wave spike scratch
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }
@@ -301,16 +316,17 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
 }
 
 // passes: 1, 2, or 0 = both back to back
-template <int KTH>
+template <int KTL, int KTH>
 static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
-    auto k1 = k_fused5<KTH, 1>;
-    auto k2 = k_fused5<KTH, 2>;
+    auto k1 = k_fused5<KTL, KTH, 1>;
+    auto k2 = k_fused5<KTL, KTH, 2>;
+    const size_t lds2 = (size_t)2 * pgl_img_bytes(KTH) + 256;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (e != hipSuccess) return e;
     if (pass != 2) {
         hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
@@ -318,7 +334,7 @@ static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStre
         if (e != hipSuccess) return e;
     }
     if (pass != 1 && fp.want_grad) {
-        hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), (size_t)2 * pgl_img_bytes(KTH) + 256, s, fp);
+        hipLaunchKernelGGL(k2, dim3(pl.blocks), dim3(512), lds2, s, fp);
         e = hipGetLastError();
     }
     return e;
@@ -326,16 +342,16 @@ static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStre
 
 static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass = 0)
 {
-    switch (pl.KTW) {
-    case 1: return launch_fused5_t<1>(pl, fp, s, pass);
-    case 2: return launch_fused5_t<2>(pl, fp, s, pass);
-    case 3: return launch_fused5_t<3>(pl, fp, s, pass);
-    case 5: return launch_fused5_t<5>(pl, fp, s, pass);
-    case 7: return launch_fused5_t<7>(pl, fp, s, pass);
-    case 10: return launch_fused5_t<10>(pl, fp, s, pass);
-    case 13: return launch_fused5_t<13>(pl, fp, s, pass);
-    case 16: return launch_fused5_t<16>(pl, fp, s, pass);
-    case 20: return launch_fused5_t<20>(pl, fp, s, pass);
+    switch (pl.ktl << 8 | pl.kth) {
+    case 1 << 8 | 1: return launch_fused5_t<1, 1>(pl, fp, s, pass);
+    case 2 << 8 | 2: return launch_fused5_t<2, 2>(pl, fp, s, pass);
+    case 3 << 8 | 3: return launch_fused5_t<3, 3>(pl, fp, s, pass);
+    case 5 << 8 | 5: return launch_fused5_t<5, 5>(pl, fp, s, pass);
+    case 7 << 8 | 7: return launch_fused5_t<7, 7>(pl, fp, s, pass);
+    case 9 << 8 | 11: return launch_fused5_t<9, 11>(pl, fp, s, pass);
+    case 12 << 8 | 14: return launch_fused5_t<12, 14>(pl, fp, s, pass);
+    case 14 << 8 | 18: return launch_fused5_t<14, 18>(pl, fp, s, pass);
+    case 18 << 8 | 22: return launch_fused5_t<18, 22>(pl, fp, s, pass);
     }
     return hipErrorInvalidValue;
 }
@@ -741,6 +757,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.want_grad = want_grad ? 1 : 0;
     fp.dbg = h->opt_dbg;
     fp.Fimg = (const unsigned char*)h->fimg.p;
+    fp.img_tile0 = h->fimg_tile0;
 }
 
 static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
@@ -781,20 +798,25 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
     return launch_fused2(pl, fp, s);
 }
 
-// Resident feature tiles of the whole recording for half width `kth` k-tiles (k_build_fimg):
-// built on first use and after every change of spikes / basis / stimulus features.
-static int ensure_feature_images(pgl_handle h, int kth)
+// Resident feature tiles (k_build_fimg) of the evaluated time range [tile0, tile0 + ntiles) for the
+// column split (ktl, kth): built on first use and after every change of spikes / basis / stimulus
+// features / time range.  A time-sharded rank (pgl_set_time_range) therefore builds and keeps only its
+// own 1/G of the recording.
+static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles)
 {
-    if (h->fimg_kth == kth && h->fimg.p) return PGL_OK;
-    const size_t bytes = (size_t)h->nT16 * 2 * (size_t)pgl_img_bytes(kth);
+    if (h->fimg_kth == (ktl << 8 | kth) && h->fimg_tile0 == tile0 && h->fimg_ntiles == ntiles && h->fimg.p)
+        return PGL_OK;
+    const size_t bytes = (size_t)ntiles * img_pair_bytes(ktl, kth);
     ENSURE(h->fimg, bytes);
-    dim3 grid((unsigned)h->nT16, 2);
+    dim3 grid((unsigned)ntiles, 2);
     hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
-                       h->Rk, h->Dstim, kth, (unsigned char*)h->fimg.p);
+                       h->Rk, h->Dstim, ktl, kth, tile0, (unsigned char*)h->fimg.p);
     HIPCHK(hipGetLastError());
-    h->fimg_kth = kth;
+    h->fimg_kth = ktl << 8 | kth;
+    h->fimg_tile0 = tile0;
+    h->fimg_ntiles = ntiles;
     return PGL_OK;
 }
 
@@ -837,7 +859,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (fresh) HIPCHK(hipMemsetAsync(h->Xbuf.p, 0, need, h->stream));
         }
         if (pl.version == 5) {
-            rc = ensure_feature_images(h, pl.KTW);
+            rc = ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles);
             if (rc) return rc;
         }
         FusedParams fp;
@@ -850,7 +872,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 1 launch: ") + hipGetErrorString(e));
             HIPCHK(hipEventRecord(h->ev_fork, h->stream));
             HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true, 0, pl.KTW,
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true, 0, pl.ktl,
                                       h->aux_stream);
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
@@ -858,7 +880,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 2 launch: ") + hipGetErrorString(e));
             HIPCHK(hipEventRecord(h->ev[2], h->stream));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, false, pl.KTW, pl.KTW);
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, false, pl.ktl, pl.kth);
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev[3], h->stream));
             h->timing_valid = true;
@@ -1037,10 +1059,10 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     const double P = 1.0 + h->Dstim + h->Kimp;
     double v[12];
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
-    v[10] = (pl.version == 5) ? (double)h->nT16 * 2.0 * pgl_img_bytes(pl.KTW) : 0.0;   // resident feature bytes
+    v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth) : 0.0;   // resident feature bytes
     // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
-    // pass 1 and half of them again in pass 2, residual slab written and read)
-    v[11] = (pl.version == 5) ? 1.5 * v[10] + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
+    // pass 1 and the H part again in pass 2, residual slab written and read)
+    v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
             : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0 : 0.0;
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;

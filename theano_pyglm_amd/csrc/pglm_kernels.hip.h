@@ -32,8 +32,15 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) of the forward passes
 #endif
 #define PGL_MAXB 8
+#ifndef PGL_PRIO
+#define PGL_PRIO 1           // k_fused5: waves 4-7 lead the first half of every MFMA loop (s_setprio)
+#endif
+#ifndef PGL_EBAR
+#define PGL_EBAR 1           // k_fused5: barrier between the epilogue and the backward loop
+#endif
 #ifndef PGL_ENE
-#define PGL_ENE 2            // elements a lane carries through the rate epilogue together (k_fused5)
+#define PGL_ENE 4            // elements a lane carries through the rate epilogue together (k_fused5):
+                             // 4 = pgl_rate4 (fixed instruction order), 2 = pgl_rate_terms_n<2> only
 #endif
 
 struct FusedParams {
@@ -71,6 +78,7 @@ struct FusedParams {
     int want_grad;
     int dbg;                             // timing ablation bits (results invalid when != 0)
     const unsigned char* __restrict__ Fimg;   // resident feature tiles (k_fused5), else null
+    int img_tile0;                       // first tile the resident images cover
 };
 
 // ---------------------------------------------------------------------------
@@ -232,6 +240,215 @@ __device__ __forceinline__ void pgl_rate_terms_n(const double (&x)[NE], const do
     }
 }
 
+// ---------------------------------------------------------------------------
+// Rate epilogue of one 16x16 tile on the accumulator layout: four elements per lane carried
+// through every stage together, in a fixed instruction order (a scheduling barrier after every
+// row of four).  The f64 VALU shares its pipeline with the f64 MFMA and a dependent v_fma_f64
+// costs ~11 cycles against 4 of issue: the compiler's own order (register pressure first) runs
+// the Horner chains one after the other, i.e. latency bound.  Constants arrive by scalar loads
+// (SGPR operands: no VGPRs, no LDS reads) through a pointer the caller has made opaque inside the
+// tile loop, so the loads are not hoisted out of it.
+//   explinear, every lane in the series regime (exp(-|x|) < 9.6e-5, i.e. |x| > 9.25): handled here;
+//   exp nonlinearity: handled here; anything else (or lam == 0 / NaN): returns false and the caller
+//   takes the general two-at-a-time path (pgl_rate_terms_n).
+// The spike terms  S log(lam)  and  S/lam  concern ~2 % of the elements: they are compacted
+// through a per-wave LDS scratch (one element per lane) and evaluated once per tile instead of
+// once per accumulator register.
+//   x[4] currents, sc[4] spike counts; res[4] = d ll / d x; returns the tile's ll contribution
+//   of this lane in `term`.
+// ---------------------------------------------------------------------------
+// Phase timeline instrumentation (dev builds only: hipcc -DPGL_PROF, tools/phase_profile.py):
+// per wave, cycles between the phase boundaries of a tile summed over the chunk.
+#ifdef PGL_PROF
+__device__ long long g_pgl_prof[2][4096][8][12];          // [pass-1][workgroup][wave][phase]
+#define PGL_PROF_DECL long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t = __builtin_amdgcn_s_memtime(); \
+    const long long prof_rt0 = __builtin_amdgcn_s_memrealtime(), prof_t0 = prof_t;
+#define PGL_PROF_MARK(i)                                           \
+    do {                                                           \
+        const long long t_ = __builtin_amdgcn_s_memtime();         \
+        prof_acc[i] += t_ - prof_t;                                \
+        prof_t = t_;                                               \
+    } while (0)
+#define PGL_PROF_STORE(pass)                                                                  \
+    do {                                                                                      \
+        prof_acc[10] = __builtin_amdgcn_s_memtime() - prof_t0;          /* shader cycles of the loop */ \
+        prof_acc[11] = __builtin_amdgcn_s_memrealtime() - prof_rt0;     /* 100 MHz ticks of the loop */  \
+        if (lane == 0 && blockIdx.x < 4096)                                                   \
+            for (int i_ = 0; i_ < 12; ++i_) g_pgl_prof[pass - 1][blockIdx.x][wave][i_] = prof_acc[i_]; \
+    } while (0)
+#else
+#define PGL_PROF_DECL
+#define PGL_PROF_MARK(i)
+#define PGL_PROF_STORE(pass)
+#endif
+#ifdef PGL_PROF
+#define PGL_PROF_ARGS , long long (&prof_acc)[12], long long& prof_t
+#define PGL_PROF_PASS , prof_acc, prof_t
+#else
+#define PGL_PROF_ARGS
+#define PGL_PROF_PASS
+#endif
+typedef double pgl_d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) double* pgl_k_cdp;
+#define PGL_ROW __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (&sc)[4], const int nlin,
+                                          const double dt, const pgl_k_cdp C, double* scratch,
+                                          const int lane, double& term, double (&res)[4] PGL_PROF_ARGS)
+{
+    double k[4], r[4], q[4], e[4];
+    // every constant of the exp / series stages is requested up front: one scalar-memory wait
+    double c[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) c[j] = C[j];
+    const double c13 = C[22], cthr = C[23];
+    // ---- e = exp(y), y = -|x| (explinear) or x (exp) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = rint((nlin == 1 ? -fabs(x[i]) : x[i]) * c[0]);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], c[1], (nlin == 1 ? -fabs(x[i]) : x[i]));
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], c[2], r[i]);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(c[3], r[i], c[4]);
+    PGL_ROW;
+#pragma unroll
+    for (int j = 5; j <= 13; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], c[j]);
+        PGL_ROW;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 0.5);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = fmin(fmax(k[i], -2200.0), 2200.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = ldexp(q[i], (int)k[i]);
+    PGL_ROW;
+    PGL_PROF_MARK(7);
+    if (nlin != 1) {
+        // exp nonlinearity: lam = e, term = x s - dt lam, r = s - dt lam
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double sd = (double)sc[i];
+            res[i] = fma(-dt, e[i], sd);
+            t += fma(x[i], sd, -dt * e[i]);
+        }
+        term = t;
+        return true;
+    }
+    bool small = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) small = small && (e[i] < cthr);
+    if (!__all(small)) return false;
+    // ---- series regime: log1p(e) and 1/(1+e) from their alternating series (error < e^6) ----
+    double l1p[4], inv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], 0.2, 0.25);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], 1.0, 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], c13);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], 0.5);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    PGL_ROW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l1p[i] = e[i] * l1p[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    PGL_ROW;
+    double lam[4], sig[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lam[i] = fmax(x[i], 0.0) + l1p[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sig[i] = (x[i] >= 0.0) ? inv[i] : e[i] * inv[i];
+    PGL_ROW;
+    // reference semantics at lam == 0 / NaN are the general path's business
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ok = ok && (lam[i] > 0.0);
+    if (!__all(ok)) return false;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t = fma(-dt, lam[i], t);
+    PGL_PROF_MARK(8);
+    // ---- spike terms, compacted: slot = rank of the (register, lane) pair among the tile's spikes ----
+    unsigned long long m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = __ballot(sc[i] != 0u);
+    const int n0 = __popcll(m[0]), n1 = __popcll(m[1]), n2 = __popcll(m[2]), n3 = __popcll(m[3]);
+    const int total = n0 + n1 + n2 + n3;
+    if (total == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res[i] = -dt * sig[i];
+    } else if (total <= 64) {
+        const int base[4] = {0, n0, n0 + n1, n0 + n1 + n2};
+        int slot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            slot[i] = base[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[i] >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((unsigned)m[i], 0u));
+            if (sc[i] != 0u) scratch[slot[i]] = lam[i];
+            slot[i] = (sc[i] != 0u) ? slot[i] : 0;        // lanes without a spike read slot 0, weight 0
+        }
+        __builtin_amdgcn_wave_barrier();               // one wave: its LDS operations execute in order
+        const double lc = (lane < total) ? scratch[lane] : 1.0;
+        pgl_d2 LI;
+        LI.x = pgl_log(lc, C);
+        LI.y = pgl_rcp(lc);
+        pgl_d2* const so = reinterpret_cast<pgl_d2*>(scratch + 64);
+        so[lane] = LI;
+        __builtin_amdgcn_wave_barrier();
+        pgl_d2 g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = so[slot[i]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double sd = (double)sc[i];
+            t = fma(g[i].x, sd, t);
+            res[i] = fma(sd, g[i].y, -dt) * sig[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            res[i] = -dt * sig[i];
+            if (m[i] != 0ull) {
+                const double sd = (double)sc[i];
+                const double L = pgl_log(lam[i], C);
+                const double I = pgl_rcp(lam[i]);
+                t = (sc[i] != 0u) ? fma(L, sd, t) : t;
+                res[i] = (sc[i] != 0u) ? fma(sd, I, -dt) * sig[i] : res[i];
+            }
+        }
+    }
+    PGL_PROF_MARK(9);
+    term = t;
+    return true;
+}
+
 template <typename CP>
 __device__ __forceinline__ void pgl_rate_terms(const double x, const double s, const int nlin,
                                                const double dt, double& term, double& res,
@@ -272,7 +489,6 @@ __device__ __forceinline__ int2 pgl_decode_event(const int2 e, const int t0, con
 }
 
 typedef const __attribute__((address_space(3))) double* pgl_lds_cdp;
-typedef double pgl_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) pgl_d2* pgl_glb_cd2p;
 
 template <typename T> struct pgl_vec2;
@@ -1169,32 +1385,34 @@ __device__ __forceinline__ double conv_one(const int2* __restrict__ spk, int lo,
     return a;
 }
 
-__host__ __device__ constexpr int pgl_img_rsh(int kth) { return kth * 16 + 2; }
-__host__ __device__ constexpr int pgl_img_bytes(int kth) { return ((16 * pgl_img_rsh(kth) * 8 + 1023) / 1024) * 1024; }
+__host__ __device__ constexpr int pgl_img_rsh(int kt) { return kt * 16 + 2; }
+__host__ __device__ constexpr int pgl_img_bytes(int kt) { return ((16 * pgl_img_rsh(kt) * 8 + 1023) / 1024) * 1024; }
 
-// grid = (nT16, 2); block = 256.  One block builds one half image.
+// grid = (nT16, 2); block = 256.  One block builds one image: part 0 = the first ktl k-tiles of
+// feature columns ("L"), part 1 = the following kth k-tiles ("H"); a tile's L and H images are adjacent.
 __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk,
                                                     const int* __restrict__ wlo,
                                                     const int* __restrict__ whi,
                                                     const double* __restrict__ phi,
                                                     const double* __restrict__ fstim, long long nT,
-                                                    int N, int B, int R, int Dstim, int kth,
-                                                    unsigned char* __restrict__ Fimg)
+                                                    int N, int B, int R, int Dstim, int ktl, int kth,
+                                                    int tile0, unsigned char* __restrict__ Fimg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* phiS = reinterpret_cast<double*>(smem);
     for (int i = threadIdx.x; i < B * R; i += blockDim.x) phiS[i] = phi[i];
     __syncthreads();
-    const int tile = blockIdx.x, half = blockIdx.y;
-    const int rsh = pgl_img_rsh(kth), c0 = kth * 16, Kimp = N * B;
-    const size_t img = (size_t)pgl_img_bytes(kth);
-    double* dst = reinterpret_cast<double*>(Fimg + ((size_t)tile * 2 + half) * img);
-    const int nel = (int)(img / 8);
+    const int tile = tile0 + blockIdx.x, part = blockIdx.y;
+    const int kt = part ? kth : ktl;
+    const int rsh = pgl_img_rsh(kt), cw = kt * 16, cbeg = part ? ktl * 16 : 0, Kimp = N * B;
+    const size_t imgl = (size_t)pgl_img_bytes(ktl), imgh = (size_t)pgl_img_bytes(kth);
+    double* dst = reinterpret_cast<double*>(Fimg + (size_t)blockIdx.x * (imgl + imgh) + (part ? imgl : 0));
+    const int nel = (int)((part ? imgh : imgl) / 8);
     for (int i = threadIdx.x; i < nel; i += blockDim.x) {
         const int t = i / rsh, c = i - t * rsh;
         double v = 0.0;
-        if (t < 16 && c < c0) {
-            const int col = half * c0 + c;
+        if (t < 16 && c < cw) {
+            const int col = cbeg + c;
             const long long tg = (long long)tile * 16 + t;
             if (col < Kimp) {
                 const int np = col / B, b = col - np * B;
@@ -1207,13 +1425,14 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
     }
 }
 
-template <int KTH>
+// whole image of KT k-tiles by LDS-DMA: 1 KiB pieces, piece c by wave c % 8
+template <int KT>
 __device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
                                              const int wave, const int lane)
 {
     typedef __attribute__((address_space(1))) void gvoid;
     typedef __attribute__((address_space(3))) void lvoid;
-    constexpr int NCH = pgl_img_bytes(KTH) / 1024;
+    constexpr int NCH = pgl_img_bytes(KT) / 1024;
 #pragma unroll
     for (int c0 = 0; c0 < NCH; c0 += 8) {
         const int c = c0 + wave;
@@ -1223,14 +1442,14 @@ __device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ g
     }
 }
 
-// one round of a half-image DMA: round j moves the 1 KiB pieces 8j .. 8j+7, one per wave
-template <int KTH>
+// one round of an image DMA: round j moves the 1 KiB pieces 8j .. 8j+7, one per wave
+template <int KT>
 __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
                                               const int round, const int wave, const int lane)
 {
     typedef __attribute__((address_space(1))) void gvoid;
     typedef __attribute__((address_space(3))) void lvoid;
-    constexpr int NCH = pgl_img_bytes(KTH) / 1024;
+    constexpr int NCH = pgl_img_bytes(KT) / 1024;
     const int c = round * 8 + wave;
     if (c < NCH)
         __builtin_amdgcn_global_load_lds((gvoid*)(gimg + (size_t)c * 1024 + lane * 16),
@@ -1239,44 +1458,39 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // Fused ll + grad kernel, version 5: the two-pass structure of k_fused3 on resident feature tiles.
-//   pass 1, per tile: [L_i | H_i in LDS] forward over both halves | barrier | DMA of L_{i+1} (third
-//           buffer) and H_{i+1} (over H_i) | epilogue on the accumulator registers | r to HBM |
-//           backward for the first half from L_i | wait for the DMA | barrier.
-//   pass 2, per tile: wait for H_i | barrier | DMA of H_{i+1} into the other buffer | backward
-//           for the second half with r read back.
+// The feature columns are cut into an "L" part of KTL k-tiles and an "H" part of KTH (KTL <= KTH:
+// pass 1 also carries the forward ring, the accumulators and the epilogue in its 256 registers, so
+// it keeps the smaller share of G).
+//   pass 1, per tile: [L_i | H_i in LDS] forward over both parts | barrier | epilogue on the
+//           accumulator registers (both waves of a SIMD side by side) | barrier | r to HBM | backward
+//           for the L columns from L_i, the DMA of L_{i+1} (third buffer) and H_{i+1} (over H_i) issued
+//           between its MFMAs | wait for the DMA | barrier.
+//   pass 2, per tile: wait for H_i | barrier | backward for the H columns with r read back, the DMA of
+//           H_{i+1} (other buffer) issued between its MFMAs.
 // No event windows, no basis tables, no staging: the waves only issue DMA, LDS reads and MFMAs.
+// What the phase timeline (tools/phase_profile.py) taught:
+//   * one LDS-DMA piece costs ~32 cycles of the CU's address path and blocks the issuing wave: a
+//     burst of 84 pieces behind a barrier idles the MFMA pipes for ~2.7k cycles per tile.  Issued
+//     between the backward MFMAs, waves 0-3 and their SIMD partners 4-7 half a period apart, a SIMD
+//     always has one wave feeding the pipe.  (Not in the forward loop: a DMA in flight sits in front
+//     of the Wmat ring loads in the in-order vmcnt queue.)
+//   * MFMA arbitration between the two waves of a SIMD goes by priority, then age: at equal priority
+//     the older wave leaves every loop thousands of cycles early and its partner, alone, cannot keep
+//     the pipe full.  Waves 4-7 lead the first half of every loop (s_setprio), waves 0-3 the second.
+//   * f64 VALU work beside a partner's back-to-back MFMAs gets one issue slot per 64-cycle MFMA:
+//     the two epilogues of a SIMD run side by side between two barriers, four elements per lane in
+//     a fixed instruction order (pgl_rate4).
 // ---------------------------------------------------------------------------
-// Phase timeline instrumentation (dev builds only: hipcc -DPGL_PROF, tools/phase_profile.py):
-// per wave, cycles between the phase boundaries of a tile summed over the chunk.
-#ifdef PGL_PROF
-__device__ long long g_pgl_prof[2][4096][8][8];          // [pass-1][workgroup][wave][phase]
-#define PGL_PROF_DECL long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t = __builtin_amdgcn_s_memtime();
-#define PGL_PROF_MARK(i)                                           \
-    do {                                                           \
-        const long long t_ = __builtin_amdgcn_s_memtime();         \
-        prof_acc[i] += t_ - prof_t;                                \
-        prof_t = t_;                                               \
-    } while (0)
-#define PGL_PROF_STORE(pass)                                                                  \
-    do {                                                                                      \
-        if (lane == 0 && blockIdx.x < 4096)                                                   \
-            for (int i_ = 0; i_ < 8; ++i_) g_pgl_prof[pass - 1][blockIdx.x][wave][i_] = prof_acc[i_]; \
-    } while (0)
-#else
-#define PGL_PROF_DECL
-#define PGL_PROF_MARK(i)
-#define PGL_PROF_STORE(pass)
-#endif
-
-template <int KTH, int PASS>
+template <int KTL, int KTH, int PASS>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
     constexpr int TT = 16, NW = 8;
-    constexpr int KT_ALL = 2 * KTH;
+    constexpr int KT_ALL = KTL + KTH;
     constexpr int KS_ALL = 4 * KT_ALL;
-    constexpr int KSH = 4 * KTH;                 // k-steps per half
-    constexpr int RSH = pgl_img_rsh(KTH);
-    constexpr int IMG = pgl_img_bytes(KTH);
+    constexpr int KSL = 4 * KTL;                 // k-steps of the L part
+    constexpr int RSL = pgl_img_rsh(KTL), RSH = pgl_img_rsh(KTH);
+    constexpr int IMGL = pgl_img_bytes(KTL), IMGH = pgl_img_bytes(KTH);
+    constexpr int KTG = (PASS == 1) ? KTL : KTH; // k-tiles of G this pass accumulates
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -1288,15 +1502,16 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const int pt = pb * NW + wave;
     const bool active = pt < p.nPT;
 
+    // pass 1: L buffers at 0 and IMGL, H buffer behind them; pass 2: two H buffers
     unsigned char* buf0 = smem;
-    unsigned char* buf1 = smem + IMG;
-    unsigned char* buf2 = smem + 2 * IMG;        // pass 1 only
-    double* Cs = reinterpret_cast<double*>(smem + (PASS == 1 ? 3 : 2) * IMG);
+    unsigned char* buf2 = smem + IMGL;           // pass 1 only
+    unsigned char* buf1 = smem + ((PASS == 1) ? 2 * IMGL : IMGH);
+    double* Cs = reinterpret_cast<double*>(smem + ((PASS == 1) ? 2 * IMGL + IMGH : 2 * IMGH));
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
-    d4_t G[KTH];
+    d4_t G[KTG];
 #pragma unroll
-    for (int kt = 0; kt < KTH; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int kt = 0; kt < KTG; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
     const int col = lane & 15;
     const int grp = lane >> 4;
@@ -1309,44 +1524,50 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
     double* const rslab = p.Xbuf + ((size_t)(active ? pt : 0)) * 256 + lane;
     const size_t rstride = (size_t)p.nPT * 256;
-    const unsigned char* __restrict__ fimg = p.Fimg;
+    // images are indexed relative to the first tile they were built for (p.img_tile0)
+    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * (IMGL + IMGH);
+    constexpr size_t IMGS = (size_t)IMGL + IMGH;
 
-    // backward over one half image.  The DMA rounds of up to two half images of the next tile
-    // (g0 -> l0, then g1 -> l1; null = none) go out between the MFMAs: the loop has no register
-    // loads, so the in-order vmcnt queue holds nothing a DMA in flight could delay.  One piece costs
-    // ~32 cycles of the CU's address path and blocks the issuing wave meanwhile; waves 0-3 and their
-    // SIMD partners 4-7 issue half a period apart, so a SIMD always has one wave feeding the MFMA pipe.
-    constexpr int NR = (IMG / 1024 + 7) / 8;
+    // backward over one image of KTG k-tiles.  The DMA rounds of up to two images of the next tile
+    // (NR0 rounds g0 -> l0, then NR1 rounds g1 -> l1) go out between the MFMAs.
+    constexpr int NRL = (IMGL / 1024 + 7) / 8, NRH = (IMGH / 1024 + 7) / 8;
+    constexpr int NR0 = (PASS == 1) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
+    constexpr int RSG = (PASS == 1) ? RSL : RSH;
     auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
-                        unsigned char* l0, const unsigned char* g1, unsigned char* l1, const int nrounds) {
-        const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSH + col;
-        constexpr int NS = 4 * KTH;
+                        unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
+        const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSG + col;
+        constexpr int NS = 4 * KTG;
         constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
-        constexpr int DSTEP = (PASS == 1) ? ((NS >= 4 * NR) ? NS / (2 * NR) : 0)
-                                          : ((NS >= 2 * NR) ? NS / NR : 0);     // MFMAs between rounds
+        constexpr int NRT = NR0 + NR1;
+        constexpr int DSTEP = (NS >= 2 * NRT) ? NS / NRT : 0;                   // MFMAs between rounds
         double ar[PD];
 #pragma unroll
-        for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTH)) * RSH + 16 * (s % KTH)];
-        if (DSTEP == 0) {
+        for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTG)) * RSG + 16 * (s % KTG)];
+        auto round = [&](const int j) {
+            if (j < NR0)
+                pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
+            else
+                pgl_dma_round<KTH>(g1, l1, j - NR0, wave, lane);
+        };
+        if (DSTEP == 0 && dma) {
 #pragma unroll
-            for (int j = 0; j < 2 * NR; ++j)
-                if (j < nrounds) pgl_dma_round<KTH>(j < NR ? g0 : g1, j < NR ? l0 : l1, j % NR, wave, lane);
+            for (int j = 0; j < NRT; ++j) round(j);
         }
         const int phase = (wave < 4) ? ((DSTEP > 1) ? DSTEP / 2 - 1 : 0) : DSTEP - 1;
+        if (PGL_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            if (PGL_PRIO && s == NS / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             const double a = ar[s % PD];
-            if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTH)) * RSH + 16 * ((s + PD) % KTH)];
-            G[s % KTH] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTH], G[s % KTH], 0, 0, 0);
+            if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG)];
+            G[s % KTG] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTG], G[s % KTG], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             if (DSTEP > 0) {
                 constexpr int DS = (DSTEP > 0) ? DSTEP : 1;
                 const int j = s / DS;
                 const int ph = s % DS;
-                if ((ph == DS - 1 || (DS > 1 && ph == DS / 2 - 1)) && j < 2 * NR) {
-                    if (ph == phase && j < nrounds) {
-                        pgl_dma_round<KTH>(j < NR ? g0 : g1, j < NR ? l0 : l1, j % NR, wave, lane);
-                    }
+                if ((ph == DS - 1 || (DS > 1 && ph == DS / 2 - 1)) && j < NRT) {
+                    if (ph == phase && dma) round(j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1355,16 +1576,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 
     if constexpr (PASS == 1) {
         double ll_acc = 0.0, gb_acc = 0.0;
-        const double bias_l = valid_n ? p.bias[nloc] : 0.0;
+        // padding lanes (neurons >= npost) get a benign current: they must not push their wave out of
+        // the epilogue's series regime; nothing they produce is ever read
+        const double bias_l = valid_n ? p.bias[nloc] : (p.nlin == 1 ? 30.0 : 0.0);
         const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS_ALL * 64;
+        double* const wscratch = reinterpret_cast<double*>(smem + 2 * IMGL + IMGH + 256) + wave * 192;   // spike compaction
         // prologue: L and H of the first tile
         if (tile_beg < tile_end) {
-            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 0) * IMG, buf0, wave, lane);
-            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 1) * IMG, buf1, wave, lane);
+            pgl_dma_half<KTL>(fimg + (size_t)tile_beg * IMGS, buf0, wave, lane);
+            pgl_dma_half<KTH>(fimg + (size_t)tile_beg * IMGS + IMGL, buf1, wave, lane);
         }
         // spike counts of this lane's four elements (rows grp + 4r of neuron nglob): requested one tile
-        // ahead, together with the DMAs -- issued at the head of a tile these byte loads (HBM misses)
-        // sit in front of the Wmat ring in the in-order vmcnt queue and delay every forward pass
+        // ahead -- issued at the head of a tile these byte loads (HBM misses) would sit in front of the
+        // Wmat ring in the in-order vmcnt queue and delay every forward pass
         unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
         auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
 #pragma unroll
@@ -1386,12 +1610,12 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             const bool more = tile + 1 < tile_end;
 #pragma unroll
             for (int r = 0; r < 4; ++r) scb[r] = scn[r];
-            // ---- forward over both halves ----
+            // ---- forward over both parts ----
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
             constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
             if (active && !(p.dbg & 8)) {
-                const double* faL = reinterpret_cast<const double*>(Lb) + col * RSH + grp;
+                const double* faL = reinterpret_cast<const double*>(Lb) + col * RSL + grp;
                 const double* faH = reinterpret_cast<const double*>(buf1) + col * RSH + grp;
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
@@ -1402,13 +1626,15 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 #pragma unroll
                 for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
 #pragma unroll
-                for (int s = 0; s < PA; ++s) ar[s] = (s < KSH) ? faL[4 * s] : faH[4 * (s - KSH)];
+                for (int s = 0; s < PA; ++s) ar[s] = (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
+                if (PGL_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int s = 0; s < KS_ALL; ++s) {
+                    if (PGL_PRIO && s == KS_ALL / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
                     const double a = ar[s % PA];
                     const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
                     if (s + PA < KS_ALL)
-                        ar[s % PA] = (s + PA < KSH) ? faL[4 * (s + PA)] : faH[4 * (s + PA - KSH)];
+                        ar[s % PA] = (s + PA < KSL) ? faL[4 * (s + PA)] : faH[4 * (s + PA - KSL)];
                     if ((s & 1) && (s / 2 + PW2 < KS_ALL / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
                     if (s & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
@@ -1419,39 +1645,60 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             }
             PGL_PROF_MARK(0);
             const bool do_bwd = active && p.want_grad && !(p.dbg & 16);
-            // ---- epilogue on the accumulator registers, PGL_ENE elements at a time ----
+            // every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The barrier also
+            // lines the waves up for the epilogue.
+            __syncthreads();
+            PGL_PROF_MARK(2);
+            // ---- epilogue on the accumulator registers ----
             double rr[4];
             if (active) {
-                constexpr int ENE = PGL_ENE;
+                bool done = false;
+                if (PGL_ENE == 4 && !(p.dbg & 4) && (long long)t0 + TT <= p.t_hi) {
+                    // whole tile inside the evaluated range: four elements at a time, fixed order
+                    double xs[4], term4 = 0.0;
 #pragma unroll
-                for (int h2 = 0; h2 < 4 / ENE; ++h2) {
-                    double xe[ENE], se[ENE], terme[ENE], rese[ENE];
-                    bool vte[ENE];
+                    for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
+                    const double* cg = PGL_C;
+                    asm volatile("" : "+s"(cg));           // keeps the scalar loads inside the tile loop
+                    done = pgl_rate4(xs, scb, p.nlin, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
+                    if (done) {
+                        ll_acc += term4;                    // lanes of padding neurons are never read back
 #pragma unroll
-                    for (int e = 0; e < ENE; ++e) {
-                        const int r = ENE * h2 + e;
-                        xe[e] = bias_l + (acc0[r] + acc1[r]);
-                        se[e] = (double)scb[r];
-                        const long long tg = (long long)t0 + grp + 4 * r;
-                        vte[e] = valid_n && (tg < p.t_hi);
+                        for (int r = 0; r < 4; ++r) gb_acc += rr[r];
                     }
-                    if (p.dbg & 4) {
+                }
+                constexpr int ENE = (PGL_ENE == 4) ? 2 : PGL_ENE;
+                if (!done) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 4 / ENE; ++h2) {
+                        double xe[ENE], se[ENE], terme[ENE], rese[ENE];
+                        bool vte[ENE];
 #pragma unroll
                         for (int e = 0; e < ENE; ++e) {
-                            terme[e] = xe[e] * se[e];
-                            rese[e] = xe[e] - se[e];
+                            const int r = ENE * h2 + e;
+                            xe[e] = bias_l + (acc0[r] + acc1[r]);
+                            se[e] = (double)scb[r];
+                            const long long tg = (long long)t0 + grp + 4 * r;
+                            vte[e] = valid_n && (tg < p.t_hi);
                         }
-                    } else {
-                        pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
-                        asm volatile("" : "+v"(Cl));
-                        pgl_rate_terms_n<ENE>(xe, se, p.nlin, p.dt, terme, rese, Cl);
-                    }
+                        if (p.dbg & 4) {
 #pragma unroll
-                    for (int e = 0; e < ENE; ++e) {
-                        const double res = vte[e] ? rese[e] : 0.0;
-                        rr[ENE * h2 + e] = res;
-                        ll_acc += vte[e] ? terme[e] : 0.0;
-                        gb_acc += res;
+                            for (int e = 0; e < ENE; ++e) {
+                                terme[e] = xe[e] * se[e];
+                                rese[e] = xe[e] - se[e];
+                            }
+                        } else {
+                            pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                            asm volatile("" : "+v"(Cl));
+                            pgl_rate_terms_n<ENE>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                        }
+#pragma unroll
+                        for (int e = 0; e < ENE; ++e) {
+                            const double res = vte[e] ? rese[e] : 0.0;
+                            rr[ENE * h2 + e] = res;
+                            ll_acc += vte[e] ? terme[e] : 0.0;
+                            gb_acc += res;
+                        }
                     }
                 }
             } else {
@@ -1459,24 +1706,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 for (int r = 0; r < 4; ++r) rr[r] = 0.0;
             }
             PGL_PROF_MARK(1);
-            // The barrier that frees H_i (buf1) for the next tile's DMA sits behind the epilogue, not
-            // in front of it: the epilogue touches no feature buffer, and the older wave of a SIMD
-            // (which wins the MFMA arbitration and leaves the forward loop first) then runs its VALU
-            // chains in the gaps of its partner's last forward MFMAs instead of idling at the barrier.
-            __syncthreads();                              // every wave is done with H_i (buf1)
-            PGL_PROF_MARK(2);
+            if (PGL_EBAR) __syncthreads();                // both epilogues of a SIMD end before any backward MFMA
             if (more) load_counts(tile + 1, scn);         // retired by the closing vmcnt(0) of this tile
-            if (more && !do_bwd) {
-                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln, wave, lane);
-                pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, wave, lane);
+            if (!do_bwd && more) {
+                pgl_dma_half<KTL>(fimg + (size_t)(tile + 1) * IMGS, Ln, wave, lane);
+                pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, wave, lane);
             }
             PGL_PROF_MARK(3);
-            if (do_bwd) {                                 // H_{i+1} (over H_i) goes out between the MFMAs
+            if (do_bwd) {                                 // L_{i+1}, H_{i+1} go out between the MFMAs
                 double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
-                bwd_half(Lb, rr, fimg + ((size_t)(tile + 1) * 2 + 0) * IMG, Ln,
-                         fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, buf1, more ? 2 * NR : 0);
+                bwd_half(Lb, rr, fimg + (size_t)(tile + 1) * IMGS, Ln,
+                         fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, more);
             }
             PGL_PROF_MARK(4);
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
@@ -1493,7 +1735,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         if (active && p.want_grad) {
             double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL) * 256 + lane;
 #pragma unroll
-            for (int kt = 0; kt < KTH; ++kt) {
+            for (int kt = 0; kt < KTL; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
             }
@@ -1502,7 +1744,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         // =============================== pass 2 ===============================
         double rv[4] = {0.0, 0.0, 0.0, 0.0}, rn[4] = {0.0, 0.0, 0.0, 0.0};
         if (tile_beg < tile_end) {
-            pgl_dma_half<KTH>(fimg + ((size_t)tile_beg * 2 + 1) * IMG, buf0, wave, lane);
+            pgl_dma_half<KTH>(fimg + (size_t)tile_beg * IMGS + IMGL, buf0, wave, lane);
             if (active) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
@@ -1522,19 +1764,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             const bool more = tile + 1 < tile_end;
             const bool do_bwd = active && !(p.dbg & 16);
             if (more) {
-                if (!do_bwd) pgl_dma_half<KTH>(fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, wave, lane);
+                if (!do_bwd) pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, Hn, wave, lane);
                 if (active) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
                 }
             }
             PGL_PROF_MARK(2);
-            if (do_bwd) bwd_half(Hb, rv, fimg + ((size_t)(tile + 1) * 2 + 1) * IMG, Hn, nullptr, nullptr, more ? NR : 0);
+            if (do_bwd) bwd_half(Hb, rv, fimg + (size_t)(tile + 1) * IMGS + IMGL, Hn, nullptr, nullptr, more);
             PGL_PROF_MARK(3);
         }
         PGL_PROF_STORE(2);
         if (active) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTH) * 256 + lane;
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTL) * 256 + lane;
 #pragma unroll
             for (int kt = 0; kt < KTH; ++kt) {
 #pragma unroll

@@ -20,17 +20,20 @@ for i in range(4):
     ll, g = dev.ll_grad(p.theta, p.Weff)
     print("fused %.3f ms" % dev.last_timing()[0])
 lib = _lib.load()
-buf = np.zeros((2, 4096, 8, 8), dtype=np.int64)
+buf = np.zeros((2, 4096, 8, 12), dtype=np.int64)
 lib.pgl_debug_prof.argtypes = [C.c_void_p, C.c_int]
 rc = lib.pgl_debug_prof(buf.ctypes.data_as(C.c_void_p), buf.size)
 assert rc == 0
 nblk = int(info['blocks'])
 tiles = (nT + 15) // 16 / info['chunks']
-names1 = ['fwd', 'epilogue', 'barrier1', 'counts', 'r store+bwd', 'vmcnt(0)', 'barrier2']
+names1 = ['fwd', 'epi tail', 'barrier1', 'barrier1b+counts', 'r store+bwd', 'vmcnt(0)', 'barrier2', 'epi exp', 'epi series', 'epi spikes']
 names2 = ['vmcnt(0)', 'barrier', 'dma issue', 'bwd']
 for ps, names in ((0, names1), (1, names2)):
     d = buf[ps, :nblk - 1].astype(float) / tiles          # last chunk is short
-    tot = d.sum(axis=2)
+    tot = d[:, :, :10].sum(axis=2)
+    cyc, rt = buf[ps, :nblk - 1, :, 10].astype(float), buf[ps, :nblk - 1, :, 11].astype(float)
+    print("pass %d: shader clock over the tile loop %.3f GHz (s_memtime / s_memrealtime at 100 MHz), loop %.3f ms"
+          % (ps + 1, (cyc / rt).mean() * 0.1, rt.mean() / 1e5))
     print("pass %d: cycles per tile and wave (mean over %d workgroups; total %.0f)" % (ps + 1, nblk - 1, tot.mean()))
     for i, nm in enumerate(names):
         print("  %-12s mean %8.0f   waves0-3 %8.0f  waves4-7 %8.0f   min %8.0f max %8.0f"
