@@ -140,30 +140,49 @@ def map_wall_clock(S, N, dt):
 
 
 def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
-    """Oracle C port (oracle/glm_oracle.c: the reference's per-neuron dataflow on
-    materialised features) timed single-threaded on a bounded sample: the first
-    `sample_bins` bins of the same spike matrix, all neurons; cost is linear in nT."""
+    """CPU baselines of BASELINE.md section 3 on the host cores of this box, all on a bounded sample
+    (the first `sample_bins` bins of the same spike matrix, all neurons; cost is linear in nT):
+      B1  oracle/glm_oracle.c: the reference's per-neuron dataflow on materialised features (N passes
+          over fS per evaluation), single thread = `value`; the same with OpenMP over neurons;
+      B2  oracle/glm_blocked.c: all neurons in one time-tiled sweep over fS (F.W, rate epilogue and
+          F^T r per tile; fS streamed once), OpenMP over time blocks on all cores -- the strong baseline;
+      set_data: the copy of (fS, S) into the model's shared variables that the reference performs
+          before EVERY evaluation (glm.py:99-110 via coord_descent.py:52-57), timed alone."""
     from oracle import c_oracle as CO
     nT, N = S.shape
+    scale = nT / float(sample_bins)
     Ss = np.ascontiguousarray(S[:sample_bins])
     fS = CO.features(Ss, ibasis)
-    n_sub = N                               # single-thread leg: every neuron
     t0 = time.time()
-    CO.ll_grad(Ss, fS, theta[:n_sub], Weff, 'explinear', dt, 0, n_sub, threads=1)
-    t1 = time.time() - t0
-    per_eval_1 = t1 * (N / float(n_sub)) * (nT / float(sample_bins))
+    CO.ll_grad(Ss, fS, theta, Weff, 'explinear', dt, 0, N, threads=1)
+    per_eval_1 = (time.time() - t0) * scale
     cores = os.cpu_count() or 1
     t0 = time.time()
     CO.ll_grad(Ss, fS, theta, Weff, 'explinear', dt, threads=cores)
-    tm = time.time() - t0
-    per_eval_m = tm * (nT / float(sample_bins))
+    per_eval_m = (time.time() - t0) * scale
+    CO.ll_grad_blocked(Ss[:20000], fS[:20000], theta, Weff, 'explinear', dt, threads=cores)   # thread pool warm-up
+    t0 = time.time()
+    CO.ll_grad_blocked(Ss, fS, theta, Weff, 'explinear', dt, threads=cores)
+    per_eval_b2 = (time.time() - t0) * scale
+    t0 = time.time()
+    CO.ll_grad_blocked(Ss[:sample_bins // 8], fS[:sample_bins // 8], theta, Weff, 'explinear', dt, threads=1)
+    per_eval_b2_1 = (time.time() - t0) * scale * 8
+    copy_s = CO.set_data_copy_seconds(fS, Ss.astype(np.float64)) * scale
     return {
         "value": 1.0 / per_eval_1, "unit": "evals/s", "cores": 1, "kind": "port",
-        "sample": "first %d of %d bins, %d of %d neurons, scaled linearly; C restatement of the "
+        "sample": "first %d of %d bins, all %d neurons, scaled linearly; B1 = C restatement of the "
                   "reference per-neuron dataflow on materialised fS (oracle/glm_oracle.c)"
-                  % (sample_bins, nT, n_sub, N),
+                  % (sample_bins, nT, N),
         "all_cores": {"value": 1.0 / per_eval_m, "cores": cores,
-                      "sample": "first %d bins, all neurons, OpenMP over neurons" % sample_bins},
+                      "sample": "B1, first %d bins, all neurons, OpenMP over neurons" % sample_bins},
+        "b2_blocked": {"value": 1.0 / per_eval_b2, "cores": cores, "single_core_value": 1.0 / per_eval_b2_1,
+                       "sample": "B2 = all neurons in one time-tiled sweep over fS, fused rate epilogue, "
+                                 "OpenMP over time blocks (oracle/glm_blocked.c); first %d bins "
+                                 "(single core: first %d)" % (sample_bins, sample_bins // 8)},
+        "set_data_copy": {"seconds_per_eval": copy_s, "bytes_per_eval": float(nT) * N * (ibasis.shape[1] + 1) * 8,
+                          "note": "the reference copies fS and S into Theano shared variables before every "
+                                  "nlp / grad_nlp call (glm.py:99-110); one memcpy thread, scaled from the sample; "
+                                  "not included in the figures above"},
     }
 
 
@@ -182,12 +201,20 @@ def main():
     ap.add_argument('--debug-single-device', action='store_true')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Build (if stale) BEFORE torch or anything else touches the GPU: a compiler child must never be
+    # spawned from a process that has initialised HIP, least of all under rocprofv3 (build_hip raises
+    # when the library is stale under a profiler and scrubs the preload variables otherwise).
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_hip()
+        if not args.no_cpu_baseline and world == 1:
+            ge.build_oracle()
+
+    import torch
+    import torch.distributed as dist
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n"
@@ -200,11 +227,8 @@ def main():
         dist.init_process_group('gloo' if args.debug_single_device else 'nccl', rank=rank,
                                 world_size=world)
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build_hip()
     if world > 1:
-        dist.barrier()
+        dist.barrier()                       # rank 0 has finished building
     from theano_pyglm_amd import _lib
 
     N, dt = args.neurons, 0.001
@@ -233,6 +257,11 @@ def main():
         n_lo, n_hi = PL.shard_bounds(N, rank, world)
         t_lo, t_hi = 0, nT
 
+    # A dedicated non-default stream is made current for everything below: torch's default stream
+    # has handle 0 (the NULL stream), which pgl_set_stream cannot name -- kernels would silently run on
+    # the handle's own stream, un-ordered with the RCCL collectives.
+    bench_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(bench_stream)
     d_theta = torch.from_numpy(theta[n_lo:n_hi].copy()).cuda()
     d_Weff = torch.from_numpy(Weff).cuda()
     # one contiguous block [ll | grad] so that a single all-reduce moves both
@@ -249,7 +278,8 @@ def main():
     # ordered against -- so evaluation k, its all-reduce and evaluation k+1 serialise on the GPU
     # without a host synchronisation per step.  Every launch records its own HIP event set on
     # that stream; the mean kernel duration over the timed region is read back after the loop.
-    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert torch.cuda.current_stream().cuda_stream == bench_stream.cuda_stream != 0
+    dev.set_stream(bench_stream.cuda_stream)
 
     def step(record):
         dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr(),
@@ -311,6 +341,17 @@ def main():
     achieved = info['flops'] / (kern_ms * 1e-3) / 1e12
     ll_host = d_ll.cpu().numpy()
     assert np.all(np.isfinite(ll_host)), "non-finite ll"
+    if world > 1:
+        # the sharded evaluation must equal the single-rank evaluation of the whole recording
+        if args.shard == 'time':
+            ll_pop = ll_host                                   # all-reduced: full ll of all N neurons
+        else:
+            ll_pop = np.concatenate([g.cpu().numpy() for g in gather])
+        if rank == 0:
+            dev.set_time_range(0, nT)
+            ll_ref, _ = dev.ll_grad(theta, Weff, 0, N, want_grad=False)
+            assert np.allclose(ll_pop, ll_ref, rtol=1e-10, atol=0), \
+                "sharded population ll differs from the single-rank evaluation"
 
     if rank == 0:
         out = {

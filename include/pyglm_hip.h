@@ -45,8 +45,11 @@ typedef struct pgl_context* pgl_handle;
 /* flags for pgl_set_option */
 #define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
 #define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
-#define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel for >= 65 post-synaptic neurons per call,
-                                * 8-wave K-split kernel otherwise;
+#define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel on resident tiles for >= 65 post-synaptic neurons per call;
+                                * below that the K-split kernel, on resident feature tiles (6) when the
+                                * feature row is short enough for two LDS step buffers (N*B + Dstim up to
+                                * ~320-450 columns depending on the post block), else with in-kernel
+                                * feature generation (2);  6 = force the resident K-split kernel when it fits;
                                 * 2 = force the K-split kernel; 3 = force the two-pass kernel with
                                 * on-the-fly features; 4 = force the two-pass kernel on resident feature
                                 * tiles.  Auto uses 4's kernel (k_fused5) when the call covers >= 65
@@ -107,6 +110,11 @@ int pgl_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* theta,
 /* Same with device pointers, asynchronous on the handle's stream; pair with pgl_sync. */
 int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
                     const double* d_Weff, double* d_ll, double* d_grad);
+/* The same for an arbitrary list of post-synaptic neurons: d_idx[j] (device, int32, distinct) is the
+ * neuron of row j of d_theta / d_ll / d_grad.  Lets a lock-step optimiser evaluate only the neurons
+ * whose line search is still running (the reference fits one neuron per call, coord_descent.py:161-204). */
+int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double* d_theta,
+                         const double* d_Weff, double* d_ll, double* d_grad);
 int pgl_sync(pgl_handle h);
 
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
@@ -141,6 +149,26 @@ int pgl_gibbs_ll(pgl_handle h, int n_pre, double aw_cur, const double* w, int K,
 /* After A[n_pre,n_post]*W[n_pre,n_post] changed by `delta` (gibbs.py:1044-1066 writes the
  * new sample into the state dict): I_net += delta * I_imp[:,n_pre] on the device. */
 int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
+
+/* The same collapsed-Gibbs inner loop for MANY columns per launch.  Given the rest of the state the
+ * columns (A[:,n], W[:,n]) are conditionally independent -- the reference maps them over its engines
+ * (parallel_gibbs.py:162-165, concatenate_parallel_updates 24-37) -- so one call serves one
+ * (n_pre, n_post) pair of every listed column.
+ *   prepare_all: theta (N,P) flat feature weights of all neurons, Weff (N,N); computes the total
+ *     current I_stim + I_net of every post-synaptic neuron once (forward-only MFMA pass,
+ *     gibbs.py:812-833 for all n_post) and keeps it, with theta, on the device.  Honours
+ *     pgl_set_time_range (ll sums then run over [t_lo, t_hi)).
+ *   ll_cols: for column c: n_post[c], n_pre[c], aw_cur[c] = current A*W of the pair, w[c*K .. c*K+K)
+ *     candidate weights (K <= 16, e.g. the 10 Gauss-Hermite nodes + w = 0, gibbs.py:1002-1032);
+ *     ll_out[c*K + k] as pgl_gibbs_ll.  The impulse weights of the pair are theta[n_post][1+Dstim+n_pre*B ..].
+ *   update_cols: after A*W of pair c changed by delta[c]: I_net[:, n_post[c]] += delta[c]*I_imp (n_post distinct).
+ *   currents: copy out bias-free total current I_stim + I_net of one neuron over the prepared range. */
+int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff);
+int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre,
+                      const double* aw_cur, const double* w, int K, double* ll_out);
+int pgl_gibbs_update_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre,
+                          const double* delta);
+int pgl_gibbs_currents(pgl_handle h, int n_post, double* x_out);
 
 /* Spike-triggered average, pyglm/utils/sta.py:6-85 (used by smart_init.py:28-98 and 100-158):
  *   A[i,l,d] = sum_t S[t,n_i] * istim[t-l,d] / sum_t S[t,n_i],  l = 0..L-1, terms with t-l < 0 dropped,
@@ -190,7 +218,7 @@ int pgl_set_stream(pgl_handle h, void* stream);
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),
  * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins), [9]=kernel the call would use
  * (1 4-wave, 2 K-split, 3 K-split with f32 features, 4 two-pass, 5 two-pass on resident feature
- * tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
+ * tiles, 6 K-split on resident feature tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
  * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab). */
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info);
 

@@ -13,7 +13,8 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        srcs = [os.path.join(_HERE, f) for f in ('glm_oracle.c', 'glm_blocked.c', 'Makefile')]
+        if not os.path.exists(_SO) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
             subprocess.check_call(['make', '-s', '-C', _HERE])
         _lib = C.CDLL(_SO)
         _lib.oracle_ll_grad_neuron.restype = C.c_double
@@ -56,3 +57,37 @@ def ll_grad(S_u8, fS, theta, Weff, kind, dt, n_lo=0, n_hi=None, fstim=None, thre
                        C.c_int(1 if kind == 'explinear' else 0), C.c_double(dt), _p(ll), _p(g),
                        C.c_int(threads))
     return ll, g
+
+
+def ll_grad_blocked(S_u8, fS, theta, Weff, kind, dt, fstim=None, threads=1, want_grad=True):
+    """B2: all neurons in one time-tiled sweep over fS (oracle/glm_blocked.c), OpenMP over time."""
+    lib = load()
+    S = np.ascontiguousarray(S_u8, dtype=np.uint8)
+    nT, N = S.shape
+    B = fS.shape[2]
+    Dstim = 0 if fstim is None else fstim.shape[1]
+    P = 1 + Dstim + N * B
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    assert th.shape == (N, P)
+    We = np.ascontiguousarray(Weff, dtype=np.float64)
+    fS = np.ascontiguousarray(fS, dtype=np.float64)
+    fst = None if fstim is None else np.ascontiguousarray(fstim, dtype=np.float64)
+    ll = np.empty(N)
+    g = np.empty((N, P)) if want_grad else None
+    lib.oracle_ll_grad_blocked(_p(S), C.c_int64(nT), C.c_int(N), C.c_int(B), _p(fS), _p(fst),
+                               C.c_int(Dstim), _p(th), _p(We), C.c_int(1 if kind == 'explinear' else 0),
+                               C.c_double(dt), _p(ll), _p(g), C.c_int(threads))
+    return ll, g
+
+
+def set_data_copy_seconds(fS, S_f64):
+    """Seconds one Glm.set_data copy of (fS, S) takes (glm.py:99-110), single thread."""
+    import time
+    lib = load()
+    fS = np.ascontiguousarray(fS, dtype=np.float64)
+    Sf = np.ascontiguousarray(S_f64, dtype=np.float64)
+    dst = np.empty(fS.size + Sf.size)
+    lib.oracle_set_data_copy(_p(fS), C.c_size_t(fS.size), _p(Sf), C.c_size_t(Sf.size), _p(dst))   # first touch
+    t0 = time.perf_counter()
+    lib.oracle_set_data_copy(_p(fS), C.c_size_t(fS.size), _p(Sf), C.c_size_t(Sf.size), _p(dst))
+    return time.perf_counter() - t0

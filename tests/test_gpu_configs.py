@@ -1,0 +1,428 @@
+"""
+Every BASELINE.json configuration at its OWN size on the GPU (C1 ... C5; C3's properties live in
+test_gpu_kernels.test_full_size_properties_c3).  At full size the oracle is too slow for the whole
+recording, so each test combines
+  * size-independent properties of the device path (ll-only == ll+grad, chunk / time-shard additivity,
+    directional derivative, two independent device implementations agreeing), and
+  * oracle parity on a time sub-range of the SAME full-size handle (features depend on the past only,
+    pgl_set_time_range restricts the sums), or on the whole recording where the oracle is fast (C1).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import glm_oracle as O
+from tests import helpers as H
+from tests.test_gpu_population import oracle_log_p
+from theano_pyglm_amd import _lib
+from theano_pyglm_amd import parallel as PL
+from theano_pyglm_amd.harness.generate_synth_data import make_dataset
+from theano_pyglm_amd.inference import gibbs as G
+from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity
+from theano_pyglm_amd.population import Population
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL, G_RTOL = 1e-10, 1e-9
+
+
+def _full_size_properties(p, dev, nsub, neurons, shards=8):
+    """Shared body of the C2 / C5 full-size tests (same checks as the C3 test)."""
+    rng = np.random.default_rng(5)
+    nT = p.nT
+    ll, g = dev.ll_grad(p.theta, p.Weff)
+    assert np.all(np.isfinite(ll)) and np.all(np.isfinite(g))
+    ll_only, _ = dev.ll_grad(p.theta, p.Weff, want_grad=False)
+    assert np.array_equal(ll, ll_only)
+    dev.set_option(_lib.OPT_NCHUNKS, 61)
+    ll_c, g_c = dev.ll_grad(p.theta, p.Weff)
+    dev.set_option(_lib.OPT_NCHUNKS, 0)
+    assert np.allclose(ll_c, ll, rtol=1e-12) and H.rel_err(g_c, g) < 1e-11
+    ll_s, g_s = 0.0, 0.0
+    for r in range(shards):
+        lo, hi = PL.time_shard_bounds(nT, r, shards)
+        dev.set_time_range(lo, hi)
+        a, b = dev.ll_grad(p.theta, p.Weff)
+        ll_s, g_s = ll_s + a, g_s + b
+    dev.set_time_range(0, nT)
+    assert np.allclose(ll_s, ll, rtol=1e-12) and H.rel_err(g_s, g) < 1e-11
+    d = rng.standard_normal(p.theta.shape)
+    eps = 1e-6
+    lp, _ = dev.ll_grad(p.theta + eps * d, p.Weff, want_grad=False)
+    lm, _ = dev.ll_grad(p.theta - eps * d, p.Weff, want_grad=False)
+    fd = (lp - lm) / (2 * eps)
+    an = np.sum(g * d, axis=1)
+    assert np.max(np.abs(fd - an)) < 1e-5 * np.max(np.abs(an))
+    # oracle on the first nsub bins
+    dev.set_time_range(0, nsub)
+    q = H.Problem(p.N, nsub, p.ibasis, kind=p.kind, seed=0, Dstim=0)
+    q.S, q.theta, q.Weff, q._fS, q.Dstim, q.P = p.S[:nsub], p.theta, p.Weff, None, p.Dstim, p.P
+    q.fstim = None if p.fstim is None else p.fstim[:nsub]
+    for n in neurons:
+        a, b = dev.ll_grad(p.theta[n:n + 1], p.Weff, n, n + 1)
+        a0, b0 = q.oracle_ll_grad(n, n + 1)
+        assert np.allclose(a, a0, rtol=LL_RTOL) and H.rel_err(b, b0) < G_RTOL
+    # ... and of a whole block of neurons in one call (the batched kernel's own shape)
+    a, b = dev.ll_grad(p.theta, p.Weff)
+    for n in neurons:
+        a0, b0 = q.oracle_ll_grad(n, n + 1)
+        assert np.allclose(a[n], a0[0], rtol=LL_RTOL) and H.rel_err(b[n], b0[0]) < G_RTOL
+    dev.set_time_range(0, nT)
+
+
+def test_c2_full_size():
+    """BASELINE config C2: standard_glm N=32, T=300 s (nT = 300 000), ll+grad."""
+    p = H.Problem(32, 300000, H.std_ibasis(), seed=1234 + 2, w_scale=0.5)
+    dev = p.device()
+    _full_size_properties(p, dev, 24000, (0, 17, 31))
+    dev.close()
+
+
+def test_c5_full_size_device_built_stimulus():
+    """BASELINE config C5: spatiotemporal_glm N=64, T=300 s, D_stim=3: exp nonlinearity, B=3, R=300,
+    the 9 stimulus feature columns built on the device from the raw (3000, 3) stimulus (K11/K12)."""
+    from theano_pyglm_amd.models.model_factory import make_model
+    N, nT = 64, 300000
+    popn = Population(make_model('spatiotemporal_glm', N=N, dt=0.001))
+    bk = popn.glm.bkgd_model
+    rng = np.random.RandomState(1234 + 5)
+    stim = rng.randn(nT // 100, 3)
+    p = H.Problem(N, nT, popn.glm.imp_model.ibasis, kind='exp', seed=1234 + 5, Dstim=0, w_scale=0.02)
+    dev = p.device()
+    dev.set_stimulus(stim, 0.1, bk.ibasis_t, bk.ibasis_x, layout=0)
+    assert dev.Dstim == 9
+    nsub = 20000
+    fst = dev.get_stim_features()
+    ref = O.spatiotemporal_stim_features(stim, 0.1, 0.001, nsub, bk.ibasis_x, bk.ibasis_t)
+    assert np.max(np.abs(fst[:nsub] - ref)) < 1e-11
+    # far end of the recording too (interpolation clamps at the last stimulus frame)
+    tail = O.spatiotemporal_stim_features(stim, 0.1, 0.001, nT, bk.ibasis_x, bk.ibasis_t)[-4000:]
+    assert np.max(np.abs(fst[-4000:] - tail)) < 1e-11
+    # flat feature weights [bias, w_stim(9), w_ir]
+    P = 1 + 9 + N * 3
+    theta = np.zeros((N, P))
+    theta[:, 0] = p.theta[:, 0]
+    theta[:, 1:10] = 0.1 * rng.randn(N, 9)
+    theta[:, 10:] = p.theta[:, 1:]
+    p.theta, p.P, p.Dstim, p.fstim = theta, P, 9, fst
+    assert dev.info()['ktiles'] in (13, 14)                  # 64*3 + 9 = 201 columns (padded per kernel)
+    _full_size_properties(p, dev, nsub, (0, 33, 63))
+    dev.close()
+
+
+def test_c5_stress_wide_stimulus_reduced_T():
+    """C5 stress variant at reduced T: D_stim = 1024 pixels, identity spatial basis, Bt = 3 ->
+    3072 stimulus columns + 192 impulse columns through the sliced path, N = 64."""
+    from theano_pyglm_amd.models import templates
+    N, nT = 64, 6000
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = 1024
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': 1024}
+    popn = Population(make_model(tmpl, N=N, dt=0.001))
+    bk = popn.glm.bkgd_model
+    rng = np.random.RandomState(55)
+    stim = rng.randn(nT // 100, 1024)
+    p = H.Problem(N, nT, popn.glm.imp_model.ibasis, kind='exp', seed=56, Dstim=0, w_scale=0.02)
+    dev = p.device()
+    dev.set_stimulus(stim, 0.1, bk.ibasis_t, None, layout=0)
+    assert dev.Dstim == 3072
+    fst = dev.get_stim_features()
+    ref = O.spatiotemporal_stim_features(stim, 0.1, 0.001, nT, np.eye(1024), bk.ibasis_t)
+    assert np.max(np.abs(fst - ref)) < 1e-11
+    P = 1 + 3072 + N * 3
+    theta = np.zeros((N, P))
+    theta[:, 0] = p.theta[:, 0]
+    theta[:, 1:3073] = 0.01 * rng.randn(N, 3072)
+    theta[:, 3073:] = p.theta[:, 1:]
+    p.theta, p.P, p.Dstim, p.fstim = theta, P, 3072, ref
+    ll, g = dev.ll_grad(p.theta, p.Weff)
+    for n in (0, 40, 63):
+        a0, b0 = p.oracle_ll_grad(n, n + 1)
+        assert np.allclose(ll[n], a0[0], rtol=LL_RTOL) and H.rel_err(g[n], b0[0]) < 1e-8
+    dev.close()
+
+
+def test_explinear_mixed_regimes_in_one_wave():
+    """explinear epilogue with currents spanning [-30, 30] inside every wave (lanes of one MFMA tile
+    are 16 different neurons): series lanes (|x| > 9.25) and full log1p lanes side by side, x
+    crossing 0, through every kernel family."""
+    N = 16
+    for kern in (2, 3, 4, 6):
+        p = H.Problem(N, 3000, H.std_ibasis(), seed=40, rate_hz=40.0, w_scale=0.3)
+        p.theta[:, 0] = np.linspace(-30.0, 30.0, N)
+        p.theta[5, 0], p.theta[6, 0] = -0.2, 0.2              # straddle 0 with the impulse currents on top
+        ll0, g0 = p.oracle_ll_grad()
+        x = p.theta[:, 0][None, :] + np.einsum('tkb,nkb->tn', p.fS, p.theta[:, 1:].reshape(N, N, p.B))
+        assert x.min() < -25 and x.max() > 25 and np.any((x[:, 5] < 0)) and np.any((x[:, 5] > 0))
+        d = p.device()
+        d.set_option(_lib.OPT_KERNEL, kern)
+        ll, g = d.ll_grad(p.theta, p.Weff)
+        assert np.allclose(ll, ll0, rtol=LL_RTOL), kern
+        assert H.rel_err(g, g0) < G_RTOL, kern
+        d.close()
+    # the MCMC inner-ll kernels on the same mixture (both device implementations)
+    p = H.Problem(N, 3000, H.std_ibasis(), seed=41, rate_hz=40.0, w_scale=0.3, weighted=True)
+    p.theta[:, 0] = np.linspace(-30.0, 30.0, N)
+    d = p.device()
+    d.gibbs_prepare_all(p.theta, p.Weff)
+    cols = np.arange(N)
+    pre = (cols * 7 + 3) % N
+    ws = np.tile(np.linspace(-3, 3, 11), (N, 1))
+    aw = p.Weff[pre, cols]
+    got = d.gibbs_ll_cols(cols, pre, aw, ws)
+    for c in (0, 5, 8, 15):
+        w = p.theta[c, 1:].reshape(N, p.B)
+        I_imp = O.impulse_currents(p.fS, w)
+        I_other = O.other_current(I_imp, (p.Weff != 0).astype(float), p.Weff, pre[c], c)
+        ref = O.mcmc_inner_ll(ws[c], p.theta[c, 0], 0.0, I_other, I_imp[:, pre[c]], p.S[:, c].astype(float),
+                              p.dt, p.kind)
+        assert np.allclose(got[c], ref, rtol=1e-10)
+        d.gibbs_prepare(c, p.theta[c], p.Weff[:, c])
+        assert np.allclose(d.gibbs_ll(pre[c], aw[c], ws[c]), ref, rtol=1e-10)
+    d.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# C4: sparse_weighted_model ("network_glm"), N = 128, T = 600 s: the collapsed-Gibbs inner ll
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def c4():
+    N, nT = 128, 600000
+    model = make_model('sparse_weighted_model', N=N, dt=0.001)
+    stabilize_sparsity(model)
+    popn = Population(model)
+    rng = np.random.default_rng(1234 + 4)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    data = {'S': S, 'N': N, 'dt': 0.001, 'T': 600.0, 'stim': None, 'dt_stim': 0.1}
+    popn.add_data(data)
+    x = popn.sample(np.random.RandomState(4))
+    # a raw prior draw W ~ N(0, 1) drives some quadrature nodes to lam = 0 (NaN by glm.py:52, the
+    # reference's "log_G not finie"): shrink the weights like harness/synth_mcmc.py does
+    x['net']['weights']['W'] = 0.2 * np.asarray(x['net']['weights']['W'])
+    return model, popn, data, x
+
+
+def _oracle_inner_ll(popn, x, S_sub, n_pre, n_post, ws, fS=None):
+    N = popn.N
+    if fS is None:
+        fS = O.convolve_with_basis_fft(S_sub.astype(float), popn.glm.imp_model.ibasis)
+    xn = x['glms'][n_post]
+    w = popn.glm.imp_model.flat_weights(xn['imp']).reshape(N, -1)
+    I_imp = O.impulse_currents(fS, w)
+    A = np.asarray(x['net']['graph']['A'], float).reshape(N, N)
+    W = np.asarray(x['net']['weights']['W'], float).reshape(N, N)
+    I_other = O.other_current(I_imp, A, W, n_pre, n_post)
+    return O.mcmc_inner_ll(ws, popn.glm.bias_model.I_bias(xn['bias']), 0.0, I_other, I_imp[:, n_pre],
+                           S_sub[:, n_post].astype(float), popn.glm.dt, popn.glm.nlin_model.kind)
+
+
+def test_c4_inner_ll_full_size(c4):
+    model, popn, data, x = c4
+    N, nT = 128, 600000
+    h = popn._handle(data)
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+    W = np.asarray(x['net']['weights']['W'], float).reshape(N, N)
+    edges = np.argwhere((A != 0) & ~np.eye(N, dtype=bool))
+    assert len(edges) > 20                                    # rho = 0.0063 -> ~100 off-diagonal edges
+    e_pre, e_post = int(edges[0][0]), int(edges[0][1])
+    pairs = [(e_pre, e_post), (5, 5), (77, 3), (0, 127), (126, e_post)]     # an edge, a diagonal, non-edges
+    upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(1))
+    upd.preprocess(popn)
+    theta = popn.theta_matrix(x)
+    Weff = A * W
+    nodes = {}
+    for n_pre, n_post in pairs:
+        mu, sg = (upd.mu_w_ref, upd.sigma_w_ref) if n_pre == n_post else (upd.mu_w, upd.sigma_w)
+        nodes[(n_pre, n_post)] = np.concatenate((O.gauss_hermite_nodes(mu, sg)[0], [0.0]))
+    # -- full size: the single-column path (k_impulse_T + k_ll_current[_spikes]) and the batched path
+    #    (forward MFMA pass + k_gibbs_ll_cols) are independent device implementations
+    h.gibbs_prepare_all(theta, Weff)
+    cols = np.array([q for _, q in pairs])
+    pre = np.array([q for q, _ in pairs])
+    ws = np.array([nodes[pq] for pq in pairs])
+    aw = Weff[pre, cols]
+    ll_b = h.gibbs_ll_cols(cols, pre, aw, ws)
+    # outer quadrature nodes (|w| ~ 4.9) times a tall normalised impulse can push x below -745:
+    # lam == 0 and the reference expression log(0)*S is NaN (glm.py:52; gibbs.py:1012-1019 maps it to
+    # -inf) -- both device paths and the oracle must produce the same NaN pattern
+    assert np.isfinite(ll_b).mean() > 0.5 and np.all(np.isfinite(ll_b[:, -1]))
+    close = lambda a, b, rtol: np.allclose(a, b, rtol=rtol, atol=0, equal_nan=True)
+    for i, (n_pre, n_post) in enumerate(pairs):
+        h.gibbs_prepare(n_post, theta[n_post], Weff[:, n_post])
+        ll_s = h.gibbs_ll(n_pre, Weff[n_pre, n_post], ws[i])
+        assert close(ll_s, ll_b[i], 1e-11)
+        # 23 weights = two launches of <= 16 agree with separate calls
+        w23 = np.linspace(-2.0, 2.0, 23)
+        l23 = h.gibbs_ll(n_pre, Weff[n_pre, n_post], w23)
+        assert np.array_equal(l23[:16], h.gibbs_ll(n_pre, Weff[n_pre, n_post], w23[:16]), equal_nan=True)
+        assert np.array_equal(l23[16:], h.gibbs_ll(n_pre, Weff[n_pre, n_post], w23[16:]), equal_nan=True)
+        assert close(h.gibbs_ll_cols(cols[i:i + 1], pre[i:i + 1], aw[i:i + 1], w23[None, :])[0], l23, 1e-11)
+    # all 128 columns in one launch == the same pairs one at a time
+    pre_all = (np.arange(N) * 37 + 11) % N
+    ws_all = np.tile(nodes[(77, 3)], (N, 1))
+    ll_all = h.gibbs_ll_cols(np.arange(N), pre_all, Weff[pre_all, np.arange(N)], ws_all)
+    for c in (0, 64, 127):
+        one = h.gibbs_ll_cols([c], [pre_all[c]], [Weff[pre_all[c], c]], ws_all[c:c + 1])
+        assert close(one[0], ll_all[c], 1e-12)
+    # -- gibbs_update then re-prepare agree (rank-1 update of the resident currents)
+    upd_cols, upd_pre = np.array([3, e_post, 127]), np.array([77, e_pre, 0])
+    delta = np.array([0.7, -Weff[e_pre, e_post], -0.4])
+    h.gibbs_update_cols(upd_cols, upd_pre, delta)
+    W2 = Weff.copy()
+    W2[upd_pre, upd_cols] += delta
+    probe_pre = np.array([9, 126, 64])
+    ll_u = h.gibbs_ll_cols(upd_cols, probe_pre, W2[probe_pre, upd_cols], ws[:3])
+    h.gibbs_prepare_all(theta, W2)
+    ll_r = h.gibbs_ll_cols(upd_cols, probe_pre, W2[probe_pre, upd_cols], ws[:3])
+    assert close(ll_u, ll_r, 1e-11)
+    # the single-column path's update too
+    h.gibbs_prepare(3, theta[3], Weff[:, 3])
+    h.gibbs_update(77, 0.7)
+    assert close(h.gibbs_ll(9, W2[9, 3], ws[0]), ll_r[0], 1e-11)
+    # -- oracle parity on the first 24 000 bins of the full-size handle
+    nsub = 24000
+    S_sub = data['S'][:nsub]
+    fS = O.convolve_with_basis_fft(S_sub.astype(float), popn.glm.imp_model.ibasis)
+    h.set_time_range(0, nsub)
+    h.gibbs_prepare_all(theta, Weff)
+    ll_sub = h.gibbs_ll_cols(cols, pre, aw, ws)
+    for i, (n_pre, n_post) in enumerate(pairs):
+        ref = _oracle_inner_ll(popn, x, S_sub, n_pre, n_post, ws[i], fS)
+        assert close(ll_sub[i], ref, 1e-10), (n_pre, n_post)
+        h.gibbs_prepare(n_post, theta[n_post], Weff[:, n_post])
+        assert close(h.gibbs_ll(n_pre, Weff[n_pre, n_post], ws[i]), ref, 1e-10)
+    h.set_time_range(0, nT)
+
+
+def test_c4_column_update_and_sweep_full_size(c4):
+    """One full column update (128 pairs, reference order) and one batched sweep of all 16 384 pairs at
+    C4 size keep the state consistent: compute_log_p of the device == oracle on a sub-range."""
+    import time
+    model, popn, data, x0 = c4
+    N, nT, nsub = 128, 600000, 24000
+    x = copy.deepcopy(x0)
+    upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(2))
+    upd.preprocess(popn)
+    stats = upd.update(x, 17)
+    assert len(stats) == N and sorted(s[0] for s in stats) == list(range(N))
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+    assert set(np.unique(A)) <= {0, 1}
+    t0 = time.time()
+    upd.update_all(x)
+    sweep_s = time.time() - t0
+    print("C4 batched collapsed-Gibbs sweep (16 384 pairs): %.3f s, %d ARS evaluations" % (sweep_s, upd.n_ars_evals))
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+    W = np.asarray(x['net']['weights']['W']).reshape(N, N)
+    assert set(np.unique(A)) <= {0, 1} and np.all(np.isfinite(W))
+    assert len(upd.last_stats) == N
+    assert sweep_s < 2.0
+    lp = popn.compute_log_p(x)
+    assert np.isfinite(lp)
+    # oracle on the sub-range of the same handle
+    h = popn._handle(data)
+    h.set_time_range(0, nsub)
+    ll_dev = popn.compute_ll_vector(x)
+    h.set_time_range(0, nT)
+    S_sub = data['S'][:nsub].astype(float)
+    fS = O.convolve_with_basis_fft(S_sub, popn.glm.imp_model.ibasis)
+    Weff = popn.W_eff(x)
+    for n in (17, 0, 100):
+        xn = x['glms'][n]
+        w = popn.glm.imp_model.flat_weights(xn['imp']).reshape(N, -1)
+        ref = O.glm_ll(n, S_sub, fS, w, Weff[:, n], popn.glm.bias_model.I_bias(xn['bias']), 0.001, 'explinear')
+        assert np.allclose(ll_dev[n], ref, rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------
+# C1: standard_glm N = 4, T = 60 s end to end through the harness (test/generate_synth_data.py ->
+# test/synth_map.py:10-32 -> test/synth_mcmc.py:61-96)
+# ---------------------------------------------------------------------------------------------
+def test_c1_harness_end_to_end(tmp_path, capsys):
+    from theano_pyglm_amd.harness import synth_map
+    model, popn_true, data = make_dataset('standard_glm', 4, 60.0, seed=1234 + 1)   # lam_true == lam_sim inside
+    assert data['S'].shape == (60000, 4) and data['S'].sum() > 1000
+    clean = dict((k, v) for k, v in data.items() if not k.startswith('_') and k not in ('fstim', 'preprocessed'))
+    # -- synth_map: LL_inf > LL0, results.pkl written, oracle log p at the result
+    rng = np.random.RandomState(3)
+    popn, _, _ = synth_map.initialize_test_harness('standard_glm', dict(clean))
+    x0 = popn.sample(np.random.RandomState(3))
+    ll0 = popn.compute_log_p(x0)
+    x_inf, ll_inf, wall = synth_map.run_synth_test('standard_glm', dict(clean), str(tmp_path), rng=rng)
+    out = capsys.readouterr().out
+    assert 'LL0:' in out and 'LL_inf:' in out
+    assert (tmp_path / 'results.pkl').exists()
+    assert ll_inf > ll0 + 10.0
+    ll_true = popn_true.compute_log_p(data['vars'])             # "true LL" of synth_harness.py:54-57
+    assert ll_inf > ll_true - 0.02 * abs(ll_true)
+    lp_or, _ = oracle_log_p(popn, clean, x_inf)
+    assert np.allclose(popn.compute_log_p(x_inf), lp_or, rtol=1e-10)
+    assert np.allclose(ll_inf, lp_or, rtol=1e-10)
+    # sequential scipy fits (the reference's own optimiser) reach the same optimum
+    from theano_pyglm_amd.inference.coord_descent import coord_descent
+    x_b = coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+    x_s = coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    lb, ls = popn.compute_log_p(x_b), popn.compute_log_p(x_s)
+    assert abs(lb - ls) < 1e-6 * abs(ls)
+    # -- synth_mcmc: sparse_weighted_model on the same data, MAP-initialised chain
+    m2 = make_model('sparse_weighted_model', N=4, dt=0.001)
+    stabilize_sparsity(m2)
+    pop2 = Population(m2)
+    pop2.add_data(dict(clean))
+    lps = []
+    smpls = G.gibbs_sample(pop2, N_samples=5, x0=None, init_from_mle=True, rng=np.random.RandomState(4),
+                           callback=lambda xx: lps.append(pop2.compute_log_p(xx)), verbose=False)
+    assert len(smpls) == 6 and np.all(np.isfinite(lps))
+    x_last = smpls[-1]
+    lp_last = pop2.compute_log_p(x_last)
+    assert np.allclose(lp_last, oracle_log_p(pop2, clean, x_last)[0], rtol=1e-9)
+    # the chain stays in the neighbourhood of the MAP-initialised state (no collapse of the likelihood)
+    assert lp_last > lps[0] - 0.01 * abs(lps[0])
+    popn.release_data()
+    pop2.release_data()
+
+
+# ---------------------------------------------------------------------------------------------
+# The MAP metric: lock-step batched BFGS == sequential per-neuron scipy BFGS (fit_glm,
+# coord_descent.py:161-204, maxiter 225) at config size
+# ---------------------------------------------------------------------------------------------
+def _map_compare(N, nT, neurons, seed):
+    from theano_pyglm_amd.inference import coord_descent as cd
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    rng = np.random.default_rng(seed)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn = Population(make_model('standard_glm', N=N, dt=0.001))
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(seed))
+    xb = copy.deepcopy(x0)
+    nlp_b, iters, evals = fit_glms_batched_torch(popn, xb)
+    st = popn.last_fit_stats
+    assert st['converged_gtol'] + st['stalled'] + st['maxiter'] == N
+    assert st['neuron_evaluations'] <= evals * N
+    prms = cd.prep_first_order_glm_inference(popn)
+    xs = copy.deepcopy(x0)
+    for n in neurons:
+        nv = popn.extract_vars(xs, n)
+        res = cd.fit_glm(nv, n, prms)
+        # per-neuron negative log posterior at the two optima
+        assert abs(res.fun - nlp_b[n]) <= 1e-6 * abs(res.fun), (n, res.fun, nlp_b[n], st)
+        # and the lock-step result is a stationary point of the device objective
+        g = popn.compute_grad(xb, n)
+        assert np.max(np.abs(g)) < 1e-3
+    popn.release_data()
+    return st
+
+
+def test_map_lockstep_matches_sequential_c2():
+    """C2 (N=32, T=300 s): every neuron's lock-step optimum equals the sequential scipy fit."""
+    st = _map_compare(32, 300000, range(32), 1234 + 2)
+    print("C2 lock-step BFGS:", st)
+    assert st['converged_gtol'] >= 30
+
+
+def test_map_lockstep_matches_sequential_c3_subset():
+    """C3 (N=128, T=600 s): four neurons of the lock-step sweep against sequential scipy fits."""
+    st = _map_compare(128, 600000, (0, 41, 86, 127), 1234 + 3)
+    print("C3 lock-step BFGS:", st)
+    assert st['converged_gtol'] >= 120
+    assert st['neuron_evaluations'] < st['evaluations'] * 128        # finished neurons were masked out

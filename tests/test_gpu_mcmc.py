@@ -114,7 +114,8 @@ def test_ars_weight_draw_matches_inverse_cdf(swm4):
     mu_w, sigma_w = upd.mu_w, upd.sigma_w
     W_nns = np.sqrt(2) * sigma_w * upd.GAUSS_HERMITE_ABSCISSAE + mu_w
     log_L = h.gibbs_ll(n_pre, aw, W_nns)
-    ars = np.array([upd._adaptive_rejection_sample_w(h, n_pre, aw, mu_w, sigma_w, W_nns, log_L)
+    ars = np.array([upd._adaptive_rejection_sample_w(lambda w: h.gibbs_ll(n_pre, aw, np.array([w]))[0],
+                                                     mu_w, sigma_w, W_nns, log_L)
                     for _ in range(400)])
     assert upd.n_ars_evals < 400 * 12                   # a handful of extra abscissae per draw (sharp posterior)
     grid = mu_w + sigma_w * np.linspace(-5.0, 5.0, 801)

@@ -383,5 +383,6 @@ def test_map_with_cross_validation(std4):
     assert popn2.glm.imp_model.prior.lam == models[best_ind]['impulse']['prior']['lam']
     x_rand = popn2.sample(np.random.RandomState(6))
     assert popn2.compute_ll(best_x) > popn2.compute_ll(x_rand)
-    assert len(popn2._handles) == 3                               # train / held-out / all, uploaded once
+    assert len(popn2._handles) == 1                               # the train / held-out handles were released
     popn2.release_data()
+    assert popn2._handles == []

@@ -204,3 +204,19 @@ def test_sta_oracle_definition():
     assert np.allclose(np.outer(w['w_t'], w['w_x']), np.outer(wt, wx), atol=1e-12)
     wb = O.sta_stim_weights(sn, 'basis', ibt)
     assert np.allclose(wb['w_stim'].reshape(D, 3), np.outer(wx, wt), atol=1e-12)
+
+
+def test_blocked_c_baseline_matches_reference_dataflow():
+    """oracle/glm_blocked.c (B2, all neurons per time tile) == oracle/glm_oracle.c (B1, per neuron)."""
+    from oracle import c_oracle as CO
+    from tests import helpers as H
+    for kind, D, N in (('explinear', 0, 20), ('exp', 3, 7)):
+        p = H.Problem(N, 1501, H.std_ibasis(), kind=kind, seed=1, weighted=True, Dstim=D)
+        fS = CO.features(p.S, p.ibasis)
+        ll0, g0 = CO.ll_grad(p.S, fS, p.theta, p.Weff, kind, p.dt, fstim=p.fstim)
+        for th in (1, 3):
+            ll, g = CO.ll_grad_blocked(p.S, fS, p.theta, p.Weff, kind, p.dt, fstim=p.fstim, threads=th)
+            assert np.allclose(ll, ll0, rtol=1e-12) and H.rel_err(g, g0) < 1e-12
+        ll, _ = CO.ll_grad_blocked(p.S, fS, p.theta, p.Weff, kind, p.dt, fstim=p.fstim, want_grad=False)
+        assert np.allclose(ll, ll0, rtol=1e-12)
+    assert CO.set_data_copy_seconds(fS, p.S.astype(float)) > 0

@@ -83,12 +83,65 @@ def test_sharded_population_ll(N):
 
 def test_shard_bounds_cover():
     from theano_pyglm_amd import parallel as PL
-    for nT, G in ((600000, 8), (700, 2), (1000, 3), (17, 4)):
+    for nT, G in ((600000, 8), (700, 2), (1000, 3), (17, 2)):
         b = [PL.time_shard_bounds(nT, r, G) for r in range(G)]
         assert b[0][0] == 0 and b[-1][1] == nT
         assert all(b[i][1] == b[i + 1][0] for i in range(G - 1))
         assert all(lo % 16 == 0 for lo, hi in b)
+    with pytest.raises(ValueError):
+        PL.time_shard_bounds(17, 0, 4)                 # 2 tiles over 4 ranks: a rank would be empty
     for N, G in ((128, 8), (7, 3), (4, 8)):
         b = PL.all_shard_bounds(N, G)
         assert b[0][0] == 0 and b[-1][1] == N
         assert all(b[i][1] == b[i + 1][0] for i in range(G - 1))
+
+
+def _worker_bcast(rank, world, port, out):
+    import torch.distributed as dist
+    from theano_pyglm_amd import parallel as PL
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    data = None
+    if rank == 0:
+        rng = np.random.RandomState(3)
+        data = {'S': (rng.rand(500, 5) < 0.05).astype(float), 'N': 5, 'dt': 0.001, 'T': 0.5,
+                'stim': rng.randn(5, 2), 'dt_stim': 0.1, 'vars': {'a': np.arange(3)},
+                'fS': 'must not travel', '_private': object()}
+    got = PL.broadcast_data(data, src=0)
+    # X4: each rank holds its own columns of a matrix
+    M = np.arange(25.0).reshape(5, 5)
+    lo, hi = PL.shard_bounds(5, rank, world)
+    full = PL.allgather_cols(M[:, lo:hi], 5)
+    import torch
+    t = torch.full((3,), float(rank + 1), dtype=torch.float64)
+    PL.allreduce_sum_t(t)
+    rows = PL.allgather_rows_t(torch.arange(lo, hi, dtype=torch.float64)[:, None] * torch.ones(1, 2, dtype=torch.float64), 5)
+    out.put((rank, got, full, t.numpy(), rows.numpy()))
+    dist.destroy_process_group()
+
+
+def test_broadcast_data_and_column_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bcast, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    rng = np.random.RandomState(3)
+    S = (rng.rand(500, 5) < 0.05).astype(float)
+    stim = rng.randn(5, 2)
+    for rank, got, full, t, rows in res:
+        assert got['S'].dtype == np.uint8 and np.array_equal(got['S'], S)      # counts travel as uint8
+        assert np.array_equal(got['stim'], stim)
+        assert got['N'] == 5 and got['dt'] == 0.001 and got['dt_stim'] == 0.1 and got['T'] == 0.5
+        assert np.array_equal(got['vars']['a'], np.arange(3))
+        assert 'fS' not in got and '_private' not in got
+        assert np.array_equal(full, np.arange(25.0).reshape(5, 5))
+        assert np.array_equal(t, np.full(3, 3.0))
+        assert np.array_equal(rows[:, 0], np.arange(5.0)) and rows.shape == (5, 2)

@@ -27,6 +27,7 @@ SYMBOLS = [
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
     'pgl_timing_summary', 'pgl_set_stream',
+    'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
 ]
 
 
@@ -95,6 +96,7 @@ def load():
     lib.pgl_sta.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int, vp]
     lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pgl_ll_grad_list_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
     lib.pgl_features.argtypes = [vp, vp]
     lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
@@ -103,6 +105,10 @@ def load():
     lib.pgl_gibbs_prepare.argtypes = [vp, C.c_int, vp, vp]
     lib.pgl_gibbs_ll.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.pgl_gibbs_update.argtypes = [vp, C.c_int, C.c_double]
+    lib.pgl_gibbs_prepare_all.argtypes = [vp, vp, vp]
+    lib.pgl_gibbs_ll_cols.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.pgl_gibbs_update_cols.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.pgl_gibbs_currents.argtypes = [vp, C.c_int, vp]
     lib.pgl_last_timing.argtypes = [vp, dp, dp]
     lib.pgl_info.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     lib.pgl_simulate.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, vp, vp, vp,
@@ -268,6 +274,13 @@ class DeviceGlm(object):
                                       C.c_void_p(d_Weff), C.c_void_p(d_ll),
                                       C.c_void_p(d_grad) if d_grad else None))
 
+    def ll_grad_list_dev(self, d_idx, count, d_theta, d_Weff, d_ll, d_grad):
+        """ll+grad of the `count` neurons listed in d_idx (device int32 pointer); row j of the device
+        arrays belongs to neuron d_idx[j].  Asynchronous like ll_grad_dev."""
+        _chk(self.lib.pgl_ll_grad_list_dev(self.h, C.c_void_p(d_idx), int(count), C.c_void_p(d_theta),
+                                           C.c_void_p(d_Weff), C.c_void_p(d_ll),
+                                           C.c_void_p(d_grad) if d_grad else None))
+
     def sync(self):
         _chk(self.lib.pgl_sync(self.h))
 
@@ -283,9 +296,19 @@ class DeviceGlm(object):
         return n.value, a.value, b.value
 
     def set_stream(self, stream_ptr):
-        """Order the handle's work on a caller-owned HIP stream (integer hipStream_t, e.g.
-        torch.cuda.current_stream().cuda_stream); None returns to the handle's own stream."""
-        _chk(self.lib.pgl_set_stream(self.h, None if not stream_ptr else C.c_void_p(int(stream_ptr))))
+        """Order the handle's work on a caller-owned HIP stream (integer hipStream_t of a
+        torch.cuda.Stream(): `.cuda_stream`); None returns to the handle's own stream.
+        The NULL stream cannot be named through this call (pgl_set_stream(NULL) means "own stream"):
+        torch's DEFAULT stream has handle 0, so `torch.cuda.current_stream().cuda_stream` is only
+        valid inside `with torch.cuda.stream(torch.cuda.Stream())` -- a 0 raises instead of silently
+        un-ordering the kernels from the caller's collectives."""
+        if stream_ptr is None:
+            _chk(self.lib.pgl_set_stream(self.h, None))
+            return
+        if int(stream_ptr) == 0:
+            raise ValueError("stream handle 0 is the NULL stream: create a torch.cuda.Stream(), make it "
+                             "current and pass its .cuda_stream")
+        _chk(self.lib.pgl_set_stream(self.h, C.c_void_p(int(stream_ptr))))
 
     def info(self, n_lo=0, n_hi=None):
         n_hi = self.N if n_hi is None else n_hi
@@ -342,3 +365,42 @@ class DeviceGlm(object):
 
     def gibbs_update(self, n_pre, delta):
         _chk(self.lib.pgl_gibbs_update(self.h, int(n_pre), float(delta)))
+
+    # -- batched column Gibbs (all post-synaptic columns resident) ---------------
+    def gibbs_prepare_all(self, theta, Weff):
+        th = _f64(theta, (self.N, self.P))
+        We = _f64(Weff, (self.N, self.N))
+        _chk(self.lib.pgl_gibbs_prepare_all(self.h, _ptr(th), _ptr(We)))
+
+    def gibbs_ll_cols(self, n_post, n_pre, aw_cur, ws):
+        """ll (ncols, K) at the candidate weights ws (ncols, K) of the pairs (n_pre[c], n_post[c])."""
+        n_post = np.ascontiguousarray(n_post, dtype=np.int32)
+        n_pre = np.ascontiguousarray(n_pre, dtype=np.int32)
+        ws = _f64(ws)
+        if ws.ndim == 1:
+            ws = ws[None, :]
+        aw = _f64(aw_cur, (len(n_post),))
+        if n_pre.shape != n_post.shape or ws.shape[0] != len(n_post):
+            raise ValueError("n_post, n_pre, aw_cur, ws must describe the same columns")
+        out = np.empty(ws.shape)
+        K = ws.shape[1]
+        for k0 in range(0, K, 16):                     # at most 16 candidate weights per launch
+            wk = np.ascontiguousarray(ws[:, k0:k0 + 16])
+            ok = np.empty(wk.shape)
+            _chk(self.lib.pgl_gibbs_ll_cols(self.h, len(n_post), _ptr(n_post), _ptr(n_pre), _ptr(aw),
+                                            _ptr(wk), wk.shape[1], _ptr(ok)))
+            out[:, k0:k0 + 16] = ok
+        return out
+
+    def gibbs_update_cols(self, n_post, n_pre, delta):
+        n_post = np.ascontiguousarray(n_post, dtype=np.int32)
+        n_pre = np.ascontiguousarray(n_pre, dtype=np.int32)
+        d = _f64(delta, (len(n_post),))
+        if len(n_post) == 0:
+            return
+        _chk(self.lib.pgl_gibbs_update_cols(self.h, len(n_post), _ptr(n_post), _ptr(n_pre), _ptr(d)))
+
+    def gibbs_currents(self, n_post, nrows=None):
+        out = np.empty(self.nT if nrows is None else int(nrows))
+        _chk(self.lib.pgl_gibbs_currents(self.h, int(n_post), _ptr(out)))
+        return out

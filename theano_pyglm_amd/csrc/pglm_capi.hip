@@ -55,8 +55,15 @@ struct pgl_context {
     int fimg_kth = 0;                    // widths (ktl << 8 | kth, k-tiles) the images were built for; 0 = stale
     int fimg_tile0 = 0, fimg_ntiles = 0; // 16-bin tiles the images cover (the evaluated time range)
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
+    const int* cur_pidx = nullptr;       // post-neuron list of the evaluation being enqueued (device)
     int gibbs_npost = -1;
     double gibbs_bias = 0;
+    // batched column Gibbs (pgl_gibbs_prepare_all / _ll_cols / _update_cols)
+    DevBuf GX, gtheta, gargs, gpart, gout;
+    int gx_xs = 0;                       // row stride of GX (16 * post tiles); 0 = not prepared
+    int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
+    unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
+    size_t pin_args_cap = 0;
     int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0;
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
@@ -90,6 +97,7 @@ struct Plan {
     int tile0;
     int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
+    int mt;                             // version 6: 16-bin tiles per step
     size_t lds;
     bool f32;
 };
@@ -213,6 +221,27 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         pl.KT = pl.KTW * pl.KSPLIT;
         pl.wpb = nw;
         pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
+        // version 6: the same K-split geometry on resident feature tiles (k_fused6) when two step
+        // buffers of whole-row images fit the LDS: short feature rows (C1, C2, C5)
+        pl.mt = 0;
+        if (pl.version == 2 && single_slice && (h->opt_kernel == 0 || h->opt_kernel == 6) && h->opt_ptw == 0) {
+            for (int mt = 2; mt >= 1 && pl.mt == 0; --mt) {
+                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(pl.KT) + (size_t)mt * (nw + pl.PTW) * 2048 + 256;
+                if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) pl.mt = mt;
+            }
+            if (pl.mt > 0) {
+                bool ok = true;
+                if (h->opt_kernel == 0 &&
+                    !(h->fimg_kth == (pl.KT << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                        const size_t want = (size_t)pl.nTiles * pgl_img_bytes(pl.KT);
+                        if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) ok = false;
+                    }
+                }
+                if (ok) pl.version = 6;
+            }
+        }
     }
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
@@ -227,8 +256,16 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     const size_t esz = pl.f32 ? 4 : 8;
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
     if (pl.version == 5) {
-        pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8;   // + per-wave spike scratch
+        pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8 + 16;   // + per-wave spike scratch + H ticket
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
+        return PGL_OK;
+    }
+    if (pl.version == 6) {
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * (8 + pl.PTW) * 2048 + 256;
+        // chunks are whole steps of mt tiles
+        pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
+        pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
+        pl.blocks = pl.nChunks * pl.nPB;
         return PGL_OK;
     }
     if (pl.version == 4) {
@@ -356,8 +393,52 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
     return hipErrorInvalidValue;
 }
 
+template <int KTW, int PTW, int MT>
+static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (8 / PTW)) + (size_t)MT * (8 + PTW) * 2048 + 256;
+    if constexpr (need <= 160 * 1024) {
+        auto kern = k_fused6<KTW, PTW, MT>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int PTW, int MT>
+static hipError_t launch_fused6_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KTW) {
+    case 1: return launch_fused6_t<1, PTW, MT>(pl, fp, s);
+    case 2: return launch_fused6_t<2, PTW, MT>(pl, fp, s);
+    case 3: return launch_fused6_t<3, PTW, MT>(pl, fp, s);
+    case 5: return launch_fused6_t<5, PTW, MT>(pl, fp, s);
+    case 7: return launch_fused6_t<7, PTW, MT>(pl, fp, s);
+    case 10: return launch_fused6_t<10, PTW, MT>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.PTW * 4 + pl.mt) {
+    case 1 * 4 + 1: return launch_fused6_k<1, 1>(pl, fp, s);
+    case 1 * 4 + 2: return launch_fused6_k<1, 2>(pl, fp, s);
+    case 2 * 4 + 1: return launch_fused6_k<2, 1>(pl, fp, s);
+    case 2 * 4 + 2: return launch_fused6_k<2, 2>(pl, fp, s);
+    case 4 * 4 + 1: return launch_fused6_k<4, 1>(pl, fp, s);
+    case 4 * 4 + 2: return launch_fused6_k<4, 2>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.version == 6) return launch_fused6(pl, fp, s);
     if (pl.version == 5) return launch_fused5(pl, fp, s);
     if (pl.version == 4) return launch_fused3(pl, fp, s);
     if (pl.version == 3) {
@@ -432,12 +513,14 @@ int pgl_destroy(pgl_handle h)
     DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
                       &h->gbpart, &h->Xbuf, &h->fimg, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
-                      &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan};
+                      &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
+                      &h->gargs, &h->gpart, &h->gout};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
             if (h->evr[s][i]) (void)hipEventDestroy(h->evr[s][i]);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_args) (void)hipHostFree(h->pin_args);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
@@ -540,6 +623,7 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     h->have_spikes = true;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
+    h->gx_xs = 0;
     return PGL_OK;
 }
 
@@ -591,6 +675,7 @@ int pgl_set_basis(pgl_handle h, const double* ibasis)
     h->have_basis = true;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
+    h->gx_xs = 0;
     return PGL_OK;
 }
 
@@ -603,6 +688,7 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     h->Ktot = h->Kimp + Dstim;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
+    h->gx_xs = 0;
     if (Dstim > 0) {
         const size_t bytes = (size_t)h->nT * Dstim * 8;
         ENSURE(h->fstim, bytes);
@@ -656,6 +742,7 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
     h->Ktot = h->Kimp + Dstim;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
+    h->gx_xs = 0;
     return PGL_OK;
 }
 
@@ -758,6 +845,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.dbg = h->opt_dbg;
     fp.Fimg = (const unsigned char*)h->fimg.p;
     fp.img_tile0 = h->fimg_tile0;
+    fp.pidx = h->cur_pidx;
 }
 
 static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
@@ -770,7 +858,7 @@ static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, 
     hipLaunchKernelGGL(k_prep_w, dim3(blocks), dim3(256), 0, h->stream, d_theta, d_Weff,
                        (double*)h->Wfrag.p, (double*)h->bias.p, sl.Ns, h->B, sl.Ds, sl.Ns * h->B,
                        sl.Ns * h->B + sl.Ds, pl.KS, n_lo, pl.npost, pl.nPT, 1,
-                       h->N, sl.np0, h->Dstim, sl.ds0);
+                       h->N, sl.np0, h->Dstim, sl.ds0, h->cur_pidx);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -788,7 +876,7 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
                        sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
                        pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0, kt0,
-                       nkt);
+                       nkt, h->cur_pidx);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -804,11 +892,12 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
 // own 1/G of the recording.
 static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles)
 {
+    // kth == 0: one image per tile holding all ktl k-tiles (k_fused6); else the L / H pair of k_fused5
     if (h->fimg_kth == (ktl << 8 | kth) && h->fimg_tile0 == tile0 && h->fimg_ntiles == ntiles && h->fimg.p)
         return PGL_OK;
-    const size_t bytes = (size_t)ntiles * img_pair_bytes(ktl, kth);
+    const size_t bytes = (size_t)ntiles * (kth ? img_pair_bytes(ktl, kth) : (size_t)pgl_img_bytes(ktl));
     ENSURE(h->fimg, bytes);
-    dim3 grid((unsigned)ntiles, 2);
+    dim3 grid((unsigned)ntiles, kth ? 2 : 1);
     hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
@@ -860,6 +949,10 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         }
         if (pl.version == 5) {
             rc = ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles);
+            if (rc) return rc;
+        }
+        if (pl.version == 6) {
+            rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
             if (rc) return rc;
         }
         FusedParams fp;
@@ -925,7 +1018,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             hipLaunchKernelGGL(k_rows_epilogue, grid, dim3(256), 0, h->stream, (double*)h->Xbuf.p, xs,
                                (const double*)h->bias.p, (const uint8_t*)h->S.p, h->N, n_lo, p0.npost,
                                (long long)h->t_lo, (long long)h->t_hi, rows, h->nlin, h->dt,
-                               (double*)h->tmpA.p, (double*)h->tmpB.p);
+                               (double*)h->tmpA.p, (double*)h->tmpB.p, h->cur_pidx);
             HIPCHK(hipGetLastError());
             if (row1 > h->t_hi) {
                 hipLaunchKernelGGL(k_rows_zero, dim3(64), dim3(256), 0, h->stream, (double*)h->Xbuf.p, xs,
@@ -966,6 +1059,20 @@ int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta, con
     HIPCHK(hipSetDevice(h->device));
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     return enqueue_ll_grad(h, n_lo, n_hi, d_theta, d_Weff, d_ll, d_grad);
+}
+
+int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double* d_theta,
+                         const double* d_Weff, double* d_ll, double* d_grad)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!d_idx || !d_theta || !d_Weff || !d_ll) return fail(PGL_ERR_ARG, "null argument");
+    if (count <= 0 || count > h->N) return fail(PGL_ERR_ARG, "bad neuron count");
+    HIPCHK(hipSetDevice(h->device));
+    h->cur_pidx = d_idx;
+    rc = enqueue_ll_grad(h, 0, count, d_theta, d_Weff, d_ll, d_grad);
+    h->cur_pidx = nullptr;
+    return rc;
 }
 
 int pgl_sync(pgl_handle h)
@@ -1059,11 +1166,13 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     const double P = 1.0 + h->Dstim + h->Kimp;
     double v[12];
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
-    v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth) : 0.0;   // resident feature bytes
+    v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth)
+            : (pl.version == 6) ? (double)pl.nTiles * (double)pgl_img_bytes(pl.KT) : 0.0;            // resident feature bytes
     // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
     // pass 1 and the H part again in pass 2, residual slab written and read)
     v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
-            : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0 : 0.0;
+            : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
+            : (pl.version == 6) ? v[10] * pl.nPB : 0.0;
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;
     const double nrows = (double)(h->t_hi - h->t_lo);
@@ -1157,8 +1266,12 @@ static int run_ll_current(pgl_handle h, const double* d_base, const double* d_st
                           const double* w, int K, double* ll_out)
 {
     // blocks of the streaming part; the spike-bin part writes one more partial row
-    const int nblocks = (int)std::min<int64_t>(1024, (h->nT + 255) / 256);
-    const int e_lo = h->h_ptr[n_post], e_hi = h->h_ptr[n_post + 1];
+    // the sums run over the evaluated time range [t_lo, t_hi) (pgl_set_time_range)
+    const int nblocks = (int)std::min<int64_t>(1024, (h->t_hi - h->t_lo + 255) / 256);
+    const int2* evb = h->h_ev.data();
+    const auto before = [](const int2& e, int64_t t) { return (int64_t)e.x < t; };
+    const int e_lo = (int)(std::lower_bound(evb + h->h_ptr[n_post], evb + h->h_ptr[n_post + 1], h->t_lo, before) - evb);
+    const int e_hi = (int)(std::lower_bound(evb + h->h_ptr[n_post], evb + h->h_ptr[n_post + 1], h->t_hi, before) - evb);
     const int sblocks = std::max(1, std::min(256, (e_hi - e_lo + 255) / 256));
     ENSURE(h->part, (size_t)(nblocks + sblocks) * PGL_KMAX * 8);
     ENSURE(h->outK, PGL_KMAX * 8);
@@ -1169,7 +1282,7 @@ static int run_ll_current(pgl_handle h, const double* d_base, const double* d_st
         for (int k = 0; k < PGL_KMAX; ++k) wv.w[k] = (k < kk) ? w[k0 + k] : 0.0;
         hipLaunchKernelGGL(k_ll_current, dim3(nblocks), dim3(256), 0, h->stream, d_base, d_stim,
                            d_col, bias, aw_cur, wv, kk, h->nlin, h->dt,
-                           (long long)h->nT, (double*)h->part.p);
+                           (long long)h->t_lo, (long long)h->t_hi, (double*)h->part.p);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_ll_current_spikes, dim3(sblocks), dim3(256), 0, h->stream,
                            (const int2*)h->spk.p, e_lo, e_hi, d_base, d_stim, d_col, bias, aw_cur,
@@ -1213,6 +1326,166 @@ int pgl_gibbs_update(pgl_handle h, int n_pre, double delta)
     hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, h->stream, (double*)h->Inet.p, col, delta,
                        (long long)h->nT);
     HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+// ---- batched column Gibbs: all post-synaptic columns on the device at once ----------------------
+int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!theta || !Weff) return fail(PGL_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t P = 1 + (size_t)h->Dstim + h->Kimp;
+    const int N = h->N;
+    ENSURE(h->gtheta, (size_t)N * P * 8);
+    ENSURE(h->Weff, (size_t)N * N * 8);
+    HIPCHK(hipMemcpyAsync(h->gtheta.p, theta, (size_t)N * P * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->Weff.p, Weff, (size_t)N * N * 8, hipMemcpyHostToDevice, h->stream));
+    // forward-only launches of the K-split kernel: GX[t][n] = sum_slices F_s . W_s (stimulus columns
+    // included), the same phase 1 as the sliced ll+grad path
+    const std::vector<Slice> slices = make_slices(h);
+    std::vector<Plan> plans(slices.size());
+    size_t maxLL = 0;
+    for (size_t i = 0; i < slices.size(); ++i) {
+        rc = make_plan(h, 0, N, slices[i], plans[i], false);
+        if (rc) return rc;
+        maxLL = std::max(maxLL, (size_t)plans[i].nChunks * plans[i].nPT * plans[i].KSPLIT * 64 * 8);
+    }
+    ENSURE(h->llpart, maxLL);
+    ENSURE(h->gbpart, maxLL);
+    const int xs = plans[0].nPT * 16;
+    ENSURE(h->GX, (size_t)h->nT * xs * 8);
+    const long long row0 = (long long)plans[0].tile0 * 16;
+    const long long row1 = std::min<long long>(h->nT, (long long)(plans[0].tile0 + plans[0].nTiles) * 16);
+    HIPCHK(hipMemsetAsync((double*)h->GX.p + row0 * xs, 0, (size_t)(row1 - row0) * xs * 8, h->stream));
+    for (size_t i = 0; i < slices.size(); ++i) {
+        rc = launch_prep(h, plans[i], slices[i], 0, (const double*)h->gtheta.p, (const double*)h->Weff.p);
+        if (rc) return rc;
+        FusedParams fp;
+        fill_params(h, plans[i], slices[i], 0, false, 1, fp);
+        fp.Xbuf = (double*)h->GX.p;
+        fp.xstride = xs;
+        hipError_t e = launch_any(plans[i], fp, h->stream);
+        if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("forward launch: ") + hipGetErrorString(e));
+    }
+    h->gx_xs = xs;
+    h->gx_t_lo = h->t_lo;
+    h->gx_t_hi = h->t_hi;
+    return PGL_OK;
+}
+
+// stage the column arguments in one pinned block, one H2D copy: [cols | pre | aw | w]
+static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre, const double* aw,
+                      const double* w, int nw, GibbsColsParams& gp, size_t extra_out_bytes)
+{
+    if (h->gx_xs == 0) return fail(PGL_ERR_STATE, "pgl_gibbs_prepare_all has not been called");
+    if (h->gx_t_lo != h->t_lo || h->gx_t_hi != h->t_hi)
+        return fail(PGL_ERR_STATE, "time range changed since pgl_gibbs_prepare_all");
+    if (ncols <= 0 || !n_post || !n_pre || !w) return fail(PGL_ERR_ARG, "bad argument");
+    for (int c = 0; c < ncols; ++c)
+        if (n_post[c] < 0 || n_post[c] >= h->N || n_pre[c] < 0 || n_pre[c] >= h->N)
+            return fail(PGL_ERR_ARG, "neuron index out of range");
+    const size_t o_pre = (size_t)ncols * 4, o_aw = ((o_pre + (size_t)ncols * 4 + 7) / 8) * 8;
+    const size_t o_w = o_aw + (size_t)ncols * 8, bytes = o_w + (size_t)ncols * nw * 8;
+    const size_t need = std::max(bytes, extra_out_bytes);
+    if (need > h->pin_args_cap) {
+        if (h->pin_args) (void)hipHostFree(h->pin_args);
+        h->pin_args = nullptr;
+        h->pin_args_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&h->pin_args, need * 2, hipHostMallocDefault));
+        h->pin_args_cap = need * 2;
+    }
+    ENSURE(h->gargs, bytes);
+    std::memcpy(h->pin_args, n_post, (size_t)ncols * 4);
+    std::memcpy(h->pin_args + o_pre, n_pre, (size_t)ncols * 4);
+    for (int c = 0; c < ncols; ++c) reinterpret_cast<double*>(h->pin_args + o_aw)[c] = aw ? aw[c] : 0.0;
+    std::memcpy(h->pin_args + o_w, w, (size_t)ncols * nw * 8);
+    HIPCHK(hipMemcpyAsync(h->gargs.p, h->pin_args, bytes, hipMemcpyHostToDevice, h->stream));
+    const unsigned char* d = (const unsigned char*)h->gargs.p;
+    gp.GX = (const double*)h->GX.p; gp.xs = h->gx_xs; gp.S = (const uint8_t*)h->S.p;
+    gp.N = h->N; gp.B = h->B; gp.R = h->Rk; gp.P = 1 + h->Dstim + h->Kimp; gp.woff = 1 + h->Dstim;
+    gp.spk = (const int2*)h->spk.p; gp.wlo = (const int*)h->wlo.p; gp.whi = (const int*)h->whi.p;
+    gp.phi = (const double*)h->phi.p; gp.theta = (const double*)h->gtheta.p;
+    gp.cols = (const int*)d; gp.pre = (const int*)(d + o_pre); gp.aw = (const double*)(d + o_aw);
+    gp.w = (const double*)(d + o_w);
+    gp.ncols = ncols; gp.K = nw; gp.nlin = h->nlin; gp.dt = h->dt;
+    gp.t_lo = h->t_lo; gp.t_hi = h->t_hi;
+    int cp = 1;
+    while (cp < ncols && cp < 256) cp <<= 1;
+    gp.CP = cp;
+    gp.part = nullptr;
+    return PGL_OK;
+}
+
+int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre,
+                      const double* aw_cur, const double* w, int K, double* ll_out)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (K <= 0 || K > PGL_KMAX || !ll_out) return fail(PGL_ERR_ARG, "K must be in 1..16");
+    HIPCHK(hipSetDevice(h->device));
+    GibbsColsParams gp;
+    rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8);
+    if (rc) return rc;
+    // rows per block: enough blocks to fill the chip, whole passes of 4*RPB rows
+    const int RPB = 256 / gp.CP, pass = 4 * RPB;
+    const int ygroups = (ncols + gp.CP - 1) / gp.CP;
+    const long long nrows = h->t_hi - h->t_lo;
+    long long rows = (nrows * ygroups + 4 * h->numCU - 1) / (4LL * h->numCU);
+    rows = std::max<long long>(pass, std::min<long long>(rows, 4096));
+    rows = (rows + pass - 1) / pass * pass;
+    gp.rows = (int)rows;
+    const int nblk = (int)((nrows + rows - 1) / rows);
+    ENSURE(h->gpart, (size_t)nblk * ncols * PGL_KMAX * 8);
+    ENSURE(h->gout, (size_t)ncols * K * 8);
+    gp.part = (double*)h->gpart.p;
+    const size_t lds = ((size_t)h->B * h->Rk + (size_t)gp.CP * K + 4 * (64 * 4 + 64 * PGL_KMAX)) * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gibbs_ll_cols),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gibbs_ll_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gibbs_reduce_cols, dim3(ncols), dim3(64), 0, h->stream, (const double*)h->gpart.p,
+                       nblk, ncols, K, (double*)h->gout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->pin_args, h->gout.p, (size_t)ncols * K * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memcpy(ll_out, h->pin_args, (size_t)ncols * K * 8);
+    return PGL_OK;
+}
+
+int pgl_gibbs_update_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre, const double* delta)
+{
+    int rc = check_ready(h);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    for (int a = 0; a < ncols; ++a)                       // two deltas for one post neuron would race
+        for (int b = a + 1; b < ncols; ++b)
+            if (n_post && n_post[a] == n_post[b]) return fail(PGL_ERR_ARG, "duplicate post-synaptic column");
+    GibbsColsParams gp;
+    rc = stage_cols(h, ncols, n_post, n_pre, nullptr, delta, 1, gp, 0);
+    if (rc) return rc;
+    const int ygroups = (ncols + gp.CP - 1) / gp.CP;
+    const long long nrows = h->t_hi - h->t_lo;
+    gp.rows = 1024;
+    const int nblk = (int)((nrows + gp.rows - 1) / gp.rows);
+    const size_t lds = (size_t)h->B * h->Rk * 8;
+    hipLaunchKernelGGL(k_gibbs_update_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp, (double*)h->GX.p);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_gibbs_currents(pgl_handle h, int n_post, double* x_out)
+{
+    if (!h || !x_out) return fail(PGL_ERR_ARG, "null argument");
+    if (h->gx_xs == 0) return fail(PGL_ERR_STATE, "pgl_gibbs_prepare_all has not been called");
+    if (n_post < 0 || n_post >= h->N) return fail(PGL_ERR_ARG, "n_post out of range");
+    HIPCHK(hipSetDevice(h->device));
+    const long long nrows = h->gx_t_hi - h->gx_t_lo;
+    HIPCHK(hipMemcpy2DAsync(x_out, 8, (const double*)h->GX.p + h->gx_t_lo * h->gx_xs + n_post,
+                            (size_t)h->gx_xs * 8, 8, (size_t)nrows, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PGL_OK;
 }
 

@@ -38,6 +38,16 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifndef PGL_EBAR
 #define PGL_EBAR 1           // k_fused5: barrier between the epilogue and the backward loop
 #endif
+#ifndef PGL_V2
+#define PGL_V2 0             // k_fused5 pass 1 (A/B variants, measured equal within noise: 3.28-3.37 ms): 1 = without the two mid-tile barriers: the H part of the forward pass
+                             // runs first and an LDS ticket (not a barrier) tells the DMA when every wave is done
+                             // with H_i; the epilogue runs at raised wave priority beside the partner's MFMAs;
+                             // 2 = the closing barrier is a ticket too: a wave only ever waits for the data it
+                             // is about to touch (tile landed / buffer free), the waves drift by up to a tile
+#endif
+#ifndef PGL_EPRIO
+#define PGL_EPRIO 3          // wave priority during the rate epilogue (PGL_V2)
+#endif
 #ifndef PGL_ENE
 #define PGL_ENE 4            // elements a lane carries through the rate epilogue together (k_fused5):
                              // 4 = pgl_rate4 (fixed instruction order), 2 = pgl_rate_terms_n<2> only
@@ -79,6 +89,8 @@ struct FusedParams {
     int dbg;                             // timing ablation bits (results invalid when != 0)
     const unsigned char* __restrict__ Fimg;   // resident feature tiles (k_fused5), else null
     int img_tile0;                       // first tile the resident images cover
+    const int* __restrict__ pidx;        // post-synaptic neuron of local column j (null: n_lo + j) -- an
+                                         // arbitrary subset of neurons per launch (pgl_ll_grad_list_dev)
 };
 
 // ---------------------------------------------------------------------------
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
     const int grp = lane >> 4;
     const int nloc = pt * 16 + col;
     const bool valid_n = active && (nloc < p.npost);
-    const int nglob = p.n_lo + (valid_n ? nloc : 0);
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
     const double bias_l = valid_n ? p.bias[nloc] : 0.0;
     const double* __restrict__ wrow =
         p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
@@ -1024,7 +1036,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
     const int grp = lane >> 4;
     const int nloc = pt * 16 + col;
     const bool valid_n = active && (nloc < p.npost);
-    const int nglob = p.n_lo + (valid_n ? nloc : 0);
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
     const double bias_l = valid_n ? p.bias[nloc] : 0.0;
     const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS_ALL * 64;
     const int oddoff = B * RP * ESZ;
@@ -1405,7 +1417,7 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
     const int tile = tile0 + blockIdx.x, part = blockIdx.y;
     const int kt = part ? kth : ktl;
     const int rsh = pgl_img_rsh(kt), cw = kt * 16, cbeg = part ? ktl * 16 : 0, Kimp = N * B;
-    const size_t imgl = (size_t)pgl_img_bytes(ktl), imgh = (size_t)pgl_img_bytes(kth);
+    const size_t imgl = (size_t)pgl_img_bytes(ktl), imgh = (gridDim.y > 1) ? (size_t)pgl_img_bytes(kth) : 0;
     double* dst = reinterpret_cast<double*>(Fimg + (size_t)blockIdx.x * (imgl + imgh) + (part ? imgl : 0));
     const int nel = (int)((part ? imgh : imgl) / 8);
     for (int i = threadIdx.x; i < nel; i += blockDim.x) {
@@ -1517,7 +1529,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const int grp = lane >> 4;
     const int nloc = pt * 16 + col;
     const bool valid_n = active && (nloc < p.npost);
-    const int nglob = p.n_lo + (valid_n ? nloc : 0);
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
 
     const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
@@ -1533,6 +1545,20 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int NRL = (IMGL / 1024 + 7) / 8, NRH = (IMGH / 1024 + 7) / 8;
     constexpr int NR0 = (PASS == 1) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
     constexpr int RSG = (PASS == 1) ? RSL : RSH;
+    // ticket counter of pass 1 (PGL_V2): wave w adds 1 per tile once its forward pass has consumed H_i
+    volatile unsigned* const hdone = reinterpret_cast<volatile unsigned*>(smem + 2 * IMGL + IMGH + 256 + 8 * 192 * 8);
+    // hdone[1]: tiles whose images have landed (one count per wave after its vmcnt(0)); hdone[2]: waves
+    // that are done with the L buffer of the tile (PGL_V2 == 2)
+    unsigned h_target = 0;
+    auto wait_h = [&]() {
+        while (*hdone < h_target) __builtin_amdgcn_s_sleep(1);
+    };
+    auto wait_ticket = [&](const int which, const unsigned target) {
+        while (hdone[which] < target) __builtin_amdgcn_s_sleep(1);
+    };
+    auto add_ticket = [&](const int which) {
+        if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone) + which, 1u);
+    };
     auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
                         unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
         const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSG + col;
@@ -1544,10 +1570,14 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 #pragma unroll
         for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTG)) * RSG + 16 * (s % KTG)];
         auto round = [&](const int j) {
-            if (j < NR0)
+            if (j < NR0) {
+                // the L image of the next tile goes over the one of the previous tile: every wave has left it
+                if (PASS == 1 && PGL_V2 == 2 && j == 0) wait_ticket(2, h_target - NW);
                 pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
-            else
+            } else {
+                if (PASS == 1 && PGL_V2 && j == NR0) wait_h();       // every wave is done reading H_i
                 pgl_dma_round<KTH>(g1, l1, j - NR0, wave, lane);
+            }
         };
         if (DSTEP == 0 && dma) {
 #pragma unroll
@@ -1599,10 +1629,14 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             }
         };
         if (tile_beg < tile_end) load_counts(tile_beg, scn);
+        if (PGL_V2 && tid < 4) hdone[tid] = 0u;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
         __syncthreads();
         PGL_PROF_DECL
         for (int tile = tile_beg; tile < tile_end; ++tile) {
+            h_target += NW;
+            if (PGL_V2 && !active && lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);
+            if (PGL_V2 == 2 && tile > tile_beg) wait_ticket(1, h_target - NW);     // L_i, H_i landed (all waves' pieces)
             const int t0 = tile * TT;
             const int par = (tile - tile_beg) & 1;
             const unsigned char* Lb = par ? buf2 : buf0;     // L alternates buf0 / buf2, H lives in buf1
@@ -1623,33 +1657,50 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
                 double ar[PA];
+                // k-step order: with PGL_V2 the H columns go first (step q is k-step (q + KSL) % KS_ALL), so
+                // that H_i is dead -- and its buffer free for the DMA of H_{i+1} -- early in the pass
+                constexpr int KOFF = PGL_V2 ? KSL : 0;
+                auto afrag = [&](const int q) -> double {
+                    const int s = (q + KOFF) % KS_ALL;
+                    return (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
+                };
 #pragma unroll
-                for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+                for (int q = 0; q < PW2; ++q) wr[q] = wr2[(((2 * q + KOFF) % KS_ALL) / 2) * 64 + lane];
 #pragma unroll
-                for (int s = 0; s < PA; ++s) ar[s] = (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
+                for (int q = 0; q < PA; ++q) ar[q] = afrag(q);
                 if (PGL_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int s = 0; s < KS_ALL; ++s) {
-                    if (PGL_PRIO && s == KS_ALL / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
-                    const double a = ar[s % PA];
-                    const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
-                    if (s + PA < KS_ALL)
-                        ar[s % PA] = (s + PA < KSL) ? faL[4 * (s + PA)] : faH[4 * (s + PA - KSL)];
-                    if ((s & 1) && (s / 2 + PW2 < KS_ALL / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
-                    if (s & 1)
+                for (int q = 0; q < KS_ALL; ++q) {
+                    if (PGL_PRIO && q == KS_ALL / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+                    const double a = ar[q % PA];
+                    const double b = (q & 1) ? wr[(q / 2) % PW2].y : wr[(q / 2) % PW2].x;
+                    if (q + PA < KS_ALL) ar[q % PA] = afrag(q + PA);
+                    if ((q & 1) && (q / 2 + PW2 < KS_ALL / 2))
+                        wr[(q / 2) % PW2] = wr2[(((2 * (q / 2 + PW2) + KOFF) % KS_ALL) / 2) * 64 + lane];
+                    if (q & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
                     else
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
-                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    // the last A fragment of H was requested PA steps before the first L step was issued
+                    if (PGL_V2 && q == KS_ALL - KSL + PA - 1) {
+                        if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+            } else if (PGL_V2 && active) {
+                if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);      // dbg & 8: no forward pass
             }
             PGL_PROF_MARK(0);
             const bool do_bwd = active && p.want_grad && !(p.dbg & 16);
-            // every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The barrier also
-            // lines the waves up for the epilogue.
-            __syncthreads();
+            // (without PGL_V2) every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The
+            // barrier also lines the waves up for the epilogue.
+            if (!PGL_V2) __syncthreads();
             PGL_PROF_MARK(2);
             // ---- epilogue on the accumulator registers ----
+            // PGL_V2: at raised priority -- its dependent f64 chains take the issue slots they can use and
+            // the partner wave's MFMAs fill the rest of the shared DP pipe
+            if (PGL_V2 != 0 && PGL_EPRIO != 0) __builtin_amdgcn_s_setprio(PGL_EPRIO);
             double rr[4];
             if (active) {
                 bool done = false;
@@ -1706,10 +1757,13 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 for (int r = 0; r < 4; ++r) rr[r] = 0.0;
             }
             PGL_PROF_MARK(1);
-            if (PGL_EBAR) __syncthreads();                // both epilogues of a SIMD end before any backward MFMA
+            if (PGL_V2 != 0 && PGL_EPRIO != 0) __builtin_amdgcn_s_setprio(0);
+            if (PGL_EBAR && !PGL_V2) __syncthreads();     // both epilogues of a SIMD end before any backward MFMA
             if (more) load_counts(tile + 1, scn);         // retired by the closing vmcnt(0) of this tile
             if (!do_bwd && more) {
+                if (PGL_V2 == 2) wait_ticket(2, h_target - NW);
                 pgl_dma_half<KTL>(fimg + (size_t)(tile + 1) * IMGS, Ln, wave, lane);
+                if (PGL_V2) wait_h();
                 pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, wave, lane);
             }
             PGL_PROF_MARK(3);
@@ -1721,9 +1775,13 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                          fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, more);
             }
             PGL_PROF_MARK(4);
+            if (PGL_V2 == 2) add_ticket(2);              // done with L_i (forward and backward)
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
             PGL_PROF_MARK(5);
-            __syncthreads();
+            if (PGL_V2 == 2)
+                add_ticket(1);
+            else
+                __syncthreads();
             PGL_PROF_MARK(6);
         }
         PGL_PROF_STORE(1);
@@ -1787,13 +1845,211 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 }
 
 // ---------------------------------------------------------------------------
+// Fused ll + grad kernel, version 6: the K-split scheme of k_fused2 (PTW post tiles x KSPLIT slices of
+// the feature columns over the 8 waves of a workgroup, ONE pass, G in registers) on RESIDENT feature
+// tiles -- for the populations whose whole feature row is short (N*B + Dstim <= ~320 columns: C1, C2,
+// C5, masked subsets of them), where k_fused5's one-wave-per-post-tile layout would leave most waves
+// idle and k_fused2 spends more time regenerating features than multiplying them.
+//   image of one 16-bin tile = [16][RS] f64, RS = 16*KT_ALL + 2, padded to 1 KiB (k_build_fimg, one part)
+//   a STEP covers MT consecutive tiles (MT = 2 when the images are small): the three workgroup barriers
+//   of the scheme (images landed | partial currents exchanged | residuals exchanged) are paid once per
+//   step; the images of step i+1 arrive by LDS-DMA in the other buffer while step i computes.
+// Same partial layout as k_fused2 (k_finalize / k_finalize_ll reduce it).
+// ---------------------------------------------------------------------------
+template <int KTW, int PTW, int MT>
+__global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
+{
+    constexpr int TT = 16, NW = 8;
+    constexpr int KSPLIT = NW / PTW;
+    constexpr int KSW = KTW * 4;
+    constexpr int KT_ALL = KTW * KSPLIT;
+    constexpr int KS_ALL = KSW * KSPLIT;
+    constexpr int RS = pgl_img_rsh(KT_ALL);
+    constexpr int IMG = pgl_img_bytes(KT_ALL);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptl = wave % PTW;
+    const int ksl = wave / PTW;
+    const int nPB = (p.nPT + PTW - 1) / PTW;
+    const int pb = blockIdx.x % nPB;
+    const int chunk = blockIdx.x / nPB;
+    const int pt = pb * PTW + ptl;
+    const bool active = pt < p.nPT;
+
+    unsigned char* bufs = smem;                                          // [2][MT][IMG]
+    double* Xp = reinterpret_cast<double*>(smem + (size_t)2 * MT * IMG); // [MT][NW][4][64] partial currents
+    double* Rb = Xp + (size_t)MT * NW * 256;                             // [MT][PTW][4][64] residuals
+    double* Cs = Rb + (size_t)MT * PTW * 256;                            // [32] math constants
+    if (tid < 32) Cs[tid] = PGL_C[tid];
+
+    d4_t G[KTW];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double ll_acc = 0.0, gb_acc = 0.0;
+
+    const int col = lane & 15;
+    const int grp = lane >> 4;
+    const int nloc = pt * 16 + col;
+    const bool valid_n = active && (nloc < p.npost);
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
+    const double bias_l = valid_n ? p.bias[nloc] : 0.0;
+    const double* __restrict__ wrow =
+        p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
+    const int kcol0 = ksl * KTW * 16;
+    // epilogue ownership as in k_fused2: the 256 elements of a post tile are split over its KSPLIT waves
+    constexpr int EPW = (KSPLIT >= 4) ? 1 : 4 / KSPLIT;
+    int er[EPW];
+#pragma unroll
+    for (int e = 0; e < EPW; ++e) er[e] = (KSPLIT == 8) ? (ksl >> 1) : (KSPLIT == 4) ? ksl : ksl * EPW + e;
+    const bool emine = (KSPLIT == 8) ? ((lane >> 5) == (ksl & 1)) : true;
+
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
+    int tile_end = tile_beg + p.tilesPerChunk;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
+    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG;
+
+    auto dma_step = [&](const int tile0s, unsigned char* dst) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (tile0s + m < tile_end)
+                pgl_dma_half<KT_ALL>(fimg + (size_t)(tile0s + m) * IMG, dst + (size_t)m * IMG, wave, lane);
+    };
+    if (tile_beg < tile_end) dma_step(tile_beg, bufs);
+
+    int par = 0;
+    for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
+        const unsigned char* cur = bufs + (size_t)par * MT * IMG;
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces of the step landed
+        __syncthreads();                                  // ... everybody's; the other buffer is free
+        if (tile + MT < tile_end) dma_step(tile + MT, bufs + (size_t)(par ^ 1) * MT * IMG);
+        // post-synaptic counts of the elements this wave owns in the epilogue
+        double sc[MT][EPW];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int e = 0; e < EPW; ++e) {
+                const long long tg = (long long)(tile + m) * TT + grp + 4 * er[e];
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+                sc[m][e] = (double)p.S[tc * p.Nall + nglob];
+            }
+        }
+        // ---- forward over this wave's K slice, tile by tile ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
+            d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+            if (active && tile + m < tile_end) {
+                const double* fa = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + col * RS + kcol0 + grp;
+                const double* wr_s = wrow;
+                asm volatile("" : "+s"(wr_s));
+                constexpr int PW2 = (KSW / 2 < PGL_PW / 2) ? KSW / 2 : PGL_PW / 2;
+                constexpr int PA = (KSW < 4) ? KSW : 4;
+                const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
+                pgl_d2 wr[PW2];
+                double ar[PA];
+#pragma unroll
+                for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+#pragma unroll
+                for (int s = 0; s < PA; ++s) ar[s] = fa[4 * s];
+#pragma unroll
+                for (int s = 0; s < KSW; ++s) {
+                    const double a = ar[s % PA];
+                    const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
+                    if (s + PA < KSW) ar[s % PA] = fa[4 * (s + PA)];
+                    if ((s & 1) && (s / 2 + PW2 < KSW / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
+                    if (s & 1)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            double* xw = Xp + ((size_t)m * NW + wave) * 256 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xw[r * 64] = acc0[r] + acc1[r];
+        }
+        __syncthreads();
+        // ---- epilogue: sum of the KSPLIT partials + bias -> ll terms, residuals ----
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                double xe[EPW], rese[EPW], terme[EPW];
+                bool vte[EPW];
+#pragma unroll
+                for (int e = 0; e < EPW; ++e) {
+                    const int r = er[e];
+                    double x = bias_l;
+#pragma unroll
+                    for (int k2 = 0; k2 < KSPLIT; ++k2)
+                        x += Xp[((size_t)m * NW + ptl + PTW * k2) * 256 + r * 64 + lane];
+                    const long long tg = (long long)(tile + m) * TT + grp + 4 * r;
+                    vte[e] = valid_n && (tg < p.t_hi) && emine && (tile + m < tile_end);
+                    xe[e] = x;
+                }
+                pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                asm volatile("" : "+v"(Cl));
+                pgl_rate_terms_n<EPW>(xe, sc[m], p.nlin, p.dt, terme, rese, Cl);
+#pragma unroll
+                for (int e = 0; e < EPW; ++e) {
+                    const double res = vte[e] ? rese[e] : 0.0;
+                    ll_acc += vte[e] ? terme[e] : 0.0;
+                    gb_acc += res;
+                    if (emine) Rb[((size_t)m * PTW + ptl) * 256 + er[e] * 64 + lane] = res;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- backward on this wave's K slice ----
+        if (active && p.want_grad) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (tile + m >= tile_end) break;
+                double rr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rr[r] = Rb[((size_t)m * PTW + ptl) * 256 + r * 64 + lane];
+                const double* fb = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + grp * RS + kcol0 + col;
+                constexpr int NS = 4 * KTW;
+                constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
+                double ar[PD];
+#pragma unroll
+                for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTW)) * RS + 16 * (s % KTW)];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double a = ar[s % PD];
+                    if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTW)) * RS + 16 * ((s + PD) % KTW)];
+                    G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KTW], G[s % KTW], 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    if (active) {
+        const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
+        p.llpart[slot * 64 + lane] = ll_acc;
+        p.gbpart[slot * 64 + lane] = gb_acc;
+        if (p.want_grad) {
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + (size_t)ksl * KTW) * 256 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // prep: Wmat in MFMA B-fragment order + bias vector
 //   Wfrag[pt][ks][lane] = Wmat[k = 4ks + (lane>>4)][n = 16pt + (lane&15)]
 // ---------------------------------------------------------------------------
 __global__ void k_prep_w(const double* __restrict__ theta, const double* __restrict__ Weff,
                          double* __restrict__ Wfrag, double* __restrict__ bias, int N, int B,
                          int Dstim, int Kimp, int Ktot, int KS, int n_lo, int npost, int nPT,
-                         int pair, int Nall, int np0, int DsAll, int ds0)
+                         int pair, int Nall, int np0, int DsAll, int ds0, const int* __restrict__ pidx)
 {
     // N / Dstim / Kimp describe the launch's feature-column slice (see FusedParams)
     const int P = 1 + DsAll + Nall * B;
@@ -1809,7 +2065,7 @@ __global__ void k_prep_w(const double* __restrict__ theta, const double* __restr
         if (n < npost && k < Ktot) {
             if (k < Kimp) {
                 const int npre = np0 + k / B;
-                v = theta[(size_t)n * P + 1 + DsAll + np0 * B + k] * Weff[(size_t)npre * Nall + (n_lo + n)];
+                v = theta[(size_t)n * P + 1 + DsAll + np0 * B + k] * Weff[(size_t)npre * Nall + (pidx ? pidx[n] : n_lo + n)];
             } else {
                 v = theta[(size_t)n * P + 1 + ds0 + (k - Kimp)];
             }
@@ -1831,7 +2087,7 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
                            int nChunks, int Nall, int np0, int DsAll, int ds0, int nsub, int kt0,
-                           int nkt)
+                           int nkt, const int* __restrict__ pidx)
 {
     // reduces the k-tiles [kt0, kt0 + nkt) of every post tile (the two halves of the two-pass
     // kernels are reduced by separate launches: the first one runs beside pass 2)
@@ -1888,7 +2144,7 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
             const double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
             if (k < Kimp) {
                 const int npre = np0 + k / B;
-                grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (n_lo + n)];
+                grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (pidx ? pidx[n] : n_lo + n)];
             } else {
                 grad_out[(size_t)n * P + 1 + ds0 + (k - Kimp)] = s;
             }
@@ -1937,7 +2193,8 @@ __global__ __launch_bounds__(256) void k_rows_epilogue(double* __restrict__ Xbuf
                                                        int n_lo, int npost, long long t_lo,
                                                        long long t_hi, int rows, int nlin, double dt,
                                                        double* __restrict__ llp,
-                                                       double* __restrict__ gbp)
+                                                       double* __restrict__ gbp,
+                                                       const int* __restrict__ pidx)
 {
     const int n = blockIdx.y * 256 + threadIdx.x;
     if (n >= npost) return;
@@ -1948,7 +2205,7 @@ __global__ __launch_bounds__(256) void k_rows_epilogue(double* __restrict__ Xbuf
     double ll = 0.0, gb = 0.0;
     for (long long t = t0; t < t1; ++t) {
         const double x = Xbuf[t * xstride + n] + b;
-        const double s = (double)S[t * Nall + n_lo + n];
+        const double s = (double)S[t * Nall + (pidx ? pidx[n] : n_lo + n)];
         double term, res;
         pgl_rate_terms(x, s, nlin, dt, term, res, PGL_C);
         ll += term;
@@ -2120,8 +2377,8 @@ __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ b
                                                     const double* __restrict__ stim,
                                                     const double* __restrict__ colv, double bias,
                                                     double aw_cur, const PglWeights wv,
-                                                    int K, int nlin, double dt, long long nT,
-                                                    double* __restrict__ part)
+                                                    int K, int nlin, double dt, long long t_lo,
+                                                    long long nT, double* __restrict__ part)
 {
     __shared__ double red[4][PGL_KMAX];
     double wk[PGL_KMAX], acc[PGL_KMAX];
@@ -2130,7 +2387,7 @@ __global__ __launch_bounds__(256) void k_ll_current(const double* __restrict__ b
         wk[k] = (k < K) ? wv.w[k] : 0.0;
         acc[k] = 0.0;
     }
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nT;
+    for (long long t = t_lo + blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nT;
          t += (long long)gridDim.x * blockDim.x) {
         const double c = colv[t];
         const double x0 = bias + (stim ? stim[t] : 0.0) + base[t] - aw_cur * c;
@@ -2205,6 +2462,240 @@ __global__ __launch_bounds__(64) void k_reduce_parts(const double* __restrict__ 
     for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(size_t)b * PGL_KMAX + k];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) out[k] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Collapsed-Gibbs inner ll for MANY post-synaptic columns per launch (gibbs.py:977-1066).  The
+// columns (A[:,n], W[:,n]) are conditionally independent given the rest -- the reference maps them
+// over its engines (parallel_gibbs.py:162-165) -- so one launch evaluates, for every listed column
+// c = (n_post, n_pre), the K candidate weights of the pair:
+//   ic[t]   = sum_b fS[t,n_pre,b] * beta[n_post][n_pre][b]        (impulse.py:58 / 308, from the events)
+//   x_k[t]  = bias + GX[t][n_post] - aw_cur*ic[t] + w_k*ic[t]     (gibbs.py:914: rank-1 downdate of
+//             the resident total current instead of the (nT,N) gemv per pair, gibbs.py:835-864)
+//   ll_k    = sum_t -dt*lam_k + S[t,n_post]*log(lam_k)            (gibbs.py:910-937, glm.py:52)
+// GX (nT, xs) holds I_stim + I_net of all post neurons (forward-only MFMA pass at prepare time).
+// Thread = one column (tid % CP) and every (256/CP)-th bin of the block's rows; four elements per
+// lane and pass.  log(lam) is needed for the ~2 % of bins with a spike only: those elements are
+// compacted through a per-wave LDS list (rank by ballot), evaluated once per pass by the first
+// lanes and read back by their owners -- fixed order, so results are reproducible.
+//   part[(bt * ncols + c) * PGL_KMAX + k]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double pgl_pair_current(const int2* __restrict__ spk, const int lo, const int hi,
+                                                   const int tg, const int R, const int B,
+                                                   const double* __restrict__ phiS,
+                                                   const double (&beta)[PGL_MAXB])
+{
+    double a = 0.0;
+    for (int j = lo; j < hi; ++j) {
+        const int2 e = spk[j];
+        const int d = tg - e.x - 1;
+        if (d >= 0 && d < R) {
+            double hh = 0.0;
+            for (int b = 0; b < B; ++b) hh = fma(phiS[b * R + d], beta[b], hh);
+            a = fma((double)e.y, hh, a);
+        }
+    }
+    return a;
+}
+
+struct GibbsColsParams {
+    const double* __restrict__ GX;       // (nT, xs) I_stim + I_net of every post neuron
+    int xs;
+    const uint8_t* __restrict__ S;       // (nT, N) counts
+    int N, B, R, P, woff;                // woff = 1 + Dstim: first impulse weight of a theta row
+    const int2* __restrict__ spk;
+    const int* __restrict__ wlo;
+    const int* __restrict__ whi;
+    const double* __restrict__ phi;      // [B][R]
+    const double* __restrict__ theta;    // (N, P) flat feature weights given at prepare time
+    const int* __restrict__ cols;        // [ncols] n_post
+    const int* __restrict__ pre;         // [ncols] n_pre
+    const double* __restrict__ aw;       // [ncols] current A*W of the pair (part of GX)
+    const double* __restrict__ w;        // [ncols][K] candidate weights (ll) / [ncols] deltas (update)
+    int ncols, CP, K, nlin;
+    double dt;
+    long long t_lo, t_hi;
+    int rows;                            // bins per block
+    double* __restrict__ part;
+};
+
+__global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* phiS = reinterpret_cast<double*>(smem);                 // [B][R]
+    double* wS = phiS + p.B * p.R;                                  // [CP][K]
+    double* scr = wS + p.CP * p.K;                                  // per wave: 64 x (x0, ic, s, col) + 64 x K
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, CP = p.CP, RPB = 256 / CP;
+    const int cl = tid % CP, rsub = tid / CP;
+    const int c = blockIdx.y * CP + cl;
+    const bool valid = c < p.ncols;
+    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
+    for (int i = tid; i < CP * K; i += 256) {
+        const int cc = blockIdx.y * CP + i / K;
+        wS[i] = (cc < p.ncols) ? p.w[(size_t)cc * K + i % K] : 0.0;
+    }
+    double* ent = scr + (size_t)wave * (64 * 4 + 64 * PGL_KMAX);    // [64][4]
+    double* outv = ent + 64 * 4;                                    // [64][PGL_KMAX]
+    __syncthreads();
+
+    const int n = valid ? p.cols[c] : 0, np = valid ? p.pre[c] : 0;
+    const double awc = valid ? p.aw[c] : 0.0;
+    const double bias = valid ? p.theta[(size_t)n * p.P] : 0.0;
+    double beta[PGL_MAXB];
+#pragma unroll
+    for (int b = 0; b < PGL_MAXB; ++b)
+        beta[b] = (valid && b < p.B) ? p.theta[(size_t)n * p.P + p.woff + np * p.B + b] : 0.0;
+    double acc[PGL_KMAX];
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
+
+    const long long tb0 = p.t_lo + (long long)blockIdx.x * p.rows;
+    long long tb1 = tb0 + p.rows;
+    if (tb1 > p.t_hi) tb1 = p.t_hi;
+    // passes of 4*RPB rows: element i of this lane is row tp + rsub + i*RPB
+    for (long long tp = tb0; tp < tb1; tp += 4 * RPB) {
+        double x0[4], ic[4];
+        unsigned sc[4];
+        bool live[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long t = tp + rsub + (long long)i * RPB;
+            live[i] = valid && t < tb1;
+            const long long tc = live[i] ? t : p.t_lo;
+            const int tile = (int)(tc >> 4);
+            ic[i] = live[i] ? pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + np], p.whi[(size_t)tile * p.N + np],
+                                               (int)tc, p.R, p.B, phiS, beta)
+                            : 0.0;
+            // idle elements get a benign current (series regime of the softplus)
+            x0[i] = live[i] ? (bias + p.GX[tc * p.xs + n]) - awc * ic[i] : (p.nlin == 1 ? 30.0 : 0.0);
+            sc[i] = live[i] ? p.S[tc * p.N + n] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < PGL_KMAX; ++k) {
+            if (k < K) {
+                const double wk = wS[cl * K + k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double lam = pgl_lambda_only(fma(wk, ic[i], x0[i]), p.nlin, PGL_C);
+                    // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
+                    const double v = (lam == 0.0) ? __builtin_nan("") : -p.dt * lam;
+                    acc[k] += live[i] ? v : 0.0;
+                }
+            }
+        }
+        // ---- spike terms, compacted per wave ----
+        unsigned long long m[4];
+        int cnt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = __ballot(sc[i] != 0u);
+            cnt[i] = __popcll(m[i]);
+        }
+        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (total == 0) continue;
+        int slot[4];
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            slot[i] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[i] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m[i], 0u));
+            base += cnt[i];
+        }
+        for (int r0 = 0; r0 < total; r0 += 64) {                    // rounds of 64 entries (almost always one)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (sc[i] != 0u && slot[i] >= r0 && slot[i] < r0 + 64) {
+                    double* e = ent + (size_t)(slot[i] - r0) * 4;
+                    e[0] = x0[i]; e[1] = ic[i]; e[2] = (double)sc[i]; e[3] = (double)cl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (r0 + lane < total) {
+                const double* e = ent + (size_t)lane * 4;
+                const double ex0 = e[0], eic = e[1], es = e[2];
+                const int ecl = (int)e[3];
+                for (int k = 0; k < K; ++k) {
+                    const double x = fma(wS[ecl * K + k], eic, ex0);
+                    double loglam = x;
+                    if (p.nlin == 1) {
+                        // pgl_lambda_only's wave-uniform series test would see a partial wave here
+                        const double ee = pgl_exp(-fabs(x), PGL_C);
+                        const double u = 1.0 + ee;
+                        const double lam = fmax(x, 0.0) + (pgl_log(u, PGL_C) + (ee - (u - 1.0)) * pgl_rcp(u));
+                        loglam = pgl_log(lam, PGL_C);
+                    }
+                    outv[(size_t)lane * PGL_KMAX + k] = es * loglam;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (sc[i] != 0u && slot[i] >= r0 && slot[i] < r0 + 64) {
+                    const double* o = outv + (size_t)(slot[i] - r0) * PGL_KMAX;
+                    for (int k = 0; k < K; ++k) acc[k] += o[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- block reduction per column: rows rsub = 0..RPB-1 of the same column, fixed order ----
+    __syncthreads();
+    double* red = scr;                                              // [256][PGL_KMAX]
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) red[(size_t)tid * PGL_KMAX + k] = acc[k];
+    __syncthreads();
+    if (rsub == 0 && valid) {
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int r = 0; r < RPB; ++r) s += red[(size_t)(r * CP + cl) * PGL_KMAX + k];
+            p.part[((size_t)blockIdx.x * p.ncols + c) * PGL_KMAX + k] = s;
+        }
+    }
+}
+
+// out[c][k] = sum over the time blocks (fixed order); grid = ncols, block = 64
+__global__ __launch_bounds__(64) void k_gibbs_reduce_cols(const double* __restrict__ part, int nblk,
+                                                          int ncols, int K, double* __restrict__ out)
+{
+    const int c = blockIdx.x;
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 64) s += part[((size_t)b * ncols + c) * PGL_KMAX + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x == 0) out[(size_t)c * K + k] = s;
+    }
+}
+
+// GX[t][n_post] += delta_c * ic_c[t] for the listed columns (gibbs.py:1044-1066 writes the new
+// (A, W) sample; here the resident total current follows it)
+__global__ __launch_bounds__(256) void k_gibbs_update_cols(const GibbsColsParams p, double* __restrict__ GXw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* phiS = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x;
+    const int CP = p.CP, RPB = 256 / CP;
+    const int cl = tid % CP, rsub = tid / CP;
+    const int c = blockIdx.y * CP + cl;
+    const bool valid = c < p.ncols;
+    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
+    __syncthreads();
+    if (!valid) return;
+    const int n = p.cols[c], np = p.pre[c];
+    const double delta = p.w[c];
+    double beta[PGL_MAXB];
+#pragma unroll
+    for (int b = 0; b < PGL_MAXB; ++b)
+        beta[b] = (b < p.B) ? p.theta[(size_t)n * p.P + p.woff + np * p.B + b] : 0.0;
+    const long long tb0 = p.t_lo + (long long)blockIdx.x * p.rows;
+    long long tb1 = tb0 + p.rows;
+    if (tb1 > p.t_hi) tb1 = p.t_hi;
+    for (long long t = tb0 + rsub; t < tb1; t += RPB) {
+        const int tile = (int)(t >> 4);
+        const double ic = pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + np], p.whi[(size_t)tile * p.N + np],
+                                           (int)t, p.R, p.B, phiS, beta);
+        GXw[t * p.xs + n] = fma(delta, ic, GXw[t * p.xs + n]);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -92,6 +92,8 @@ def run_xv(popn, data, models, train_frac=0.75, batched='torch', rng=None, verbo
     finally:
         popn.data_sequences = full_sequences
         popn.set_data(data)
+        popn.release_data(train_data)         # the split handles (and their resident features) die here
+        popn.release_data(xv_data)
     # refit the winner on all data, warm-started from its training optimum (:81-88)
     if best_model is not None:
         popn.set_hyperparameters(best_model)

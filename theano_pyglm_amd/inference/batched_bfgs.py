@@ -55,7 +55,16 @@ def _prior_terms(population, torch, X):
 
 
 def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False):
-    """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations)."""
+    """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations).
+
+    Everything runs on one dedicated torch stream: the device handles are switched to it
+    (pgl_set_stream), so prior terms, the fused ll+grad launches, the line-search bookkeeping and the
+    inverse-Hessian updates are ordered by the stream -- no host synchronisation per evaluation; the
+    host only reads the handful of scalars that steer the loop.  Neurons whose line search has
+    already succeeded are masked out of the launch (pgl_ll_grad_list_dev evaluates an arbitrary
+    list of neurons), so late, poorly conditioned neurons do not pay for the whole population.
+    A neuron whose backtracking fails restarts once from steepest descent before it is frozen
+    (scipy's BFGS stops there with "precision loss", coord_descent.py:194-199)."""
     import torch
     if not supported(population):
         raise Exception("batched GPU BFGS needs LinearBasisImpulses and No/Basis stimulus")
@@ -67,23 +76,45 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     for data in population.data_sequences:
         population.set_data(data)
         handles.append(population._handle(data))
+    stream = torch.cuda.Stream(dev)
+    for h in handles:
+        h.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            out = _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose)
+            stream.synchronize()
+    finally:
+        for h in handles:
+            h.set_stream(None)
+    return out
+
+
+def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose):
     X = torch.tensor(population.theta_matrix(x, n_lo, n_hi), dtype=torch.float64, device=dev)
     P = X.shape[1]
     Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
-    ll = torch.zeros(M, dtype=torch.float64, device=dev)
-    gr = torch.zeros((M, P), dtype=torch.float64, device=dev)
     n_evals = [0]
+    neuron_evals = [0]
+    rows_all = torch.arange(M, device=dev)
 
-    def evaluate(Xt):
+    def evaluate(Xt, rows=None):
+        """nlp and its gradient for the rows `rows` (default all) of the shard, at Xt (len(rows), P)."""
         Xt = Xt.contiguous()
+        cnt = Xt.shape[0]
         lp, G = _prior_terms(population, torch, Xt)
-        torch.cuda.current_stream(dev).synchronize()
+        idx = None if rows is None or cnt == M else (rows + n_lo).to(torch.int32).contiguous()
         for h in handles:
-            h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(), gr.data_ptr(), n_lo, n_hi)
-            h.sync()
+            ll = torch.empty(cnt, dtype=torch.float64, device=dev)
+            gr = torch.empty((cnt, P), dtype=torch.float64, device=dev)
+            if idx is None:
+                h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(), gr.data_ptr(), n_lo, n_hi)
+            else:
+                h.ll_grad_list_dev(idx.data_ptr(), cnt, Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(),
+                                   gr.data_ptr())
             lp = lp + ll
             G = G + gr
         n_evals[0] += 1
+        neuron_evals[0] += cnt
         f, g = -lp, -G
         f = torch.where(torch.isnan(f), torch.full_like(f, 1e16), f)
         bad = torch.isnan(g).any(1)
@@ -91,8 +122,11 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         return f, g
 
     f, g = evaluate(X)
-    H = torch.eye(P, dtype=torch.float64, device=dev).repeat(M, 1, 1)
+    eye = torch.eye(P, dtype=torch.float64, device=dev)
+    H = eye.repeat(M, 1, 1)
     active = g.abs().amax(1) > gtol
+    frozen = torch.zeros(M, dtype=torch.bool, device=dev)       # line search failed twice in a row
+    restarts = torch.zeros(M, dtype=torch.int64, device=dev)
     it = 0
     while it < maxiter and bool(active.any()):
         it += 1
@@ -100,25 +134,27 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         slope = (p * g).sum(1)
         bad = slope >= 0
         if bool(bad.any()):
-            H[bad] = torch.eye(P, dtype=torch.float64, device=dev)
+            H[bad] = eye
             p = torch.where(bad[:, None], -g, p)
             slope = (p * g).sum(1)
         alpha = torch.ones(M, dtype=torch.float64, device=dev)
         if it == 1:
             alpha = torch.clamp(1.0 / g.norm(dim=1).clamp_min(1e-300), max=1.0)
+        first = restarts > 0                                        # restarted from H = I: scale like the first step
+        alpha = torch.where(first, torch.clamp(1.0 / g.norm(dim=1).clamp_min(1e-300), max=1.0), alpha)
         done = ~active
         Xn, fn, gn = X.clone(), f.clone(), g.clone()
         for _ls in range(30):
-            Xt = torch.where(done[:, None], Xn, X + alpha[:, None] * p)
-            ft, gt = evaluate(Xt)
-            ok = (~done) & (ft <= f + 1e-4 * alpha * slope)
-            Xn = torch.where(ok[:, None], Xt, Xn)
-            fn = torch.where(ok, ft, fn)
-            gn = torch.where(ok[:, None], gt, gn)
-            done = done | ok
-            if bool(done.all()):
+            rows = rows_all[~done]
+            if rows.numel() == 0:
                 break
-            alpha = torch.where(done, alpha, alpha * 0.5)
+            Xt = X[rows] + alpha[rows, None] * p[rows]
+            ft, gt = evaluate(Xt, rows)
+            ok = ft <= f[rows] + 1e-4 * alpha[rows] * slope[rows]
+            sel = rows[ok]
+            Xn[sel], fn[sel], gn[sel] = Xt[ok], ft[ok], gt[ok]
+            done[sel] = True
+            alpha[rows[~ok]] *= 0.5
         stalled = ~done
         s = Xn - X
         y = gn - g
@@ -132,10 +168,18 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
             H += c[:, None, None] * (s[:, :, None] * s[:, None, :])
             H -= rho[:, None, None] * (Hy[:, :, None] * s[:, None, :] + s[:, :, None] * Hy[:, None, :])
         X, f, g = Xn, fn, gn
-        active = active & (~stalled) & (g.abs().amax(1) > gtol)
+        # a failed line search: one restart from steepest descent, then the neuron is frozen
+        again = stalled & (restarts == 0)
+        H[again] = eye
+        restarts = torch.where(again, restarts + 1, torch.where(stalled, restarts, torch.zeros_like(restarts)))
+        frozen = frozen | (stalled & ~again)
+        active = active & (~frozen) & (g.abs().amax(1) > gtol)
         if verbose:
             print("batched BFGS iter %d: active %d, mean nlp %.3f, evals %d"
                   % (it, int(active.sum()), float(f.mean()), n_evals[0]))
+    gmax = g.abs().amax(1)
+    n_conv = int((gmax <= gtol).sum())
+    n_frozen = int((frozen & (gmax > gtol)).sum())
     Xh = X.cpu().numpy()
     D = population.glm.Dstim
     for i, n in enumerate(range(n_lo, n_hi)):
@@ -144,5 +188,8 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         if D > 0:
             xn['bkgd']['w_stim'] = Xh[i, 1:1 + D].copy()
         xn['imp']['w_ir'] = Xh[i, 1 + D:].copy()
-    population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0]}
+    population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
+                                 'neuron_evaluations': neuron_evals[0],
+                                 'converged_gtol': n_conv, 'stalled': n_frozen,
+                                 'maxiter': M - n_conv - n_frozen}
     return f.cpu().numpy(), it, n_evals[0]

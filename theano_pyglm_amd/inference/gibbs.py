@@ -318,25 +318,96 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         F = F / F[-1]
         return float(np.interp(self.rng.random_sample(), F, ws))
 
-    def _adaptive_rejection_sample_w(self, h, n_pre, aw_cur, mu_w, sigma_w, ws, log_L):
+    def _adaptive_rejection_sample_w(self, ll_of_w, mu_w, sigma_w, ws, log_L):
         """gibbs.py:1087-1126: ARS on log N(w; mu_w, sigma_w) + ll(w), started from the quadrature
-        nodes with finite, moderate values; the density is shifted by its maximum over the nodes."""
+        nodes with finite, moderate values; the density is shifted by its maximum over the nodes.
+        ll_of_w(w) is one more device inner-ll evaluation of the pair."""
         log_post = -0.5 / sigma_w ** 2 * (ws - mu_w) ** 2 + log_L
         Z = np.amax(log_post[np.isfinite(log_post)])
         valid = np.isfinite(log_post) & (log_post > -1e8) & (log_post < 1e8)
 
         def f(w):
             self.n_ars_evals += 1
-            ll = h.gibbs_ll(n_pre, aw_cur, np.array([w]))[0]
+            ll = ll_of_w(w)
             v = -0.5 / sigma_w ** 2 * (w - mu_w) ** 2 + ll - Z
             return v if np.isfinite(v) else -np.inf
 
         return float(adaptive_rejection_sample(f, ws[valid], log_post[valid] - Z, (-np.inf, np.inf),
                                                stepsz=sigma_w / 2.0, rng=self.rng))
 
-    def update_all(self, x):
-        for n in range(self.population.N):
-            self.update(x, n)
+    def update_all(self, x, cols=None):
+        """One pair (n_pre -> n_post) of EVERY column per device launch.  Given the rest of the state
+        the columns are conditionally independent (the reference maps them over its engines and merges
+        the columns afterwards, parallel_gibbs.py:24-37, 162-165); each column visits its presynaptic
+        neurons in its own random order (gibbs.py:1238).  Step j of the sweep evaluates the 10
+        Gauss-Hermite nodes + w = 0 (gibbs.py:1002-1032) of pair (perm_c[j], c) for all columns c in
+        one launch (pgl_gibbs_ll_cols), draws A for all of them with numpy vector arithmetic, runs ARS
+        only for the columns whose edge came up, and applies the rank-1 current updates in one launch.
+        `cols`: the post-synaptic columns to resample (default all; a rank's shard in multi-GPU runs)."""
+        pop = self.population
+        N = pop.N
+        if len(pop.data_sequences) != 1:
+            for n in (range(N) if cols is None else cols):
+                self.update(x, n)
+            return x
+        pop.set_data(pop.data_sequences[0])
+        h = pop._handle(pop._current)
+        cols = np.arange(N) if cols is None else np.asarray(cols, dtype=int)
+        nc = len(cols)
+        A = np.array(x['net']['graph']['A']).reshape(N, N)
+        W = np.array(x['net']['weights']['W'], dtype=float).reshape(N, N)
+        h.gibbs_prepare_all(pop.theta_matrix(x), A * W)
+        pA = np.asarray(self.network.graph.pA, dtype=float) * np.ones((N, N))
+        with np.errstate(divide='ignore'):
+            log_pA, log_pnA = np.log(pA), np.log(1.0 - pA)
+        log_gh = np.log(self.GAUSS_HERMITE_WEIGHTS / np.sqrt(np.pi))
+        absc = np.sqrt(2) * self.GAUSS_HERMITE_ABSCISSAE
+        perms = np.array([self.rng.permutation(N) for _ in range(nc)])
+        self.last_stats = []
+        for j in range(N):
+            n_pre = perms[:, j]
+            ref = n_pre == cols
+            mu = np.where(ref, self.mu_w_ref, self.mu_w)
+            sg = np.where(ref, self.sigma_w_ref, self.sigma_w)
+            W_nns = sg[:, None] * absc[None, :] + mu[:, None]                   # gibbs.py:1004
+            probes = np.concatenate((W_nns, np.zeros((nc, 1))), axis=1)
+            aw_cur = (A[n_pre, cols] * W[n_pre, cols]).astype(float)
+            ll = h.gibbs_ll_cols(cols, n_pre, aw_cur, probes)
+            log_L, ll_noA = ll[:, :-1], ll[:, -1]
+            wl = log_L + log_gh[None, :]                                         # gibbs.py:1015-1022
+            wl[np.isnan(wl)] = -np.inf
+            mx = wl.max(axis=1)
+            if not np.all(np.isfinite(mx)):
+                raise Exception("log_G not finie")
+            log_G = mx + np.log(np.exp(wl - mx[:, None]).sum(axis=1))
+            log_pr_A = log_pA[n_pre, cols] + log_G
+            log_pr_noA = log_pnA[n_pre, cols] + ll_noA
+            log_pr_noA[np.isnan(log_pr_noA)] = -np.inf
+            m2 = np.maximum(log_pr_noA, log_pr_A)
+            if not np.all(np.isfinite(m2)):
+                raise Exception("log_sum_exp_sample: no finite entry")
+            p0 = np.exp(log_pr_noA - m2)                                         # log_sum_exp.py:4-37
+            a_new = np.where(self.rng.random_sample(nc) * (p0 + np.exp(log_pr_A - m2)) < p0, 0, 1)
+            w_new = mu + sg * self.rng.standard_normal(nc)                      # gibbs.py:1060-1062
+            for i in np.nonzero(a_new)[0]:
+                c1, p1, aw1 = cols[i:i + 1], n_pre[i:i + 1], aw_cur[i:i + 1]
+                if self.w_sampler == 'ars':
+                    w_new[i] = self._adaptive_rejection_sample_w(
+                        lambda w: float(h.gibbs_ll_cols(c1, p1, aw1, np.array([[w]]))[0, 0]),
+                        mu[i], sg[i], W_nns[i], log_L[i])
+                else:
+                    grid = mu[i] + sg[i] * np.linspace(-4.0, 4.0, self.n_grid)
+                    w_new[i] = self._inverse_cdf_sample_w(mu[i], sg[i], grid,
+                                                          h.gibbs_ll_cols(c1, p1, aw1, grid[None, :])[0])
+            delta = a_new * w_new - aw_cur
+            nz = delta != 0.0
+            if np.any(nz):
+                h.gibbs_update_cols(cols[nz], n_pre[nz], delta[nz])
+            A[n_pre, cols] = a_new
+            W[n_pre, cols] = w_new
+            self.last_stats.append((n_pre.copy(), log_G, ll_noA.copy()))
+        x['net']['graph']['A'] = A.astype(np.asarray(x['net']['graph']['A']).dtype)
+        x['net']['weights']['W'] = W.ravel()
         return x
 
     def update(self, x, n_post):
@@ -385,7 +456,8 @@ class CollapsedGibbsNetworkColumnUpdate(object):
             p0 = np.exp(log_pr_noA - m2)
             a_new = 0 if rnd() * (p0 + np.exp(log_pr_A - m2)) < p0 else 1
             if a_new == 1 and self.w_sampler == 'ars':
-                w_new = self._adaptive_rejection_sample_w(h, n_pre, aw_cur, mu_w, sigma_w, W_nns, log_L)
+                w_new = self._adaptive_rejection_sample_w(
+                    lambda w: h.gibbs_ll(n_pre, aw_cur, np.array([w]))[0], mu_w, sigma_w, W_nns, log_L)
             elif a_new == 1:
                 grid = mu_w + sigma_w * np.linspace(-4.0, 4.0, self.n_grid)
                 w_new = self._inverse_cdf_sample_w(mu_w, sigma_w, grid,
@@ -442,6 +514,7 @@ def gibbs_sample(population, N_samples=1000, x0=None, init_from_mle=True, callba
             mle_x0 = coord_descent(mle_popn, x0=mle_popn.sample(rng if rng is not np.random else None),
                                    maxiter=1, batched='torch')
             x0 = convert_model(mle_popn, mle_model, mle_x0, population, population.model, x0)
+            mle_popn.release_data()              # the MAP population's own handles (resident features)
     serial_updates, parallel_updates = initialize_updates(population, rng)
     x = x0
     x_smpls = [copy.deepcopy(x0)]      # (the reference stores x0 itself, which its in-place updates then overwrite)

@@ -1,0 +1,109 @@
+"""
+MAP coordinate descent with the post-synaptic neurons sharded over the GPUs of one node --
+counterpart of pyglm/inference/parallel_coord_descent.py (and of utils/parallel_util.py's
+engine setup), one process per GPU over torch.distributed (RCCL on the GPU box).
+
+The reference pushes the data to every IPython engine (parallel_util.py:154-183), maps
+`_parallel_fit_glm` over range(N) (parallel_coord_descent.py:137-139), gathers the fitted
+per-neuron dicts (:147) and evaluates the population log p by mapping `_compute_glm_lp` over the
+neurons and summing (:16-55).  Here rank r
+
+  * receives the data once (parallel.broadcast_data, X1) and keeps them resident on ITS GPU,
+  * fits the neurons [N*r/G, N*(r+1)/G) with the lock-step batched BFGS on its own GPU -- no
+    communication at all during the fits (the per-neuron problems are independent),
+  * all-gathers the fitted parameter rows at the end of the sweep (X3) and the per-neuron
+    log posterior terms for the convergence test (X2); the network prior is evaluated on
+    every rank from the replicated state (the reference does it on the master only, X5).
+
+Every rank returns the same state dict.
+"""
+import numpy as np
+
+from theano_pyglm_amd import parallel as PL
+from theano_pyglm_amd.inference import coord_descent as cd
+from theano_pyglm_amd.inference.smart_init import initialize_with_data
+from theano_pyglm_amd.utils.packvec import packdict, unpackdict, get_vars, set_vars
+
+
+def _device_of(population):
+    world, _ = PL.world_rank()
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    return None if dist.get_backend() == 'gloo' else 'cuda:%d' % population.device
+
+
+def parallel_compute_log_p(population, x):
+    """parallel_coord_descent.py:16-55: log p = latent + network prior + sum_n (glm prior_n + ll_n), the
+    per-neuron terms computed by the rank that owns the neuron and all-gathered (N doubles)."""
+    N = population.N
+    world, rank = PL.world_rank()
+    lo, hi = PL.shard_bounds(N, rank, world)
+    lp_n = np.zeros(hi - lo)
+    for i, n in enumerate(range(lo, hi)):
+        population._check_vars(x, n)
+        lp_n[i] = population.glm.log_prior(x['glms'][n])
+    if hi > lo:
+        for data in population.data_sequences:
+            population.set_data(data)
+            lp_n += population.compute_ll_vector(x, lo, hi)
+    lp_all = PL.allgather_rows(lp_n, N, _device_of(population))
+    lp = population.latent.log_p(x.get('latent', {})) + population.network.log_p(x['net'])
+    return float(lp + np.sum(lp_all)), lp_all
+
+
+def gather_glms(population, x, lo, hi):
+    """X3: every rank ends up with the parameters of all N neurons; rank r contributes [lo, hi)."""
+    N = population.N
+    syms = population.glm_syms()
+    shapes, rows = None, []
+    v0, shapes = packdict(get_vars(syms, x['glms'][0]))
+    for n in range(lo, hi):
+        rows.append(packdict(get_vars(syms, x['glms'][n]))[0])
+    rows = np.array(rows).reshape(hi - lo, v0.size)
+    full = PL.gather_glm_params(rows, N, _device_of(population))
+    for n in range(N):
+        if not (lo <= n < hi):
+            set_vars(syms, x['glms'][n], unpackdict(full[n].copy(), shapes))
+    return x
+
+
+def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched='torch', verbose=False):
+    """parallel_coord_descent.py:57-156.  Call on every rank of an initialised process group with the
+    same x0 (e.g. drawn from the same seed); without a process group this is coord_descent."""
+    N = population.N
+    world, rank = PL.world_rank()
+    if world == 1:
+        return cd.coord_descent(population, x0=x0, maxiter=maxiter, atol=atol, batched=batched, verbose=verbose)
+    lo, hi = PL.shard_bounds(N, rank, world)
+    if x0 is None:
+        raise ValueError("parallel_coord_descent needs the same x0 on every rank")
+    initialize_with_data(population, population.data_sequences[-1], x0)
+    x = x0
+    lp_prev, _ = parallel_compute_log_p(population, x)
+    if verbose and rank == 0:
+        print("Initial LP=%.2f." % lp_prev)
+    glm_inf_prms = cd.prep_first_order_glm_inference(population) if not batched else None
+    net_inf_prms = cd.prep_first_order_network_inference(population)
+    converged, it = False, 0
+    while not converged and it < maxiter:
+        it += 1
+        if hi > lo:
+            if batched == 'torch':
+                from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+                fit_glms_batched_torch(population, x, n_lo=lo, n_hi=hi)
+            elif batched:
+                cd.fit_glms_batched(population, x, n_lo=lo, n_hi=hi)
+            else:
+                for n in range(lo, hi):
+                    nvars = population.extract_vars(x, n)
+                    cd.fit_glm(nvars, n, glm_inf_prms)
+                    x['glms'][n] = nvars['glm']
+        gather_glms(population, x, lo, hi)
+        cd.fit_network(x, net_inf_prms)          # replicated (no-op for constant weights / complete graphs)
+        lp, _ = parallel_compute_log_p(population, x)
+        if verbose and rank == 0:
+            print("Iteration %d: LP=%.2f. Change in LP: %.2f" % (it, lp, lp - lp_prev))
+        converged = np.abs(lp - lp_prev) < atol
+        lp_prev = lp
+    return x

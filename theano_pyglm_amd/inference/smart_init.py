@@ -64,6 +64,6 @@ def initialize_stim_with_sta(population, data, x0, Ns=None):
         Ns = np.arange(population.N)
     if isinstance(Ns, (int, np.integer)):
         Ns = [int(Ns)]
-    s = sta(data['stim'], data, L, Ns=Ns)
+    s = sta(data['stim'], data, L, Ns=Ns, handle=population._find_handle(data))
     for i, n in enumerate(Ns):
         x0['glms'][n]['bkgd'].update(stim_weights_from_sta(bkgd, s[i]))

@@ -35,7 +35,8 @@ class Population(object):
         self.network = Network(model, self.latent)
         self.glm = Glm(model, self.network, self.latent)
         self.device = int(os.environ.get('PYGLM_DEVICE', '0')) if device is None else int(device)
-        self._handles = {}        # id(data dict) -> _lib.DeviceGlm
+        self._handles = []        # (data dict, _lib.DeviceGlm) pairs: the pair keeps the dict alive, so a
+                                  # recycled id() can never alias a stale handle; lookup is by identity
         self._current = None      # data dict conditioned on (set_data)
 
     # -- variables ------------------------------------------------------------
@@ -90,8 +91,14 @@ class Population(object):
         if set_as_current_data:
             self.set_data(data)
 
+    def _find_handle(self, data):
+        for d, h in self._handles:
+            if d is data:
+                return h
+        return None
+
     def _handle(self, data):
-        h = self._handles.get(id(data))
+        h = self._find_handle(data)
         if h is None:
             S = np.asarray(data['S'])
             nT, N = S.shape
@@ -106,8 +113,7 @@ class Population(object):
                     h.set_stim_features(data['fstim'])      # caller-supplied dense features
                 else:
                     self.glm.bkgd_model.upload(h, data)     # built on the device from data['stim']
-            self._handles[id(data)] = h
-            data['_device_handle'] = h        # keeps the handle alive as long as the data dict
+            self._handles.append((data, h))
         return h
 
     def set_data(self, data):
@@ -126,11 +132,15 @@ class Population(object):
             return None
         return self._handle(data).get_stim_features()
 
-    def release_data(self):
-        """Free the device buffers of every data sequence."""
-        for h in self._handles.values():
-            h.close()
-        self._handles = {}
+    def release_data(self, data=None):
+        """Free the device buffers of one data sequence (or of all of them)."""
+        keep = []
+        for d, h in self._handles:
+            if data is None or d is data:
+                h.close()
+            else:
+                keep.append((d, h))
+        self._handles = keep
 
     # -- parameters -> device layout ----------------------------------------------
     def theta_matrix(self, vars, n_lo=0, n_hi=None):

@@ -19,11 +19,41 @@ def _log_time_cosines(n_pts, n_eye, n_cos, a, b):
     return 0.5 * (np.cos(phase) + 1.0)
 
 
+def orth_table_key(prms):
+    """Key of an orthonormalised basis in the packaged tables (utils/basis_tables.npz)."""
+    return '%s_eye%d_n%d_a%.9g_b%.9g' % (prms['type'].lower(), prms.get('n_eye', 0),
+                                        prms.get('n_cos', prms.get('n_exp', 0)),
+                                        prms.get('a', 0.0), prms.get('b', 0.0))
+
+
+_TABLES = None
+
+
+def _orth(basis, prms):
+    """basis.py:97-98 orthonormalises with scipy.linalg.orth -- an SVD whose column signs depend on
+    the LAPACK build.  The bases of the model templates therefore ship as
+    package data produced by the reference's own create_basis (tools/make_basis_tables.py) and are
+    looked up, never recomputed.  Other parameters get a deterministic numpy SVD basis of the same
+    column space (largest-magnitude entry of every column made positive)."""
+    global _TABLES
+    if _TABLES is None:
+        import os
+        f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'basis_tables.npz')
+        _TABLES = dict(np.load(f)) if os.path.exists(f) else {}
+    tab = _TABLES.get(orth_table_key(prms))
+    if tab is not None and tab.shape[0] == basis.shape[0]:
+        return tab.copy()
+    u, sv, _ = np.linalg.svd(basis, full_matrices=False)
+    rank = int(np.sum(sv > sv.max() * max(basis.shape) * np.finfo(float).eps))
+    u = u[:, :rank]
+    sign = np.sign(u[np.argmax(np.abs(u), axis=0), np.arange(rank)])
+    return u * np.where(sign == 0, 1.0, sign)[None, :]
+
+
 def _finish(basis, prms, n_norm):
     """Optional orthonormalisation (basis.py:97-98) and unit-area normalisation (99-104)."""
     if prms.get('orth', False):
-        import scipy.linalg
-        basis = scipy.linalg.orth(basis)
+        basis = _orth(basis, prms)
     if prms.get('norm', False):
         if np.any(basis < 0):
             raise Exception("We can only normalize nonnegative impulse responses!")

@@ -9,8 +9,9 @@ def sta(stim, data, L, Ns=None, handle=None):
     """A[i,l,:] = sum_t S[t,Ns[i]] * istim[t-l,:] / sum_t S[t,Ns[i]]  (sta.py:43-80).
 
     stim : (Tstim, D) stimulus at sampling interval data['dt_stim']
-    data : dict with 'S' (nT,N), 'dt', 'dt_stim' (a data set already added to a Population reuses
-           its resident handle; otherwise the spikes are uploaded for this call)
+    data : dict with 'S' (nT,N), 'dt', 'dt_stim'; `handle`: the resident DeviceGlm of a data set
+           already added to a Population (Population._handle(data)); without it the spikes are
+           uploaded for this call
     L    : number of lags in bins of data['dt'];  Ns: neuron indices (default all, int allowed)
     """
     stim = np.asarray(stim, dtype=float)
@@ -22,7 +23,7 @@ def sta(stim, data, L, Ns=None, handle=None):
         Ns = np.arange(N)
     if isinstance(Ns, (int, np.integer)):
         Ns = [int(Ns)]
-    h = handle if handle is not None else data.get('_device_handle', None)
+    h = handle
     own = h is None
     if own:
         h = _lib.DeviceGlm(N, nT, 1, 1, 'exp', float(data['dt']))

@@ -1,0 +1,43 @@
+"""Where a batched collapsed-Gibbs sweep at the C4 shape spends its time (dev tool)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from theano_pyglm_amd.inference import gibbs as G
+from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity
+from theano_pyglm_amd.population import Population
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+nT = int(sys.argv[2]) if len(sys.argv) > 2 else 600000
+model = make_model('sparse_weighted_model', N=N, dt=0.001)
+stabilize_sparsity(model)
+popn = Population(model)
+rng = np.random.default_rng(1238)
+S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1})
+x = popn.sample(np.random.RandomState(4))
+x['net']['weights']['W'] = 0.2 * np.asarray(x['net']['weights']['W'])
+upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(2))
+upd.preprocess(popn)
+h = popn._handle(popn._current)
+A = np.asarray(x['net']['graph']['A']).reshape(N, N); W = np.asarray(x['net']['weights']['W']).reshape(N, N)
+t0 = time.time(); th = popn.theta_matrix(x); t_theta = time.time() - t0
+t0 = time.time(); h.gibbs_prepare_all(th, A * W); h.sync(); t_prep = time.time() - t0
+t0 = time.time(); h.gibbs_prepare_all(th, A * W); h.sync(); t_prep2 = time.time() - t0
+cols = np.arange(N); pre = (cols * 37 + 11) % N
+ws = np.tile(np.linspace(-4, 4, 11), (N, 1)); aw = (A * W)[pre, cols]
+h.gibbs_ll_cols(cols, pre, aw, ws)
+t0 = time.time()
+for _ in range(20): h.gibbs_ll_cols(cols, pre, aw, ws)
+t_ll = (time.time() - t0) / 20
+t0 = time.time()
+for _ in range(50): h.gibbs_ll_cols(cols[:1], pre[:1], aw[:1], ws[:1, :1])
+t_one = (time.time() - t0) / 50
+t0 = time.time()
+for _ in range(20): h.gibbs_update_cols(cols[:3], pre[:3], np.array([0.1, -0.1, 0.2]))
+h.sync(); t_upd = (time.time() - t0) / 20
+print("theta_matrix %.1f ms | prepare_all first %.1f ms, again %.1f ms | ll_cols(%d cols x 11) %.3f ms | "
+      "ll_cols(1 col x 1) %.3f ms | update_cols(3) %.3f ms" % (t_theta * 1e3, t_prep * 1e3, t_prep2 * 1e3, N, t_ll * 1e3, t_one * 1e3, t_upd * 1e3))
+for rep in range(2):
+    upd.n_ars_evals = 0
+    t0 = time.time(); upd.update_all(x); t_sw = time.time() - t0
+    print("sweep %d: %.3f s, ARS evals %d, edges %d" % (rep, t_sw, upd.n_ars_evals, int(np.asarray(x['net']['graph']['A']).sum())))

@@ -19,7 +19,8 @@ theta = np.zeros((N, P)); theta[:, 0] = 20.0 + 0.1 * rng.standard_normal(N)
 theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
 dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt)
 dev.set_spikes(S); dev.set_basis(ib)
-dev.set_stream(torch.cuda.current_stream().cuda_stream)
+_st = torch.cuda.Stream(); torch.cuda.set_stream(_st)      # handle 0 (default stream) cannot be named
+dev.set_stream(_st.cuda_stream)
 d_theta = torch.from_numpy(theta).cuda(); d_W = torch.ones((N, N), dtype=torch.float64, device='cuda')
 d_out = torch.zeros(N * (1 + P), dtype=torch.float64, device='cuda')
 d_ll = d_out[:N]; d_g = d_out[N:].view(N, P)
