@@ -94,6 +94,17 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
                      int layout);
 int pgl_get_stim_features(pgl_handle h, double* fstim_out);
 
+/* SpatiotemporalStimulus with a WIDE stimulus (bkgd.py:172-345): the rank-1 structure
+ * w_stim = vec(w_t (x) w_x) (bkgd.py:214-220) is kept on the device instead of materialising the
+ * (nT, Bt*Bx) feature matrix of pgl_set_stimulus (7.4 GB at D = 1024, T = 300 s):
+ *   I_stim[:,n] = causal conv( np.interp( (stim . basis_x) . w_x[n] ), basis_t . w_t[n] )
+ * -- one GEMM at the stimulus frame rate plus a 1-D convolution per neuron; gradients by the transposed
+ * operations.  After this call a theta row is [bias, w_t(Bt), w_x(Bx), w_imp(N*B)] (the reference's own
+ * packing order of 'bkgd': 'w_t' < 'w_x', packvec.py:22) with P = 1 + Bt + Bx + N*B, and gradients come
+ * back in that layout (no host chain rule).  basis_x (D,Bx) row-major or NULL = identity. */
+int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
+                               const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt);
+
 /* Restrict pgl_ll_grad to the bins [t_lo, t_hi) (t_lo a multiple of 16): ll and gradient
  * become the partial sums over that range, while features still see the spikes before t_lo.
  * The likelihood is a sum over data segments (population.py:41-43), so a time range per GPU

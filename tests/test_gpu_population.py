@@ -41,7 +41,7 @@ def oracle_log_p(popn, data, x):
         xn = x['glms'][n]
         lp += glm.log_prior(xn)
         w = glm.imp_model.flat_weights(xn['imp']).reshape(N, -1)
-        ws = glm.bkgd_model.flat_weights(xn['bkgd']) if fstim is not None else None
+        ws = glm.bkgd_model.dense_weights(xn['bkgd']) if fstim is not None else None
         lls.append(O.glm_ll(n, S, fS, w, Weff[:, n], glm.bias_model.I_bias(xn['bias']), glm.dt,
                             glm.nlin_model.kind, fstim, ws))
     return lp + np.sum(lls), np.array(lls)
@@ -273,7 +273,7 @@ def test_wide_spatiotemporal_stimulus_sliced():
             xn['bias']['bias'] = np.array([2.0])
 
     model, popn, data = make_dataset(tmpl, 4, 1.5, seed=41, check=True, adjust=tame)
-    assert popn.glm.Dstim == 768
+    assert popn.glm.bkgd_model.separable and popn.glm.Dstim == 3 + 256     # rank-1 path: theta carries [w_t, w_x]
     x = popn.sample(np.random.RandomState(42))
     tame(x)
     lp = popn.compute_log_p(x)
@@ -386,3 +386,59 @@ def test_map_with_cross_validation(std4):
     assert len(popn2._handles) == 1                               # the train / held-out handles were released
     popn2.release_data()
     assert popn2._handles == []
+
+
+def test_separable_stimulus_matches_dense_and_oracle():
+    """pgl_set_stimulus_separable (rank-1 stimulus kept as w_t, w_x on the device: frame-rate GEMM + 1-D
+    convolutions, bkgd.py:214-227) against the dense feature path (pgl_set_stimulus) and the oracle:
+    identity and non-identity spatial bases, interpolation from a coarse grid with a clamped tail,
+    a neuron sub-range and a time range."""
+    from tests import helpers as H
+    from theano_pyglm_amd import _lib
+    rng = np.random.RandomState(77)
+    N, nT, D, Bt, Rt = 6, 3000, 40, 3, 300
+    ibt = H.golden()['lr2d_ibasis_t']
+    assert ibt.shape == (Rt, Bt)
+    for Bx, dt_stim, Tstim in ((D, 0.1, 25), (5, 0.013, 231)):       # second: frames end before the recording does
+        stim = rng.randn(Tstim, D)
+        ibx = None if Bx == D else rng.randn(D, Bx)
+        p = H.Problem(N, nT, H.st_ibasis(), kind='exp', seed=5, w_scale=0.02)
+        w_t, w_x = 0.3 * rng.randn(N, Bt), 0.3 * rng.randn(N, Bx)
+        dense = p.device()
+        dense.set_stimulus(stim, dt_stim, ibt, ibx, layout=0)
+        th_d = np.concatenate((p.theta[:, :1], np.einsum('nt,nx->ntx', w_t, w_x).reshape(N, -1), p.theta[:, 1:]), axis=1)
+        ll_d, g_d = dense.ll_grad(th_d, p.Weff)
+        sep = p.device()
+        sep.set_stimulus_separable(stim, dt_stim, ibt, ibx)
+        assert sep.P == 1 + Bt + Bx + N * 3
+        th_s = np.concatenate((p.theta[:, :1], w_t, w_x, p.theta[:, 1:]), axis=1)
+        ll_s, g_s = sep.ll_grad(th_s, p.Weff)
+        assert np.allclose(ll_s, ll_d, rtol=1e-11)
+        G = g_d[:, 1:1 + Bt * Bx].reshape(N, Bt, Bx)
+        g_chain = np.concatenate((g_d[:, :1], np.einsum('ntx,nx->nt', G, w_x), np.einsum('ntx,nt->nx', G, w_t),
+                                  g_d[:, 1 + Bt * Bx:]), axis=1)
+        assert H.rel_err(g_s, g_chain) < 1e-10
+        ll_only, _ = sep.ll_grad(th_s, p.Weff, want_grad=False)
+        assert np.allclose(ll_only, ll_s, rtol=1e-13)
+        # oracle on the dense features
+        fst = O.spatiotemporal_stim_features(stim, dt_stim, 0.001, nT, np.eye(D) if ibx is None else ibx, ibt)
+        p.fstim, p.Dstim, p.P, p.theta = fst, Bt * Bx, th_d.shape[1], th_d
+        ll0, g0 = p.oracle_ll_grad()
+        assert np.allclose(ll_s, ll0, rtol=1e-10)
+        # neuron sub-range and time range (partial sums add up)
+        a, b = sep.ll_grad(th_s[2:5], p.Weff, 2, 5)
+        assert np.allclose(a, ll_s[2:5], rtol=1e-12) and H.rel_err(b, g_s[2:5]) < 1e-11
+        acc_l, acc_g = 0.0, 0.0
+        for lo, hi in ((0, 1008), (1008, 3000)):
+            sep.set_time_range(lo, hi)
+            a, b = sep.ll_grad(th_s, p.Weff)
+            acc_l, acc_g = acc_l + a, acc_g + b
+        assert np.allclose(acc_l, ll_s, rtol=1e-11) and H.rel_err(acc_g, g_s) < 1e-10
+        # state read-back (I_stim by the separable path)
+        sep.set_time_range(0, nT)
+        lam, inet, istim = sep.state(1, th_s[1], p.Weff[:, 1])
+        assert np.max(np.abs(istim - fst.dot(th_d[1, 1:1 + Bt * Bx]))) < 1e-10
+        with pytest.raises(_lib.PglError):
+            sep.get_stim_features()
+        dense.close()
+        sep.close()

@@ -27,7 +27,7 @@ SYMBOLS = [
     'pgl_impulse_currents', 'pgl_state', 'pgl_ll_from_current', 'pgl_gibbs_prepare',
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
     'pgl_timing_summary', 'pgl_set_stream',
-    'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
+    'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
 ]
 
 
@@ -91,6 +91,8 @@ def load():
     lib.pgl_set_stimulus.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int,
                                      C.c_int, C.c_int]
     lib.pgl_get_stim_features.argtypes = [vp, vp]
+    lib.pgl_set_stimulus_separable.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int,
+                                               C.c_int]
     lib.pgl_timing_summary.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pgl_set_stream.argtypes = [vp, vp]
     lib.pgl_sta.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int, vp]
@@ -237,6 +239,20 @@ class DeviceGlm(object):
                                        _ptr(bx), int(Bx), _ptr(bt), bt.shape[0], bt.shape[1],
                                        int(layout)))
         self.Dstim = int(Bx * bt.shape[1])
+
+    def set_stimulus_separable(self, stim, dt_stim, basis_t, basis_x=None):
+        """Rank-1 (w_t (x) w_x) stimulus kept separable on the device; theta rows become
+        [bias, w_t, w_x, w_imp] (see pgl_set_stimulus_separable)."""
+        stim = _f64(stim)
+        if stim.ndim != 2:
+            raise ValueError("stim must be (Tstim, D)")
+        bt = _f64(basis_t)
+        bx = None if basis_x is None else _f64(basis_x, (stim.shape[1], np.shape(basis_x)[1]))
+        Bx = stim.shape[1] if bx is None else bx.shape[1]
+        _chk(self.lib.pgl_set_stimulus_separable(self.h, _ptr(stim), stim.shape[0], stim.shape[1],
+                                                 float(dt_stim), _ptr(bx), int(Bx), _ptr(bt), bt.shape[0],
+                                                 bt.shape[1]))
+        self.Dstim = int(Bx + bt.shape[1])
 
     def get_stim_features(self):
         out = np.empty((self.nT, self.Dstim))

@@ -33,6 +33,10 @@ class NoStimulus(Component):
     def flat_weights(self, vars):
         return np.zeros((0,))
 
+    def dense_weights(self, vars):
+        """Weights of the dense feature columns (host_features); equal to flat_weights here."""
+        return self.flat_weights(vars)
+
     def chain_grad(self, vars, g_flat):
         return {}
 
@@ -71,6 +75,10 @@ class BasisStimulus(Component):
 
     def flat_weights(self, vars):
         return np.asarray(vars['w_stim'], dtype=float).reshape(-1)
+
+    def dense_weights(self, vars):
+        """Weights of the dense feature columns (host_features); equal to flat_weights here."""
+        return self.flat_weights(vars)
 
     def chain_grad(self, vars, g_flat):
         return {'w_stim': np.array(g_flat, dtype=float)}
@@ -135,16 +143,33 @@ class SpatiotemporalStimulus(Component):
         self.ibasis_t, self.ibasis_x = ibt, ibx
         self.Bt, self.Bx = ibt.shape[1], ibx.shape[1]
         self.n_vars = self.Bx + self.Bt
-        self.n_features = self.Bt * self.Bx
+        # Device layout.  Narrow stimuli (the template's D_stim = 3): the Bt*Bx dense feature columns
+        # fstim ride in the fused kernel and the flat weights are vec(w_t (x) w_x).  Wide stimuli: the
+        # rank-1 structure stays separable on the device (pgl_set_stimulus_separable) and a theta row
+        # carries [w_t, w_x] themselves.
+        self.separable = bool(self.bkgd_model.get('separable', self.Bt * self.Bx > self.SEPARABLE_FROM))
+        self.n_features = (self.Bt + self.Bx) if self.separable else self.Bt * self.Bx
+
+    SEPARABLE_FROM = 64          # dense feature columns (Bt*Bx) from which the separable device path is used
 
     def get_variables(self):
         return {'w_x': (self.Bx,), 'w_t': (self.Bt,)}
 
-    def flat_weights(self, vars):
+    def dense_weights(self, vars):
+        """w_stim = vec(w_t (x) w_x), index bt*Bx+bx (bkgd.py:214-220): weights of host_features' columns."""
         return np.outer(np.asarray(vars['w_t'], float), np.asarray(vars['w_x'], float)).reshape(-1)
 
+    def flat_weights(self, vars):
+        """The stimulus block of a device theta row."""
+        if self.separable:
+            return np.concatenate((np.asarray(vars['w_t'], float), np.asarray(vars['w_x'], float)))
+        return self.dense_weights(vars)
+
     def chain_grad(self, vars, g_flat):
-        G = np.asarray(g_flat, dtype=float).reshape(self.Bt, self.Bx)
+        g_flat = np.asarray(g_flat, dtype=float)
+        if self.separable:                    # the device already returns d/dw_t, d/dw_x
+            return {'w_t': g_flat[:self.Bt].copy(), 'w_x': g_flat[self.Bt:].copy()}
+        G = g_flat.reshape(self.Bt, self.Bx)
         return {'w_t': G.dot(np.asarray(vars['w_x'], float)),
                 'w_x': G.T.dot(np.asarray(vars['w_t'], float))}
 
@@ -178,8 +203,13 @@ class SpatiotemporalStimulus(Component):
                             % (data['stim'].shape[1], self.bkgd_model['D_stim']))
 
     def upload(self, handle, data):
-        handle.set_stimulus(np.asarray(data['stim'], dtype=float), data['dt_stim'], self.ibasis_t,
-                            self.ibasis_x, layout=0)
+        stim = np.asarray(data['stim'], dtype=float)
+        if self.separable:
+            ident = self.ibasis_x.shape[0] == self.ibasis_x.shape[1] and \
+                np.array_equal(self.ibasis_x, np.eye(self.ibasis_x.shape[0]))
+            handle.set_stimulus_separable(stim, data['dt_stim'], self.ibasis_t, None if ident else self.ibasis_x)
+        else:
+            handle.set_stimulus(stim, data['dt_stim'], self.ibasis_t, self.ibasis_x, layout=0)
 
     def host_features(self, data, nT):
         """numpy twin of the device build (used by the host-side simulator only)."""

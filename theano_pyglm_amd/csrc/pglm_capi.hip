@@ -55,6 +55,12 @@ struct pgl_context {
     int fimg_kth = 0;                    // widths (ktl << 8 | kth, k-tiles) the images were built for; 0 = stale
     int fimg_tile0 = 0, fimg_ntiles = 0; // 16-bin tiles the images cover (the evaluated time range)
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
+    // separable (rank-1) stimulus: theta rows are [bias, w_t(Bt), w_x(Bx), w_imp]; Dstim = Bt + Bx
+    bool sep = false;
+    int sepBt = 0, sepBx = 0, sepRt = 0;
+    int64_t sepT = 0;
+    double sep_dt_stim = 0;
+    DevBuf zf, zfT, sbt, Yf, Qb, Qf, spart;
     const int* cur_pidx = nullptr;       // post-neuron list of the evaluation being enqueued (device)
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -113,7 +119,7 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 {
     std::vector<Slice> out;
     const int maxNs = std::min(128, 640 / h->B);
-    int ds_left = h->Dstim, ds0 = 0;
+    int ds_left = h->sep ? 0 : h->Dstim, ds0 = 0;      // a separable stimulus is not a set of feature columns
     for (int np0 = 0; np0 < h->N; np0 += maxNs) {
         Slice sl{np0, std::min(maxNs, h->N - np0), 0, 0};
         if (np0 + sl.Ns >= h->N && ds_left > 0 && sl.Ns * h->B + ds_left <= 640) {
@@ -162,7 +168,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.version = pl.f32 ? 3 : 2;
     if (pl.version == 2 && single_slice && need >= 2) {
         if (h->opt_kernel == 3) pl.version = 4;
-        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && pl.nPT >= 5)) pl.version = 5;
+        // two-pass kernel on resident tiles from 5 post tiles on; from 4 when the feature row is too long for
+        // the resident K-split kernel (measured at K = 640: 64 neurons 2.05 ms against 2.33 ms of k_fused2)
+        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT == 4 && need > 20))))
+            pl.version = 5;
     }
     pl.tile0 = (int)(h->t_lo / 16);
     pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
@@ -514,7 +523,8 @@ int pgl_destroy(pgl_handle h)
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
                       &h->gbpart, &h->Xbuf, &h->fimg, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
-                      &h->gargs, &h->gpart, &h->gout};
+                      &h->gargs, &h->gpart, &h->gout, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
+                      &h->spart};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
@@ -686,6 +696,7 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     HIPCHK(hipSetDevice(h->device));
     h->Dstim = Dstim;
     h->Ktot = h->Kimp + Dstim;
+    h->sep = false;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
     h->gx_xs = 0;
@@ -740,10 +751,111 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
     if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_set_stimulus: ") + hipGetErrorString(e));
     h->Dstim = Dstim;
     h->Ktot = h->Kimp + Dstim;
+    h->sep = false;
     h->gibbs_npost = -1;
     h->fimg_kth = 0;
     h->gx_xs = 0;
     return PGL_OK;
+}
+
+static int launch_gemm_nt(pgl_handle h, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                          int M, int N, int K)
+{
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, h->stream, A, lda, B, ldb, C, ldc, M, N, K);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
+                               const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt)
+{
+    if (!h || !stim || !basis_t) return fail(PGL_ERR_ARG, "null argument");
+    if (Tstim <= 0 || D <= 0 || Bx <= 0 || Rt <= 0 || Bt <= 0 || !(dt_stim > 0))
+        return fail(PGL_ERR_ARG, "bad stimulus description");
+    if (!basis_x && Bx != D) return fail(PGL_ERR_ARG, "identity spatial basis needs Bx == D");
+    if ((size_t)(2 * Rt + 2 * PGL_SEP_TB) * 8 > 64 * 1024) return fail(PGL_ERR_UNSUPPORTED, "temporal basis too long");
+    HIPCHK(hipSetDevice(h->device));
+    ENSURE(h->zf, (size_t)Tstim * Bx * 8);
+    ENSURE(h->zfT, (size_t)Tstim * Bx * 8);
+    ENSURE(h->sbt, (size_t)Rt * Bt * 8);
+    HIPCHK(hipMemcpyAsync(h->sbt.p, basis_t, (size_t)Rt * Bt * 8, hipMemcpyHostToDevice, h->stream));
+    // z = stim . basis_x at the stimulus frame rate (Tstim, Bx) and its transpose, both by the NT GEMM
+    std::vector<double> bxT((size_t)Bx * D, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int b = 0; b < Bx; ++b) bxT[(size_t)b * D + d] = basis_x ? basis_x[(size_t)d * Bx + b] : (d == b ? 1.0 : 0.0);
+    DevBuf dstim, dbxT;
+    int rc = ensure(dstim, (size_t)Tstim * D * 8);
+    if (!rc) rc = ensure(dbxT, (size_t)Bx * D * 8);
+    if (rc) { release(dstim); release(dbxT); return rc; }
+    hipError_t e = hipMemcpyAsync(dstim.p, stim, (size_t)Tstim * D * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbxT.p, bxT.data(), (size_t)Bx * D * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        rc = launch_gemm_nt(h, (const double*)dstim.p, D, (const double*)dbxT.p, D, (double*)h->zf.p, Bx,
+                            (int)Tstim, Bx, D);
+        if (!rc) rc = launch_gemm_nt(h, (const double*)dbxT.p, D, (const double*)dstim.p, D, (double*)h->zfT.p,
+                                     (int)Tstim, Bx, (int)Tstim, D);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    release(dstim);
+    release(dbxT);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_set_stimulus_separable: ") + hipGetErrorString(e));
+    h->sep = true;
+    h->sepBt = Bt; h->sepBx = Bx; h->sepRt = Rt; h->sepT = Tstim; h->sep_dt_stim = dt_stim;
+    h->Dstim = Bt + Bx;                       // layout of a theta row; NOT feature columns of the fused kernels
+    h->Ktot = h->Kimp;
+    h->gibbs_npost = -1;
+    h->fimg_kth = 0;
+    h->gx_xs = 0;
+    return PGL_OK;
+}
+
+// separable stimulus, forward: X[t][j] += I_stim[t, n_lo + j] for the rows of d_theta (npost rows of P)
+static int sep_forward(pgl_handle h, const double* d_theta, int npost, double* X, int xs, int64_t t_lo, int64_t t_hi,
+                       SepParams& sp)
+{
+    const int P = 1 + h->Dstim + h->Kimp;
+    ENSURE(h->Yf, (size_t)npost * h->sepT * 8);
+    int rc = launch_gemm_nt(h, d_theta + 1 + h->sepBt, P, (const double*)h->zf.p, h->sepBx, (double*)h->Yf.p,
+                            (int)h->sepT, npost, (int)h->sepT, h->sepBx);
+    if (rc) return rc;
+    sp.Yf = (const double*)h->Yf.p; sp.basis_t = (const double*)h->sbt.p; sp.theta = d_theta;
+    sp.P = P; sp.Bt = h->sepBt; sp.Rt = h->sepRt; sp.npost = npost; sp.xs = xs;
+    sp.Tstim = h->sepT; sp.nT = h->nT; sp.t_lo = t_lo; sp.t_hi = t_hi; sp.dt = h->dt; sp.dt_stim = h->sep_dt_stim;
+    sp.X = X;
+    const int nblk = (int)((t_hi - t_lo + PGL_SEP_TB - 1) / PGL_SEP_TB);
+    hipLaunchKernelGGL(k_sep_conv_fwd, dim3(nblk, npost), dim3(256), (size_t)(2 * h->sepRt + PGL_SEP_TB) * 8,
+                       h->stream, sp);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+// separable stimulus, backward: X holds r = d ll / d x on [t_lo, t_hi) (zero behind t_hi); writes the w_t and
+// w_x columns of d_grad
+static int sep_backward(pgl_handle h, const SepParams& sp, double* d_grad)
+{
+    const int npost = sp.npost, Rt = h->sepRt;
+    const int nblk = (int)((sp.t_hi - sp.t_lo + PGL_SEP_TB - 1) / PGL_SEP_TB);
+    ENSURE(h->spart, (size_t)nblk * npost * Rt * 8);
+    hipLaunchKernelGGL(k_sep_corr, dim3(nblk, npost), dim3(256), (size_t)(Rt + 2 * PGL_SEP_TB) * 8, h->stream, sp,
+                       (double*)h->spart.p);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sep_wt_grad, dim3(npost), dim3(64), 0, h->stream, sp, (const double*)h->spart.p, nblk,
+                       d_grad);
+    HIPCHK(hipGetLastError());
+    const long long s_lo = std::max<long long>(0, sp.t_lo - Rt), nS = sp.t_hi - s_lo;
+    ENSURE(h->Qb, (size_t)npost * nS * 8);
+    ENSURE(h->Qf, (size_t)npost * h->sepT * 8);
+    const int nblk_s = (int)((nS + PGL_SEP_TB - 1) / PGL_SEP_TB);
+    hipLaunchKernelGGL(k_sep_conv_bwd, dim3(nblk_s, npost), dim3(256), (size_t)(2 * Rt + PGL_SEP_TB) * 8, h->stream,
+                       sp, (double*)h->Qb.p, s_lo, nS);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sep_interp_T, dim3((unsigned)((h->sepT + 255) / 256), npost), dim3(256), 0, h->stream, sp,
+                       (const double*)h->Qb.p, s_lo, nS, (double*)h->Qf.p);
+    HIPCHK(hipGetLastError());
+    return launch_gemm_nt(h, (const double*)h->Qf.p, (int)h->sepT, (const double*)h->zfT.p, (int)h->sepT,
+                          d_grad + 1 + h->sepBt, sp.P, npost, h->sepBx, (int)h->sepT);
 }
 
 int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
@@ -808,6 +920,7 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
 
 int pgl_get_stim_features(pgl_handle h, double* fstim_out)
 {
+    if (h && h->sep) return fail(PGL_ERR_STATE, "a separable stimulus has no dense feature matrix");
     if (!h || !fstim_out) return fail(PGL_ERR_ARG, "null argument");
     if (h->Dstim <= 0) return fail(PGL_ERR_STATE, "no stimulus features on the device");
     HIPCHK(hipSetDevice(h->device));
@@ -920,10 +1033,10 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     const std::vector<Slice> slices = make_slices(h);
     std::vector<Plan> plans(slices.size());
     for (size_t i = 0; i < slices.size(); ++i) {
-        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1);
+        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1 && !h->sep);
         if (rc) return rc;
     }
-    const bool sliced = slices.size() > 1;
+    const bool sliced = slices.size() > 1 || h->sep;     // the separable stimulus rides on the 3-phase path
     size_t maxG = 0, maxLL = 0;
     for (const Plan& pl : plans) {
         maxG = std::max(maxG, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
@@ -1000,6 +1113,12 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         ENSURE(h->Xbuf, (size_t)h->nT * xs * 8);
         HIPCHK(hipMemsetAsync((double*)h->Xbuf.p + row0 * xs, 0, (size_t)(row1 - row0) * xs * 8, h->stream));
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        SepParams sp;
+        if (h->sep) {                                          // phase 0: X = I_stim (separable stimulus)
+            if (h->cur_pidx) return fail(PGL_ERR_UNSUPPORTED, "neuron lists with a separable stimulus");
+            int rc = sep_forward(h, d_theta, p0.npost, (double*)h->Xbuf.p, xs, h->t_lo, h->t_hi, sp);
+            if (rc) return rc;
+        }
         for (size_t i = 0; i < slices.size(); ++i) {          // phase 1: X += F_s . W_s
             int rc = launch_prep(h, plans[i], slices[i], n_lo, d_theta, d_Weff);
             if (rc) return rc;
@@ -1039,6 +1158,10 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
                 hipError_t e = launch_any(plans[i], fp, h->stream);
                 if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("backward launch: ") + hipGetErrorString(e));
                 rc = launch_finalize_grad(h, plans[i], slices[i], n_lo, d_Weff, d_ll, d_grad);
+                if (rc) return rc;
+            }
+            if (h->sep) {
+                int rc = sep_backward(h, sp, d_grad);
                 if (rc) return rc;
             }
         }
@@ -1253,8 +1376,13 @@ int pgl_gibbs_prepare(pgl_handle h, int n_post, const double* theta_n, const dou
     if (rc) return rc;
     hipLaunchKernelGGL(k_inet, dim3(1024), dim3(256), 0, h->stream, (const double*)h->IimpT.p,
                        (const double*)h->wcol.p, (const double*)h->fstim.p, d_th + 1,
-                       (double*)h->Inet.p, (double*)h->Istim.p, (long long)h->nT, h->N, h->Dstim);
+                       (double*)h->Inet.p, (double*)h->Istim.p, (long long)h->nT, h->N, h->sep ? 0 : h->Dstim);
     HIPCHK(hipGetLastError());
+    if (h->sep) {                                 // I_stim of this neuron by the separable path
+        SepParams sp;
+        rc = sep_forward(h, d_th, 1, (double*)h->Istim.p, 1, 0, h->nT, sp);
+        if (rc) return rc;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->gibbs_npost = n_post;
     h->gibbs_bias = theta_n[0];
@@ -1359,6 +1487,11 @@ int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff)
     const long long row0 = (long long)plans[0].tile0 * 16;
     const long long row1 = std::min<long long>(h->nT, (long long)(plans[0].tile0 + plans[0].nTiles) * 16);
     HIPCHK(hipMemsetAsync((double*)h->GX.p + row0 * xs, 0, (size_t)(row1 - row0) * xs * 8, h->stream));
+    if (h->sep) {
+        SepParams sp;
+        rc = sep_forward(h, (const double*)h->gtheta.p, N, (double*)h->GX.p, xs, h->t_lo, h->t_hi, sp);
+        if (rc) return rc;
+    }
     for (size_t i = 0; i < slices.size(); ++i) {
         rc = launch_prep(h, plans[i], slices[i], 0, (const double*)h->gtheta.p, (const double*)h->Weff.p);
         if (rc) return rc;
@@ -1411,9 +1544,7 @@ static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     gp.w = (const double*)(d + o_w);
     gp.ncols = ncols; gp.K = nw; gp.nlin = h->nlin; gp.dt = h->dt;
     gp.t_lo = h->t_lo; gp.t_hi = h->t_hi;
-    int cp = 1;
-    while (cp < ncols && cp < 256) cp <<= 1;
-    gp.CP = cp;
+    gp.CP = std::max(1, std::min(ncols, 256 / std::max(1, nw)));   // columns per workgroup (ll) / per sweep (update)
     gp.part = nullptr;
     return PGL_OK;
 }
@@ -1428,19 +1559,23 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     GibbsColsParams gp;
     rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8);
     if (rc) return rc;
-    // rows per block: enough blocks to fill the chip, whole passes of 4*RPB rows
-    const int RPB = 256 / gp.CP, pass = 4 * RPB;
+    // enough blocks for a few per CU, at most 384 bins each (the block's presynaptic events -- window of
+    // rows + R bins, ~11 at 20 Hz -- are staged in LDS, PGL_GECAP per column), whole sub-blocks
     const int ygroups = (ncols + gp.CP - 1) / gp.CP;
     const long long nrows = h->t_hi - h->t_lo;
+    int gtb = 32;
+    while (gtb * gp.CP < 256) gtb += 32;                 // narrow launches: longer sub-blocks keep 256 threads busy
+    gp.gtb = gtb;
     long long rows = (nrows * ygroups + 4 * h->numCU - 1) / (4LL * h->numCU);
-    rows = std::max<long long>(pass, std::min<long long>(rows, 4096));
-    rows = (rows + pass - 1) / pass * pass;
+    rows = std::max<long long>(gtb, std::min<long long>(rows, 384));
+    rows = (rows + gtb - 1) / gtb * gtb;
     gp.rows = (int)rows;
     const int nblk = (int)((nrows + rows - 1) / rows);
     ENSURE(h->gpart, (size_t)nblk * ncols * PGL_KMAX * 8);
     ENSURE(h->gout, (size_t)ncols * K * 8);
     gp.part = (double*)h->gpart.p;
-    const size_t lds = ((size_t)h->B * h->Rk + (size_t)gp.CP * K + 4 * (64 * 4 + 64 * PGL_KMAX)) * 8;
+    const size_t lds = ((size_t)h->B * h->Rk + (size_t)3 * gtb * gp.CP) * 8 + (size_t)gp.CP * PGL_GECAP * 8 +
+                       (size_t)gp.CP * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gibbs_ll_cols),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));

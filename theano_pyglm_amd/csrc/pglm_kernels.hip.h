@@ -1918,6 +1918,20 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
                 pgl_dma_half<KT_ALL>(fimg + (size_t)(tile0s + m) * IMG, dst + (size_t)m * IMG, wave, lane);
     };
     if (tile_beg < tile_end) dma_step(tile_beg, bufs);
+    // this wave's slice of Wmat stays in registers for the whole chunk (KSW <= 40 fragments: the forward
+    // loop of a short slice would otherwise wait for its first L2 loads in every tile)
+    double wreg[KSW];
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) wreg[s] = 0.0;
+    if (active) {
+        const pgl_d2* wr2 = reinterpret_cast<const pgl_d2*>(wrow);
+#pragma unroll
+        for (int s2 = 0; s2 < KSW / 2; ++s2) {
+            const pgl_d2 v = wr2[s2 * 64 + lane];
+            wreg[2 * s2] = v.x;
+            wreg[2 * s2 + 1] = v.y;
+        }
+    }
 
     int par = 0;
     for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
@@ -1926,14 +1940,14 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
         __syncthreads();                                  // ... everybody's; the other buffer is free
         if (tile + MT < tile_end) dma_step(tile + MT, bufs + (size_t)(par ^ 1) * MT * IMG);
         // post-synaptic counts of the elements this wave owns in the epilogue
-        double sc[MT][EPW];
+        double sc[MT * EPW];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int e = 0; e < EPW; ++e) {
                 const long long tg = (long long)(tile + m) * TT + grp + 4 * er[e];
                 const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                sc[m][e] = (double)p.S[tc * p.Nall + nglob];
+                sc[m * EPW + e] = (double)p.S[tc * p.Nall + nglob];
             }
         }
         // ---- forward over this wave's K slice, tile by tile ----
@@ -1943,27 +1957,18 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
             if (active && tile + m < tile_end) {
                 const double* fa = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + col * RS + kcol0 + grp;
-                const double* wr_s = wrow;
-                asm volatile("" : "+s"(wr_s));
-                constexpr int PW2 = (KSW / 2 < PGL_PW / 2) ? KSW / 2 : PGL_PW / 2;
                 constexpr int PA = (KSW < 4) ? KSW : 4;
-                const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
-                pgl_d2 wr[PW2];
                 double ar[PA];
-#pragma unroll
-                for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
 #pragma unroll
                 for (int s = 0; s < PA; ++s) ar[s] = fa[4 * s];
 #pragma unroll
                 for (int s = 0; s < KSW; ++s) {
                     const double a = ar[s % PA];
-                    const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
                     if (s + PA < KSW) ar[s % PA] = fa[4 * (s + PA)];
-                    if ((s & 1) && (s / 2 + PW2 < KSW / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
                     if (s & 1)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
                     else
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1972,12 +1977,13 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
             for (int r = 0; r < 4; ++r) xw[r * 64] = acc0[r] + acc1[r];
         }
         __syncthreads();
-        // ---- epilogue: sum of the KSPLIT partials + bias -> ll terms, residuals ----
+        // ---- epilogue: sum of the KSPLIT partials + bias -> ll terms, residuals; the elements of all MT
+        // tiles go through the rate chains together (independent chains interleave) ----
         if (active) {
+            double xe[MT * EPW], rese[MT * EPW], terme[MT * EPW];
+            bool vte[MT * EPW];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                double xe[EPW], rese[EPW], terme[EPW];
-                bool vte[EPW];
 #pragma unroll
                 for (int e = 0; e < EPW; ++e) {
                     const int r = er[e];
@@ -1986,16 +1992,19 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
                     for (int k2 = 0; k2 < KSPLIT; ++k2)
                         x += Xp[((size_t)m * NW + ptl + PTW * k2) * 256 + r * 64 + lane];
                     const long long tg = (long long)(tile + m) * TT + grp + 4 * r;
-                    vte[e] = valid_n && (tg < p.t_hi) && emine && (tile + m < tile_end);
-                    xe[e] = x;
+                    vte[m * EPW + e] = valid_n && (tg < p.t_hi) && emine && (tile + m < tile_end);
+                    xe[m * EPW + e] = x;
                 }
-                pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
-                asm volatile("" : "+v"(Cl));
-                pgl_rate_terms_n<EPW>(xe, sc[m], p.nlin, p.dt, terme, rese, Cl);
+            }
+            pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+            asm volatile("" : "+v"(Cl));
+            pgl_rate_terms_n<MT * EPW>(xe, sc, p.nlin, p.dt, terme, rese, Cl);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
 #pragma unroll
                 for (int e = 0; e < EPW; ++e) {
-                    const double res = vte[e] ? rese[e] : 0.0;
-                    ll_acc += vte[e] ? terme[e] : 0.0;
+                    const double res = vte[m * EPW + e] ? rese[m * EPW + e] : 0.0;
+                    ll_acc += vte[m * EPW + e] ? terme[m * EPW + e] : 0.0;
                     gb_acc += res;
                     if (emine) Rb[((size_t)m * PTW + ptl) * 256 + er[e] * 64 + lane] = res;
                 }
@@ -2359,8 +2368,14 @@ __device__ __forceinline__ double pgl_lambda_only(const double x, const int nlin
     if (nlin != 1) return pgl_exp(x, C);
     const double e = pgl_exp(-fabs(x), C);
     double l1p;
-    if (__all(e < C[23])) {
+    if (__all(e < C[23])) {                        // |x| > 9.25: alternating series, error < e^6
         l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), C[22]), 0.5), 1.0);
+    } else if (__all(e < 0.1)) {                   // |x| > 2.3: log1p(e) = 2 atanh(s), s = e/(2+e) < 0.048
+        const double s = e * pgl_rcp(2.0 + e);
+        const double z = s * s;                    // z < 2.3e-3: z^7/15 < 2.3e-20
+        const double q = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.0 / 13.0, 1.0 / 11.0), 1.0 / 9.0), 1.0 / 7.0),
+                                           0.2), C[22]), 1.0);
+        l1p = 2.0 * s * q;
     } else {
         const double u = 1.0 + e;
         l1p = pgl_log(u, C) + (e - (u - 1.0)) * pgl_rcp(u);
@@ -2516,142 +2531,141 @@ struct GibbsColsParams {
     double dt;
     long long t_lo, t_hi;
     int rows;                            // bins per block
+    int gtb;                             // bins per sub-block (multiple of 32, gtb * CP >= 256)
     double* __restrict__ part;
 };
 
+#define PGL_GECAP 24          // staged presynaptic events per column and block (k_gibbs_ll_cols)
+
+// Thread = one (column, candidate weight) pair: one accumulator per thread, a short loop body (the code
+// of the first version -- 16 x 4 inlined softplus chains per pass -- did not fit the instruction cache
+// and ran at a tenth of the f64 rate).  Per sub-block of PGL_GTB bins the workgroup first builds the
+// pair currents of its CP columns in LDS (x0 = bias + I_stim + I_net - aw_cur*ic, ic, spike count; the
+// presynaptic events of the block's window are staged in LDS once), then every (column, weight) thread
+// walks the bins.  CP = min(ncols, 256 / K) columns per workgroup, grid = (time blocks, column groups).
 __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = p.K, CP = p.CP, RPB = 256 / CP;                   // RPB rows per phase-A sweep
     double* phiS = reinterpret_cast<double*>(smem);                 // [B][R]
-    double* wS = phiS + p.B * p.R;                                  // [CP][K]
-    double* scr = wS + p.CP * p.K;                                  // per wave: 64 x (x0, ic, s, col) + 64 x K
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = p.K, CP = p.CP, RPB = 256 / CP;
-    const int cl = tid % CP, rsub = tid / CP;
-    const int c = blockIdx.y * CP + cl;
-    const bool valid = c < p.ncols;
-    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
-    for (int i = tid; i < CP * K; i += 256) {
-        const int cc = blockIdx.y * CP + i / K;
-        wS[i] = (cc < p.ncols) ? p.w[(size_t)cc * K + i % K] : 0.0;
-    }
-    double* ent = scr + (size_t)wave * (64 * 4 + 64 * PGL_KMAX);    // [64][4]
-    double* outv = ent + 64 * 4;                                    // [64][PGL_KMAX]
-    __syncthreads();
-
-    const int n = valid ? p.cols[c] : 0, np = valid ? p.pre[c] : 0;
-    const double awc = valid ? p.aw[c] : 0.0;
-    const double bias = valid ? p.theta[(size_t)n * p.P] : 0.0;
-    double beta[PGL_MAXB];
-#pragma unroll
-    for (int b = 0; b < PGL_MAXB; ++b)
-        beta[b] = (valid && b < p.B) ? p.theta[(size_t)n * p.P + p.woff + np * p.B + b] : 0.0;
-    double acc[PGL_KMAX];
-#pragma unroll
-    for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
-
+    double* X0 = phiS + p.B * p.R;                                  // [gtb][CP], gtb * CP >= 256
+    double* IC = X0 + p.gtb * CP;
+    double* SS = IC + p.gtb * CP;
+    int2* evS = reinterpret_cast<int2*>(SS + p.gtb * CP);           // [CP][PGL_GECAP]
+    int* ecnt = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP);   // [CP] staged count, -1 = too many
+    const int tid = threadIdx.x;
     const long long tb0 = p.t_lo + (long long)blockIdx.x * p.rows;
     long long tb1 = tb0 + p.rows;
     if (tb1 > p.t_hi) tb1 = p.t_hi;
-    // passes of 4*RPB rows: element i of this lane is row tp + rsub + i*RPB
-    for (long long tp = tb0; tp < tb1; tp += 4 * RPB) {
-        double x0[4], ic[4];
-        unsigned sc[4];
-        bool live[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long t = tp + rsub + (long long)i * RPB;
-            live[i] = valid && t < tb1;
-            const long long tc = live[i] ? t : p.t_lo;
-            const int tile = (int)(tc >> 4);
-            ic[i] = live[i] ? pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + np], p.whi[(size_t)tile * p.N + np],
-                                               (int)tc, p.R, p.B, phiS, beta)
-                            : 0.0;
-            // idle elements get a benign current (series regime of the softplus)
-            x0[i] = live[i] ? (bias + p.GX[tc * p.xs + n]) - awc * ic[i] : (p.nlin == 1 ? 30.0 : 0.0);
-            sc[i] = live[i] ? p.S[tc * p.N + n] : 0u;
+    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
+    // presynaptic events that can reach the block's bins: s in [tb0 - R, tb1 - 2], per column
+    const int tile_a = (int)(tb0 >> 4), tile_b = (int)((tb1 - 1) >> 4);
+    for (int i = tid; i < CP; i += 256) {
+        const int cc = blockIdx.y * CP + i;
+        int cnt = 0;
+        if (cc < p.ncols) {
+            const int npc = p.pre[cc];
+            cnt = p.whi[(size_t)tile_b * p.N + npc] - p.wlo[(size_t)tile_a * p.N + npc];
         }
+        ecnt[i] = (cnt <= PGL_GECAP) ? cnt : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < CP * PGL_GECAP; i += 256) {
+        const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
+        const int cc = blockIdx.y * CP + ci;
+        if (cc < p.ncols && j < ecnt[ci]) evS[i] = p.spk[p.wlo[(size_t)tile_a * p.N + p.pre[cc]] + j];
+    }
+    // phase A role: column ca = tid % CP, rows ra, ra + RPB, ... of every sub-block
+    const int ca = tid % CP, ra = tid / CP;
+    const int cca = blockIdx.y * CP + ca;
+    const bool a_valid = (ra < RPB) && (cca < p.ncols);
+    const int na = a_valid ? p.cols[cca] : 0, npa = a_valid ? p.pre[cca] : 0;
+    const double awa = a_valid ? p.aw[cca] : 0.0;
+    const double biasa = a_valid ? p.theta[(size_t)na * p.P] : 0.0;
+    double beta[PGL_MAXB];
 #pragma unroll
-        for (int k = 0; k < PGL_KMAX; ++k) {
-            if (k < K) {
-                const double wk = wS[cl * K + k];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double lam = pgl_lambda_only(fma(wk, ic[i], x0[i]), p.nlin, PGL_C);
-                    // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
-                    const double v = (lam == 0.0) ? __builtin_nan("") : -p.dt * lam;
-                    acc[k] += live[i] ? v : 0.0;
-                }
-            }
-        }
-        // ---- spike terms, compacted per wave ----
-        unsigned long long m[4];
-        int cnt[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            m[i] = __ballot(sc[i] != 0u);
-            cnt[i] = __popcll(m[i]);
-        }
-        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        if (total == 0) continue;
-        int slot[4];
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            slot[i] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[i] >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m[i], 0u));
-            base += cnt[i];
-        }
-        for (int r0 = 0; r0 < total; r0 += 64) {                    // rounds of 64 entries (almost always one)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (sc[i] != 0u && slot[i] >= r0 && slot[i] < r0 + 64) {
-                    double* e = ent + (size_t)(slot[i] - r0) * 4;
-                    e[0] = x0[i]; e[1] = ic[i]; e[2] = (double)sc[i]; e[3] = (double)cl;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (r0 + lane < total) {
-                const double* e = ent + (size_t)lane * 4;
-                const double ex0 = e[0], eic = e[1], es = e[2];
-                const int ecl = (int)e[3];
-                for (int k = 0; k < K; ++k) {
-                    const double x = fma(wS[ecl * K + k], eic, ex0);
-                    double loglam = x;
-                    if (p.nlin == 1) {
-                        // pgl_lambda_only's wave-uniform series test would see a partial wave here
-                        const double ee = pgl_exp(-fabs(x), PGL_C);
-                        const double u = 1.0 + ee;
-                        const double lam = fmax(x, 0.0) + (pgl_log(u, PGL_C) + (ee - (u - 1.0)) * pgl_rcp(u));
-                        loglam = pgl_log(lam, PGL_C);
+    for (int b = 0; b < PGL_MAXB; ++b)
+        beta[b] = (a_valid && b < p.B) ? p.theta[(size_t)na * p.P + p.woff + npa * p.B + b] : 0.0;
+    // phase B role: (time split ts, weight kb, column cb), column fastest: the lanes of a wave share the
+    // candidate weight (mostly), so the wave-uniform regime tests of the softplus see currents of one
+    // sign; TS = 256 / (CP*K) threads share one (column, weight) pair when the launch is narrow (the
+    // single-pair evaluations of the ARS draws), each taking every TS-th bin
+    const int CK = CP * K;
+    const int TS = (256 / CK > 0) ? 256 / CK : 1;
+    const int ts_b = tid / CK, q_b = tid % CK;
+    const bool worker = ts_b < TS;
+    const int kb = worker ? q_b / CP : 0, cb = worker ? q_b % CP : 0;
+    const int ccb = blockIdx.y * CP + cb;
+    const bool b_valid = worker && ccb < p.ncols;
+    const double wk = b_valid ? p.w[(size_t)ccb * K + kb] : 0.0;
+    double acc = 0.0;
+    __syncthreads();
+    const int my_cnt = ecnt[ca];
+    const int2* my_ev = evS + (size_t)ca * PGL_GECAP;
+    int jlo = 0;                                                    // first staged event still inside the window
+    const int GTB = p.gtb;
+
+    for (long long ts = tb0; ts < tb1; ts += GTB) {
+        // ---- phase A: pair currents of the sub-block ----
+        if (ra < RPB) {
+            for (int tt = ra; tt < GTB; tt += RPB) {
+                const long long t = ts + tt;
+                const bool live = a_valid && t < tb1;
+                double a = 0.0, x0 = (p.nlin == 1) ? 30.0 : 0.0, sv = 0.0;   // idle: benign current (series regime)
+                if (live) {
+                    if (my_cnt >= 0) {
+                        // staged events are time-sorted; t grows along the thread's walk, so jlo only moves up
+                        for (int j = jlo; j < my_cnt; ++j) {
+                            const int2 e = my_ev[j];
+                            const int d = (int)t - e.x - 1;
+                            if (d < 0) break;
+                            if (d >= p.R) {
+                                jlo = j + 1;
+                                continue;
+                            }
+                            double hh = 0.0;
+                            for (int b = 0; b < p.B; ++b) hh = fma(phiS[b * p.R + d], beta[b], hh);
+                            a = fma((double)e.y, hh, a);
+                        }
+                    } else {
+                        const int tile = (int)(t >> 4);
+                        a = pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + npa], p.whi[(size_t)tile * p.N + npa],
+                                             (int)t, p.R, p.B, phiS, beta);
                     }
-                    outv[(size_t)lane * PGL_KMAX + k] = es * loglam;
+                    x0 = (biasa + p.GX[t * p.xs + na]) - awa * a;
+                    sv = (double)p.S[t * p.N + na];
                 }
+                X0[tt * CP + ca] = x0;
+                IC[tt * CP + ca] = a;
+                SS[tt * CP + ca] = sv;
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (sc[i] != 0u && slot[i] >= r0 && slot[i] < r0 + 64) {
-                    const double* o = outv + (size_t)(slot[i] - r0) * PGL_KMAX;
-                    for (int k = 0; k < K; ++k) acc[k] += o[k];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // ---- phase B: every (time split, weight, column) thread walks its bins ----
+        const int nb = (int)((tb1 - ts < GTB) ? tb1 - ts : GTB);
+#pragma unroll 4
+        for (int tt = worker ? ts_b : 0; tt < GTB; tt += TS) {
+            const double x = fma(wk, IC[tt * CP + cb], X0[tt * CP + cb]);
+            const double sv = SS[tt * CP + cb];
+            const double lam = pgl_lambda_only(x, p.nlin, PGL_C);
+            // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
+            double v = (lam == 0.0) ? __builtin_nan("") : -p.dt * lam;
+            if (sv != 0.0) v = fma(sv, (p.nlin == 1) ? pgl_log(lam, PGL_C) : x, v);
+            acc += (tt < nb) ? v : 0.0;
+        }
+        __syncthreads();
+    }
+    // time splits of one (column, weight) pair are summed in split order
+    if (TS > 1) {
+        double* red = X0;                                           // >= 256 doubles (gtb * CP >= 256)
+        red[tid] = acc;
+        __syncthreads();
+        if (ts_b == 0) {
+            acc = 0.0;
+            for (int j = 0; j < TS; ++j) acc += red[j * CK + q_b];
         }
     }
-    // ---- block reduction per column: rows rsub = 0..RPB-1 of the same column, fixed order ----
-    __syncthreads();
-    double* red = scr;                                              // [256][PGL_KMAX]
-#pragma unroll
-    for (int k = 0; k < PGL_KMAX; ++k) red[(size_t)tid * PGL_KMAX + k] = acc[k];
-    __syncthreads();
-    if (rsub == 0 && valid) {
-        for (int k = 0; k < K; ++k) {
-            double s = 0.0;
-            for (int r = 0; r < RPB; ++r) s += red[(size_t)(r * CP + cl) * PGL_KMAX + k];
-            p.part[((size_t)blockIdx.x * p.ncols + c) * PGL_KMAX + k] = s;
-        }
-    }
+    if (b_valid && ts_b == 0) p.part[((size_t)blockIdx.x * p.ncols + ccb) * PGL_KMAX + kb] = acc;
 }
 
 // out[c][k] = sum over the time blocks (fixed order); grid = ncols, block = 64
@@ -2680,7 +2694,7 @@ __global__ __launch_bounds__(256) void k_gibbs_update_cols(const GibbsColsParams
     const bool valid = c < p.ncols;
     for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
     __syncthreads();
-    if (!valid) return;
+    if (!valid || rsub >= RPB) return;                   // CP need not divide 256
     const int n = p.cols[c], np = p.pre[c];
     const double delta = p.w[c];
     double beta[PGL_MAXB];
@@ -2768,6 +2782,242 @@ __global__ __launch_bounds__(256) void k_stim_conv(const double* __restrict__ zx
         for (int tau = 1; tau <= Rt; ++tau) a = fma(zs[threadIdx.x + Rt - tau], bs[(tau - 1) * Bt + bt], a);
         const int colo = layout == 0 ? bt * Bx + bx : bx * Bt + bt;
         fstim[t * Dst + colo] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Separable (rank-1) stimulus path for wide stimuli (SpatiotemporalStimulus, bkgd.py:172-345):
+//   I_stim[t,n] = sum_{bt,bx} fstim[t,bt,bx] w_t[n,bt] w_x[n,bx]          (bkgd.py:214-227)
+// with fstim[t,bt,bx] = sum_tau zx[t-tau,bx] basis_t[tau-1,bt] and zx = interp(stim) . basis_x
+// (bkgd.py:303-340, basis.py:238-273).  Interpolation, projection and filtering are linear, so
+//   y_n       = interp( (stim . basis_x) . w_x[n] )        a GEMM at the STIMULUS frame rate (T_stim rows)
+//   I_stim[:,n] = causal conv of y_n with h_n = basis_t . w_t[n]            (Rt taps)
+// and the dense (nT, Bt*Bx) feature matrix (7.4 GB at D_stim = 1024, T = 300 s) is never formed.
+// Gradients by the transposes:  rho_n[tau] = sum_t r[t,n] y_n[t-tau]  ->  d/dw_t = basis_t^T rho_n;
+//   q_n[s] = sum_tau r[s+tau,n] h_n[tau-1],  Qf = interp^T q_n,  d/dw_x = (stim . basis_x)^T Qf.
+// ---------------------------------------------------------------------------
+// np.interp of a frame-rate series (clamped at both ends): value at bin t and, for the transpose, the
+// bracketing frame and weight.  Same knot logic as k_stim_project.
+__device__ __forceinline__ void pgl_interp_knot(const long long t, const double dt, const double dt_stim,
+                                                const long long Tstim, long long& i0, double& a, bool& beyond)
+{
+    const double x = dt * (double)t;
+    i0 = (long long)floor(x / dt_stim);
+    if (i0 > Tstim - 2) i0 = Tstim - 2;
+    if (i0 < 0) i0 = 0;
+    while (i0 + 1 < Tstim - 1 && dt_stim * (double)(i0 + 1) <= x) ++i0;
+    while (i0 > 0 && dt_stim * (double)i0 > x) --i0;
+    beyond = (Tstim < 2) || (x >= dt_stim * (double)(Tstim - 1));
+    const double x0 = dt_stim * (double)i0, x1 = dt_stim * (double)(i0 + 1);
+    a = (x - x0) / (x1 - x0);
+}
+__device__ __forceinline__ double pgl_interp_frames(const double* __restrict__ yf, const long long t,
+                                                    const double dt, const double dt_stim, const long long Tstim)
+{
+    if (t < 0) return 0.0;
+    long long i0;
+    double a;
+    bool beyond;
+    pgl_interp_knot(t, dt, dt_stim, Tstim, i0, a, beyond);
+    if (beyond) return yf[Tstim - 1];
+    const double f0 = yf[i0], f1 = yf[i0 + 1];
+    return (f1 - f0) * a + f0;
+}
+
+// C[m][n] (ldc) = sum_k A[m][k] (lda) * B[n][k] (ldb): small f64 GEMM, 64 x 64 tiles, 256 threads x (4 x 4)
+__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A, int lda,
+                                                 const double* __restrict__ Bm, int ldb,
+                                                 double* __restrict__ C, int ldc, int M, int Nn, int Kd)
+{
+    __shared__ double As[32][65], Bs[32][65];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < Kd; k0 += 32) {
+        for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+            const int r = i >> 5, kk = i & 31;
+            As[kk][r] = (m0 + r < M && k0 + kk < Kd) ? A[(size_t)(m0 + r) * lda + k0 + kk] : 0.0;
+            Bs[kk][r] = (n0 + r < Nn && k0 + kk < Kd) ? Bm[(size_t)(n0 + r) * ldb + k0 + kk] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = As[kk][ty * 4 + i];
+                b[i] = Bs[kk][tx * 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + ty * 4 + i < M && n0 + tx * 4 + j < Nn)
+                C[(size_t)(m0 + ty * 4 + i) * ldc + n0 + tx * 4 + j] = acc[i][j];
+}
+
+struct SepParams {
+    const double* __restrict__ Yf;       // (npost, Tstim) frame-rate projections y_n
+    const double* __restrict__ basis_t;  // (Rt, Bt)
+    const double* __restrict__ theta;    // (npost, P) rows [bias, w_t(Bt), w_x(Bx), w_imp]
+    int P, Bt, Rt, npost, xs;
+    long long Tstim, nT, t_lo, t_hi;
+    double dt, dt_stim;
+    double* __restrict__ X;              // (nT, xs) currents (forward: += I_stim) / residuals r (backward)
+};
+
+#define PGL_SEP_TB 1024
+// forward: X[t][j] += sum_{tau=1..Rt} y_j[t-tau] h_j[tau-1];  grid = (time blocks, npost), block = 256
+__global__ __launch_bounds__(256) void k_sep_conv_fwd(const SepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ys = reinterpret_cast<double*>(smem);            // [Rt + TB]: bins tb0 - Rt .. tb0 + TB - 1
+    double* hs = ys + p.Rt + PGL_SEP_TB;                     // [Rt]
+    const int j = blockIdx.y;
+    const long long tb0 = p.t_lo + (long long)blockIdx.x * PGL_SEP_TB;
+    const double* yf = p.Yf + (size_t)j * p.Tstim;
+    for (int i = threadIdx.x; i < p.Rt + PGL_SEP_TB; i += 256)
+        ys[i] = pgl_interp_frames(yf, tb0 - p.Rt + i, p.dt, p.dt_stim, p.Tstim);
+    for (int i = threadIdx.x; i < p.Rt; i += 256) {
+        double h = 0.0;
+        for (int b = 0; b < p.Bt; ++b) h = fma(p.basis_t[(size_t)i * p.Bt + b], p.theta[(size_t)j * p.P + 1 + b], h);
+        hs[i] = h;
+    }
+    __syncthreads();
+    // thread owns 4 consecutive bins: one new y per tap, four FMAs
+    const int o = threadIdx.x * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // out[o+q] = sum_tau ys[Rt + o + q - tau] hs[tau-1]
+    double w0 = ys[p.Rt + o - 1 + 0], w1 = ys[p.Rt + o - 1 + 1], w2 = ys[p.Rt + o - 1 + 2], w3 = ys[p.Rt + o - 1 + 3];
+    for (int tau = 1; tau <= p.Rt; ++tau) {
+        const double h = hs[tau - 1];
+        acc[0] = fma(w0, h, acc[0]);
+        acc[1] = fma(w1, h, acc[1]);
+        acc[2] = fma(w2, h, acc[2]);
+        acc[3] = fma(w3, h, acc[3]);
+        w3 = w2; w2 = w1; w1 = w0;
+        w0 = (tau < p.Rt) ? ys[p.Rt + o - 1 - tau] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long t = tb0 + o + q;
+        if (t < p.t_hi && t < p.nT) p.X[t * p.xs + j] += acc[q];
+    }
+}
+
+// backward, part 1: q_j[s] = sum_{tau=1..Rt} r[s+tau][j] h_j[tau-1]  -> Qb[j][s - t_lo_q]  for the bins s
+// that can reach the evaluated range, s in [t_lo - Rt, t_hi);  grid = (time blocks over that range, npost)
+__global__ __launch_bounds__(256) void k_sep_conv_bwd(const SepParams p, double* __restrict__ Qb,
+                                                      long long s_lo, long long nS)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* rs = reinterpret_cast<double*>(smem);            // [TB + Rt]: r of bins sb0 .. sb0 + TB + Rt - 1
+    double* hs = rs + p.Rt + PGL_SEP_TB;
+    const int j = blockIdx.y;
+    const long long sb0 = s_lo + (long long)blockIdx.x * PGL_SEP_TB;
+    for (int i = threadIdx.x; i < p.Rt + PGL_SEP_TB; i += 256) {
+        const long long t = sb0 + i;
+        rs[i] = (t >= p.t_lo && t < p.t_hi) ? p.X[t * p.xs + j] : 0.0;
+    }
+    for (int i = threadIdx.x; i < p.Rt; i += 256) {
+        double h = 0.0;
+        for (int b = 0; b < p.Bt; ++b) h = fma(p.basis_t[(size_t)i * p.Bt + b], p.theta[(size_t)j * p.P + 1 + b], h);
+        hs[i] = h;
+    }
+    __syncthreads();
+    const int o = threadIdx.x * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // q[o+q'] = sum_tau rs[o + q' + tau] hs[tau-1]
+    double w0 = rs[o + 1], w1 = rs[o + 2], w2 = rs[o + 3], w3 = rs[o + 4];
+    for (int tau = 1; tau <= p.Rt; ++tau) {
+        const double h = hs[tau - 1];
+        acc[0] = fma(w0, h, acc[0]);
+        acc[1] = fma(w1, h, acc[1]);
+        acc[2] = fma(w2, h, acc[2]);
+        acc[3] = fma(w3, h, acc[3]);
+        w0 = w1; w1 = w2; w2 = w3;
+        w3 = (tau < p.Rt) ? rs[o + 4 + tau] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long s = sb0 + o + q;
+        if (s - s_lo < nS) Qb[(size_t)j * nS + (s - s_lo)] = (s >= 0) ? acc[q] : 0.0;
+    }
+}
+
+// backward, part 2: Qf[j][f] = sum_s w(s -> f) q_j[s]  (transpose of np.interp); thread = (f, j), fixed order
+__global__ __launch_bounds__(256) void k_sep_interp_T(const SepParams p, const double* __restrict__ Qb,
+                                                      long long s_lo, long long nS, double* __restrict__ Qf)
+{
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (f >= p.Tstim) return;
+    const double ratio = p.dt_stim / p.dt;
+    long long a = (long long)floor((double)(f - 1) * ratio) - 2, b = (long long)ceil((double)(f + 1) * ratio) + 2;
+    if (f == p.Tstim - 1) b = s_lo + nS;                      // clamped tail: every later bin reads the last frame
+    if (a < s_lo) a = s_lo;
+    if (a < 0) a = 0;
+    if (b > s_lo + nS) b = s_lo + nS;
+    double acc = 0.0;
+    for (long long s = a; s < b; ++s) {
+        long long i0;
+        double w;
+        bool beyond;
+        pgl_interp_knot(s, p.dt, p.dt_stim, p.Tstim, i0, w, beyond);
+        double c = 0.0;
+        if (beyond) c = (f == p.Tstim - 1) ? 1.0 : 0.0;
+        else if (i0 == f) c = 1.0 - w;
+        else if (i0 + 1 == f) c = w;
+        if (c != 0.0) acc = fma(c, Qb[(size_t)j * nS + (s - s_lo)], acc);
+    }
+    Qf[(size_t)j * p.Tstim + f] = acc;
+}
+
+// backward, part 3: rho_j[tau] = sum_t r[t][j] y_j[t-tau] over one time block -> part[blk][j][tau-1]
+// grid = (time blocks over [t_lo, t_hi), npost), block = 256 (thread = lag, looping if Rt > 256)
+__global__ __launch_bounds__(256) void k_sep_corr(const SepParams p, double* __restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ys = reinterpret_cast<double*>(smem);            // [Rt + TB]
+    double* rs = ys + p.Rt + PGL_SEP_TB;                     // [TB]
+    const int j = blockIdx.y;
+    const long long tb0 = p.t_lo + (long long)blockIdx.x * PGL_SEP_TB;
+    const double* yf = p.Yf + (size_t)j * p.Tstim;
+    for (int i = threadIdx.x; i < p.Rt + PGL_SEP_TB; i += 256)
+        ys[i] = pgl_interp_frames(yf, tb0 - p.Rt + i, p.dt, p.dt_stim, p.Tstim);
+    for (int i = threadIdx.x; i < PGL_SEP_TB; i += 256) {
+        const long long t = tb0 + i;
+        rs[i] = (t < p.t_hi) ? p.X[t * p.xs + j] : 0.0;
+    }
+    __syncthreads();
+    for (int tau = 1 + threadIdx.x; tau <= p.Rt; tau += 256) {
+        double acc = 0.0;
+        for (int i = 0; i < PGL_SEP_TB; ++i) acc = fma(rs[i], ys[p.Rt + i - tau], acc);
+        part[((size_t)blockIdx.x * p.npost + j) * p.Rt + (tau - 1)] = acc;
+    }
+}
+
+// d ll / d w_t[j][bt] = sum_tau basis_t[tau-1][bt] * sum_blk part[blk][j][tau-1]; grid = npost, block = 64
+__global__ __launch_bounds__(64) void k_sep_wt_grad(const SepParams p, const double* __restrict__ part,
+                                                    int nblk, double* __restrict__ grad)
+{
+    const int j = blockIdx.x;
+    for (int b = 0; b < p.Bt; ++b) {
+        double s = 0.0;
+        for (int tau = threadIdx.x; tau < p.Rt; tau += 64) {
+            double rho = 0.0;
+            for (int k = 0; k < nblk; ++k) rho += part[((size_t)k * p.npost + j) * p.Rt + tau];
+            s = fma(p.basis_t[(size_t)tau * p.Bt + b], rho, s);
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x == 0) grad[(size_t)j * p.P + 1 + b] = s;
     }
 }
 

@@ -278,7 +278,7 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         w = self.glm.imp_model.flat_weights(xn['imp']).reshape(pop.N, -1)
         I_imp = h.impulse_currents(w)
         if self.glm.Dstim > 0:
-            I_stim = pop.stim_features().dot(self.glm.bkgd_model.flat_weights(xn['bkgd']))
+            I_stim = pop.stim_features().dot(self.glm.bkgd_model.dense_weights(xn['bkgd']))
         else:
             I_stim = 0.0
         return I_bias, I_stim, I_imp, self.network.graph.pA

@@ -130,6 +130,8 @@ class Population(object):
         data = self._current if data is None else data
         if self.glm.Dstim == 0:
             return None
+        if getattr(self.glm.bkgd_model, 'separable', False):     # no dense matrix on the device: host twin
+            return self.glm.bkgd_model.host_features(data, np.asarray(data['S']).shape[0])
         return self._handle(data).get_stim_features()
 
     def release_data(self, data=None):
@@ -281,7 +283,7 @@ class Population(object):
                    'dt': dt}
             fst = self.glm.bkgd_model.host_features(tmp, nT)
             for n in range(N):
-                X[:, n] += fst.dot(self.glm.bkgd_model.flat_weights(vars['glms'][n]['bkgd']))
+                X[:, n] += fst.dot(self.glm.bkgd_model.dense_weights(vars['glms'][n]['bkgd']))
         # imps[n_pre, n_post, :] (population.py:275-282)
         imps = np.array([self.glm.imp_model.impulse(vars['glms'][n]['imp']) for n in range(N)])
         imps = np.transpose(imps, axes=[1, 0, 2])

@@ -29,6 +29,12 @@ h.gibbs_ll_cols(cols, pre, aw, ws)
 t0 = time.time()
 for _ in range(20): h.gibbs_ll_cols(cols, pre, aw, ws)
 t_ll = (time.time() - t0) / 20
+for nm, wz in (('all weights 0 (series regime everywhere)', np.zeros((N, 11))), ('positive nodes only', np.abs(ws)),
+               ('K=1', ws[:, :1])):
+    h.gibbs_ll_cols(cols, pre, aw, wz)
+    t0 = time.time()
+    for _ in range(10): h.gibbs_ll_cols(cols, pre, aw, wz)
+    print("  ll_cols, %s: %.3f ms" % (nm, (time.time() - t0) / 10 * 1e3))
 t0 = time.time()
 for _ in range(50): h.gibbs_ll_cols(cols[:1], pre[:1], aw[:1], ws[:1, :1])
 t_one = (time.time() - t0) / 50
