@@ -139,6 +139,34 @@ def map_wall_clock(S, N, dt):
             "optimizer": "lock-step batched BFGS, maxiter 225, GPU-resident state"}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity mask capped by the cgroup CPU
+    quota (a container that sees 256 logical CPUs may be limited to a few cores' worth of time)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                         # cgroup v2: "<quota> <period>" | "max ..."
+            q, per = f.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                q = float(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(np.ceil(quota))))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     """CPU baselines of BASELINE.md section 3 on the host cores of this box, all on a bounded sample
     (the first `sample_bins` bins of the same spike matrix, all neurons; cost is linear in nT):
@@ -156,7 +184,7 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     t0 = time.time()
     CO.ll_grad(Ss, fS, theta, Weff, 'explinear', dt, 0, N, threads=1)
     per_eval_1 = (time.time() - t0) * scale
-    cores = os.cpu_count() or 1
+    cores, logical, quota = usable_cores()
     t0 = time.time()
     CO.ll_grad(Ss, fS, theta, Weff, 'explinear', dt, threads=cores)
     per_eval_m = (time.time() - t0) * scale
@@ -173,6 +201,7 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
         "sample": "first %d of %d bins, all %d neurons, scaled linearly; B1 = C restatement of the "
                   "reference per-neuron dataflow on materialised fS (oracle/glm_oracle.c)"
                   % (sample_bins, nT, N),
+        "host": {"logical_cpus": logical, "usable_cores": cores, "cgroup_cpu_quota": quota},
         "all_cores": {"value": 1.0 / per_eval_m, "cores": cores,
                       "sample": "B1, first %d bins, all neurons, OpenMP over neurons" % sample_bins},
         "b2_blocked": {"value": 1.0 / per_eval_b2, "cores": cores, "single_core_value": 1.0 / per_eval_b2_1,
@@ -294,6 +323,8 @@ def main():
                 else:
                     hl = [g.cpu() for g in gather]
                     dist.all_gather(hl, d_ll.cpu())
+                    for g, hg in zip(gather, hl):
+                        g.copy_(hg)
             elif args.shard == 'time':
                 dist.all_reduce(d_out)               # population (ll, grad) on every rank
             else:

@@ -49,7 +49,8 @@ typedef struct pgl_context* pgl_handle;
                                 * below that the K-split kernel, on resident feature tiles (6) when the
                                 * feature row is short enough for two LDS step buffers (N*B + Dstim up to
                                 * ~320-450 columns depending on the post block), else with in-kernel
-                                * feature generation (2);  6 = force the resident K-split kernel when it fits;
+                                * feature generation (2); rows of <= 320 columns and <= 64 post neurons: one wave per
+                                * post tile without any K split (7);  6 / 7 = force those kernels when they fit;
                                 * 2 = force the K-split kernel; 3 = force the two-pass kernel with
                                 * on-the-fly features; 4 = force the two-pass kernel on resident feature
                                 * tiles.  Auto uses 4's kernel (k_fused5) when the call covers >= 65
@@ -229,7 +230,7 @@ int pgl_set_stream(pgl_handle h, void* stream);
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),
  * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins), [9]=kernel the call would use
  * (1 4-wave, 2 K-split, 3 K-split with f32 features, 4 two-pass, 5 two-pass on resident feature
- * tiles, 6 K-split on resident feature tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
+ * tiles, 6 K-split on resident feature tiles, 7 single pass without K split on resident tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
  * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab). */
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info);
 

@@ -148,7 +148,7 @@ def test_explinear_mixed_regimes_in_one_wave():
     are 16 different neurons): series lanes (|x| > 9.25) and full log1p lanes side by side, x
     crossing 0, through every kernel family."""
     N = 16
-    for kern in (2, 3, 4, 6):
+    for kern in (2, 3, 4, 6, 7):
         p = H.Problem(N, 3000, H.std_ibasis(), seed=40, rate_hz=40.0, w_scale=0.3)
         p.theta[:, 0] = np.linspace(-30.0, 30.0, N)
         p.theta[5, 0], p.theta[6, 0] = -0.2, 0.2              # straddle 0 with the impulse currents on top

@@ -302,9 +302,9 @@ def test_f32_feature_kernel_agrees():
     p = H.Problem(48, 3000, H.std_ibasis(), seed=21, weighted=True)
     d0 = p.device()
     ll0, g0 = d0.ll_grad(p.theta, p.Weff)
-    assert d0.info()['kernel_version'] == 6           # short feature rows: K-split kernel on resident tiles
+    assert d0.info()['kernel_version'] == 7           # short feature rows, 3 post tiles: one wave per tile, resident tiles
     assert d0.info()['resident_feature_bytes'] > 0
-    for kern in (2, 3, 4):
+    for kern in (2, 3, 4, 6):
         d1 = p.device()
         d1.set_option(_lib.OPT_KERNEL, kern)
         ll1, g1 = d1.ll_grad(p.theta, p.Weff)
@@ -429,7 +429,7 @@ def test_forced_kernels_on_tiny_shapes():
               H.Problem(7, 16, H.std_ibasis(), seed=92, rate_hz=200.0),    # exactly one time tile
               H.Problem(33, 17, H.st_ibasis(), kind='exp', Dstim=2, seed=93, rate_hz=100.0, w_scale=0.01)):
         ll0, g0 = p.oracle_ll_grad()
-        for kern in (2, 3, 4, 6):
+        for kern in (2, 3, 4, 6, 7):
             d = p.device()
             d.set_option(_lib.OPT_KERNEL, kern)
             ll, g = d.ll_grad(p.theta, p.Weff)

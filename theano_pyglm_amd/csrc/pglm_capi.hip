@@ -104,6 +104,8 @@ struct Plan {
     int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
     int mt;                             // version 6: 16-bin tiles per step
+    int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
+    int nw7, wg7;                       // version 7: waves per workgroup (1, 2, 4), workgroups per CU
     size_t lds;
     bool f32;
 };
@@ -230,32 +232,99 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         pl.KT = pl.KTW * pl.KSPLIT;
         pl.wpb = nw;
         pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
-        // version 6: the same K-split geometry on resident feature tiles (k_fused6) when two step
-        // buffers of whole-row images fit the LDS: short feature rows (C1, C2, C5)
+        // version 6: the K-split scheme on resident feature tiles (k_fused6) when two step buffers of
+        // whole-row images fit the LDS: short feature rows (C1, C2, C5).  Post blocks of one or two tiles
+        // run as 4-wave workgroups, two per CU (less padding of K, barrier waits overlap).
         pl.mt = 0;
+        pl.nw6 = 8;
         if (pl.version == 2 && single_slice && (h->opt_kernel == 0 || h->opt_kernel == 6) && h->opt_ptw == 0) {
-            for (int mt = 2; mt >= 1 && pl.mt == 0; --mt) {
-                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(pl.KT) + (size_t)mt * (nw + pl.PTW) * 2048 + 256;
-                if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) pl.mt = mt;
+            int ptw6 = pl.PTW, nw6 = 8, ktw6 = pl.KTW;
+            if (pl.nPT <= 2) {
+                nw6 = 4;
+                ptw6 = pl.nPT;
+                const int needw6 = (need + nw6 / ptw6 - 1) / (nw6 / ptw6);
+                ktw6 = 0;
+                for (int k : kKTW)
+                    if (k >= needw6 && k <= 10) {
+                        ktw6 = k;
+                        break;
+                    }
+                if (ktw6 == 0) { nw6 = 8; ptw6 = pl.PTW; ktw6 = pl.KTW; }
             }
-            if (pl.mt > 0) {
+            const int kt6 = ktw6 * (nw6 / ptw6);
+            int mt6 = 0;
+            for (int mt = (nw6 == 4 ? 1 : 2); mt >= 1 && mt6 == 0; --mt) {
+                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt6) + (size_t)mt * (nw6 + ptw6) * 2048 + 256;
+                const size_t cap = (nw6 == 4) ? 80 * 1024 : 160 * 1024;      // two 4-wave workgroups per CU
+                if (lds6 <= cap && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
+            }
+            if (mt6 == 0 && nw6 == 4) {                                      // does not fit twice: 8-wave form
+                nw6 = 8; ptw6 = pl.PTW; ktw6 = pl.KTW;
+                const int kt8 = ktw6 * (8 / ptw6);
+                for (int mt = 2; mt >= 1 && mt6 == 0; --mt) {
+                    const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt8) + (size_t)mt * (8 + ptw6) * 2048 + 256;
+                    if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
+                }
+            }
+            if (mt6 > 0) {
+                const int ktall = ktw6 * (nw6 / ptw6);
                 bool ok = true;
                 if (h->opt_kernel == 0 &&
-                    !(h->fimg_kth == (pl.KT << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
+                    !(h->fimg_kth == (ktall << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const size_t want = (size_t)pl.nTiles * pgl_img_bytes(pl.KT);
+                        const size_t want = (size_t)pl.nTiles * pgl_img_bytes(ktall);
                         if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) ok = false;
                     }
                 }
-                if (ok) pl.version = 6;
+                if (ok) {
+                    pl.version = 6;
+                    pl.mt = mt6; pl.nw6 = nw6; pl.PTW = ptw6; pl.KTW = ktw6; pl.KSPLIT = nw6 / ptw6;
+                    pl.KT = ktall; pl.wpb = nw6;
+                    pl.nPB = (pl.nPT + pl.PTW - 1) / pl.PTW;
+                }
             }
+        }
+    }
+    // version 7: no K split at all -- one wave per post tile carries the whole feature row (<= 20 k-tiles)
+    // through forward, epilogue and backward; small workgroups, several per CU (k_fused7)
+    static const int kKT7[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};
+    pl.nw7 = 0;
+    pl.wg7 = 1;
+    // (measured, tools/small_shape_scan.py / config_table.py: 3-4 post tiles 46 TFLOP/s against 39 of the
+    // K-split kernel at C5; with 1-2 post tiles only 2-6 waves fit a CU and the 4-wave K-split form wins)
+    if ((pl.version == 2 || pl.version == 6) && !pl.f32 && single_slice && pl.nPT <= 4 && need <= 20 &&
+        ((h->opt_kernel == 0 && pl.nPT >= 3) || h->opt_kernel == 7) && h->opt_ptw == 0) {
+        int kt7 = 0;
+        for (int k : kKT7)
+            if (k >= need) {
+                kt7 = k;
+                break;
+            }
+        const int nw7 = (pl.nPT >= 3) ? 4 : pl.nPT;
+        const size_t lds7 = (size_t)2 * pgl_img_bytes(kt7) + 256 + (size_t)nw7 * 192 * 8;
+        bool ok = kt7 > 0 && lds7 <= 160 * 1024;
+        if (ok && h->opt_kernel == 0 &&
+            !(h->fimg_kth == (kt7 << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t want = (size_t)pl.nTiles * pgl_img_bytes(kt7);
+                if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) ok = false;
+            }
+        }
+        if (ok) {
+            pl.version = 7;
+            pl.nw7 = nw7;
+            pl.wg7 = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds7, (size_t)(8 / nw7)));
+            pl.PTW = nw7; pl.KSPLIT = 1; pl.KTW = kt7; pl.KT = kt7; pl.wpb = nw7;
+            pl.nPB = (pl.nPT + nw7 - 1) / nw7;
+            pl.mt = 0;
         }
     }
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
-    const int wgPerCU = 1;
+    const int wgPerCU = (pl.version == 7) ? pl.wg7 : (pl.version == 6 && pl.nw6 == 4) ? 2 : 1;
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
     pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
@@ -269,8 +338,12 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }
+    if (pl.version == 7) {
+        pl.lds = (size_t)2 * pgl_img_bytes(pl.KT) + 256 + (size_t)pl.nw7 * 192 * 8;
+        return PGL_OK;
+    }
     if (pl.version == 6) {
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * (8 + pl.PTW) * 2048 + 256;
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * (pl.nw6 + pl.PTW) * 2048 + 256;
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -402,51 +475,97 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
     return hipErrorInvalidValue;
 }
 
-template <int KTW, int PTW, int MT>
+template <int KTW, int PTW, int MT, int NW>
 static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
-    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (8 / PTW)) + (size_t)MT * (8 + PTW) * 2048 + 256;
-    if constexpr (need <= 160 * 1024) {
-        auto kern = k_fused6<KTW, PTW, MT>;
+    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * (NW + PTW) * 2048 + 256;
+    if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
+        auto kern = k_fused6<KTW, PTW, MT, NW>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+        hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NW * 64), pl.lds, s, fp);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
     }
 }
 
-template <int PTW, int MT>
+template <int PTW, int MT, int NW>
 static hipError_t launch_fused6_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
     switch (pl.KTW) {
-    case 1: return launch_fused6_t<1, PTW, MT>(pl, fp, s);
-    case 2: return launch_fused6_t<2, PTW, MT>(pl, fp, s);
-    case 3: return launch_fused6_t<3, PTW, MT>(pl, fp, s);
-    case 5: return launch_fused6_t<5, PTW, MT>(pl, fp, s);
-    case 7: return launch_fused6_t<7, PTW, MT>(pl, fp, s);
-    case 10: return launch_fused6_t<10, PTW, MT>(pl, fp, s);
+    case 1: return launch_fused6_t<1, PTW, MT, NW>(pl, fp, s);
+    case 2: return launch_fused6_t<2, PTW, MT, NW>(pl, fp, s);
+    case 3: return launch_fused6_t<3, PTW, MT, NW>(pl, fp, s);
+    case 5: return launch_fused6_t<5, PTW, MT, NW>(pl, fp, s);
+    case 7: return launch_fused6_t<7, PTW, MT, NW>(pl, fp, s);
+    case 10: return launch_fused6_t<10, PTW, MT, NW>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
 
 static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.nw6 == 4) {
+        switch (pl.PTW * 4 + pl.mt) {
+        case 1 * 4 + 1: return launch_fused6_k<1, 1, 4>(pl, fp, s);
+        case 2 * 4 + 1: return launch_fused6_k<2, 1, 4>(pl, fp, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.PTW * 4 + pl.mt) {
-    case 1 * 4 + 1: return launch_fused6_k<1, 1>(pl, fp, s);
-    case 1 * 4 + 2: return launch_fused6_k<1, 2>(pl, fp, s);
-    case 2 * 4 + 1: return launch_fused6_k<2, 1>(pl, fp, s);
-    case 2 * 4 + 2: return launch_fused6_k<2, 2>(pl, fp, s);
-    case 4 * 4 + 1: return launch_fused6_k<4, 1>(pl, fp, s);
-    case 4 * 4 + 2: return launch_fused6_k<4, 2>(pl, fp, s);
+    case 1 * 4 + 1: return launch_fused6_k<1, 1, 8>(pl, fp, s);
+    case 1 * 4 + 2: return launch_fused6_k<1, 2, 8>(pl, fp, s);
+    case 2 * 4 + 1: return launch_fused6_k<2, 1, 8>(pl, fp, s);
+    case 2 * 4 + 2: return launch_fused6_k<2, 2, 8>(pl, fp, s);
+    case 4 * 4 + 1: return launch_fused6_k<4, 1, 8>(pl, fp, s);
+    case 4 * 4 + 2: return launch_fused6_k<4, 2, 8>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int KT, int NWV>
+static hipError_t launch_fused7_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    auto kern = k_fused7<KT, NWV>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NWV * 64), pl.lds, s, fp);
+    return hipGetLastError();
+}
+
+template <int NWV>
+static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.KT) {
+    case 1: return launch_fused7_t<1, NWV>(pl, fp, s);
+    case 2: return launch_fused7_t<2, NWV>(pl, fp, s);
+    case 3: return launch_fused7_t<3, NWV>(pl, fp, s);
+    case 5: return launch_fused7_t<5, NWV>(pl, fp, s);
+    case 7: return launch_fused7_t<7, NWV>(pl, fp, s);
+    case 10: return launch_fused7_t<10, NWV>(pl, fp, s);
+    case 13: return launch_fused7_t<13, NWV>(pl, fp, s);
+    case 16: return launch_fused7_t<16, NWV>(pl, fp, s);
+    case 20: return launch_fused7_t<20, NWV>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_fused7(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    switch (pl.nw7) {
+    case 1: return launch_fused7_k<1>(pl, fp, s);
+    case 2: return launch_fused7_k<2>(pl, fp, s);
+    case 4: return launch_fused7_k<4>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
 
 static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (pl.version == 7) return launch_fused7(pl, fp, s);
     if (pl.version == 6) return launch_fused6(pl, fp, s);
     if (pl.version == 5) return launch_fused5(pl, fp, s);
     if (pl.version == 4) return launch_fused3(pl, fp, s);
@@ -1064,7 +1183,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             rc = ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles);
             if (rc) return rc;
         }
-        if (pl.version == 6) {
+        if (pl.version == 6 || pl.version == 7) {
             rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
             if (rc) return rc;
         }
@@ -1290,12 +1409,12 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     double v[12];
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
     v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth)
-            : (pl.version == 6) ? (double)pl.nTiles * (double)pgl_img_bytes(pl.KT) : 0.0;            // resident feature bytes
+            : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)pgl_img_bytes(pl.KT) : 0.0;   // resident feature bytes
     // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
     // pass 1 and the H part again in pass 2, residual slab written and read)
     v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
             : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
-            : (pl.version == 6) ? v[10] * pl.nPB : 0.0;
+            : (pl.version == 6 || pl.version == 7) ? v[10] * pl.nPB : 0.0;
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;
     const double nrows = (double)(h->t_hi - h->t_lo);

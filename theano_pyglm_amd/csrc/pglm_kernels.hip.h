@@ -296,9 +296,11 @@ __device__ long long g_pgl_prof[2][4096][8][12];          // [pass-1][workgroup]
 #ifdef PGL_PROF
 #define PGL_PROF_ARGS , long long (&prof_acc)[12], long long& prof_t
 #define PGL_PROF_PASS , prof_acc, prof_t
+#define PGL_PROF_DUMMY , pgl_prof_dummy_acc, pgl_prof_dummy_t
 #else
 #define PGL_PROF_ARGS
 #define PGL_PROF_PASS
+#define PGL_PROF_DUMMY
 #endif
 typedef double pgl_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) double* pgl_k_cdp;
@@ -1454,6 +1456,23 @@ __device__ __forceinline__ void pgl_dma_half(const unsigned char* __restrict__ g
     }
 }
 
+// whole image of KT k-tiles by LDS-DMA over NWV waves (1 KiB pieces, piece c by wave c % NWV)
+template <int KT, int NWV>
+__device__ __forceinline__ void pgl_dma_img(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
+                                            const int wave, const int lane)
+{
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int NCH = pgl_img_bytes(KT) / 1024;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += NWV) {
+        const int c = c0 + wave;
+        if (c < NCH)
+            __builtin_amdgcn_global_load_lds((gvoid*)(gimg + (size_t)c * 1024 + lane * 16),
+                                             (lvoid*)(lds_dst + (size_t)c * 1024), 16, 0, 0);
+    }
+}
+
 // one round of an image DMA: round j moves the 1 KiB pieces 8j .. 8j+7, one per wave
 template <int KT>
 __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ gimg, unsigned char* lds_dst,
@@ -1854,12 +1873,14 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 //   a STEP covers MT consecutive tiles (MT = 2 when the images are small): the three workgroup barriers
 //   of the scheme (images landed | partial currents exchanged | residuals exchanged) are paid once per
 //   step; the images of step i+1 arrive by LDS-DMA in the other buffer while step i computes.
+// Workgroups of NW = 8 waves, or NW = 4 waves (two workgroups per CU: one group's barrier waits are
+// filled by the other's MFMAs) for post blocks of one or two tiles.
 // Same partial layout as k_fused2 (k_finalize / k_finalize_ll reduce it).
 // ---------------------------------------------------------------------------
-template <int KTW, int PTW, int MT>
-__global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
+template <int KTW, int PTW, int MT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 {
-    constexpr int TT = 16, NW = 8;
+    constexpr int TT = 16;
     constexpr int KSPLIT = NW / PTW;
     constexpr int KSW = KTW * 4;
     constexpr int KT_ALL = KTW * KSPLIT;
@@ -1915,7 +1936,7 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             if (tile0s + m < tile_end)
-                pgl_dma_half<KT_ALL>(fimg + (size_t)(tile0s + m) * IMG, dst + (size_t)m * IMG, wave, lane);
+                pgl_dma_img<KT_ALL, NW>(fimg + (size_t)(tile0s + m) * IMG, dst + (size_t)m * IMG, wave, lane);
     };
     if (tile_beg < tile_end) dma_step(tile_beg, bufs);
     // this wave's slice of Wmat stays in registers for the whole chunk (KSW <= 40 fragments: the forward
@@ -1933,22 +1954,32 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
         }
     }
 
+    // post-synaptic counts of the elements this wave owns in the epilogue, requested one step ahead (a
+    // short step -- two tiles of a 160-column row are 1 500 MFMA cycles -- is over before an HBM miss returns)
+    unsigned scn[MT * EPW];
+    auto load_counts = [&](const int tile0s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int e = 0; e < EPW; ++e) {
+                const long long tg = (long long)(tile0s + m) * TT + grp + 4 * er[e];
+                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+                scn[m * EPW + e] = p.S[tc * p.Nall + nglob];
+            }
+        }
+    };
+    load_counts(tile_beg);
     int par = 0;
     for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
         const unsigned char* cur = bufs + (size_t)par * MT * IMG;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces of the step landed
         __syncthreads();                                  // ... everybody's; the other buffer is free
-        if (tile + MT < tile_end) dma_step(tile + MT, bufs + (size_t)(par ^ 1) * MT * IMG);
-        // post-synaptic counts of the elements this wave owns in the epilogue
         double sc[MT * EPW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int e = 0; e < EPW; ++e) {
-                const long long tg = (long long)(tile + m) * TT + grp + 4 * er[e];
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                sc[m * EPW + e] = (double)p.S[tc * p.Nall + nglob];
-            }
+        for (int i = 0; i < MT * EPW; ++i) sc[i] = (double)scn[i];
+        if (tile + MT < tile_end) {
+            load_counts(tile + MT);
+            dma_step(tile + MT, bufs + (size_t)(par ^ 1) * MT * IMG);
         }
         // ---- forward over this wave's K slice, tile by tile ----
 #pragma unroll
@@ -2044,6 +2075,222 @@ __global__ __launch_bounds__(512, 2) void k_fused6(const FusedParams p)
             double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + (size_t)ksl * KTW) * 256 + lane;
 #pragma unroll
             for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused ll + grad kernel, version 7: one pass on resident feature tiles WITHOUT a K split, for short
+// feature rows (KT <= 20 k-tiles, i.e. the whole G of a post tile fits a wave's registers) and few post
+// tiles: a workgroup is NWV waves = NWV post tiles on the same 16-bin tile; every wave runs the whole
+// chain forward (all K) -> rate epilogue on its own accumulator registers (four elements per lane,
+// pgl_rate4) -> backward (all K) by itself.  No partial currents or residuals travel through LDS, so the
+// only workgroup barrier per tile is "the image has landed"; several small workgroups share a CU
+// (NWV = 4: two, NWV = 2: three), each on its own time chunk, and fill one another's waits.
+//   image of a tile = [16][RS] f64 as for k_fused6 (one part), double-buffered per workgroup.
+// Partials as k_fused5 (KSPLIT = 1).
+// ---------------------------------------------------------------------------
+template <int KT, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
+{
+    constexpr int TT = 16;
+    constexpr int KS = 4 * KT;
+    constexpr int RS = pgl_img_rsh(KT);
+    constexpr int IMG = pgl_img_bytes(KT);
+    constexpr bool WREG = (KS <= 40);            // the wave's Wmat fragments stay in registers
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef PGL_PROF
+    long long pgl_prof_dummy_acc[12] = {0};
+    long long pgl_prof_dummy_t = 0;
+#endif
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nPB = (p.nPT + NWV - 1) / NWV;
+    const int pb = blockIdx.x % nPB;
+    const int chunk = blockIdx.x / nPB;
+    const int pt = pb * NWV + wave;
+    const bool active = pt < p.nPT;
+
+    unsigned char* bufs = smem;                                           // [2][IMG]
+    double* Cs = reinterpret_cast<double*>(smem + (size_t)2 * IMG);       // [32] math constants
+    double* const wscratch = Cs + 32 + wave * 192;                        // spike compaction scratch
+    if (tid < 32) Cs[tid] = PGL_C[tid];
+
+    d4_t G[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double ll_acc = 0.0, gb_acc = 0.0;
+
+    const int col = lane & 15;
+    const int grp = lane >> 4;
+    const int nloc = pt * 16 + col;
+    const bool valid_n = active && (nloc < p.npost);
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
+    // padding lanes get a benign current: they must not push their wave out of the epilogue's series regime
+    const double bias_l = valid_n ? p.bias[nloc] : (p.nlin == 1 ? 30.0 : 0.0);
+    const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS * 64;
+
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
+    int tile_end = tile_beg + p.tilesPerChunk;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
+    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG;
+
+    double wreg[WREG ? KS : 1];
+    if (WREG) {
+        const pgl_d2* wr2 = reinterpret_cast<const pgl_d2*>(wrow);
+#pragma unroll
+        for (int s2 = 0; s2 < (WREG ? KS / 2 : 0); ++s2) {
+            const pgl_d2 v = wr2[s2 * 64 + lane];
+            wreg[2 * s2] = v.x;
+            wreg[2 * s2 + 1] = v.y;
+        }
+    }
+    unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
+    auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long tg = (long long)tile * TT + grp + 4 * r;
+            const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
+            dst[r] = p.S[tc * p.Nall + nglob];
+        }
+    };
+    if (tile_beg < tile_end) {
+        pgl_dma_img<KT, NWV>(fimg + (size_t)tile_beg * IMG, bufs, wave, lane);
+        load_counts(tile_beg, scn);
+    }
+
+    int par = 0;
+    for (int tile = tile_beg; tile < tile_end; ++tile, par ^= 1) {
+        const int t0 = tile * TT;
+        const unsigned char* cur = bufs + (size_t)par * IMG;
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces landed, counts are here
+        __syncthreads();                                  // ... every wave's; the other buffer is free
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scb[r] = scn[r];
+        if (tile + 1 < tile_end) {
+            load_counts(tile + 1, scn);
+            pgl_dma_img<KT, NWV>(fimg + (size_t)(tile + 1) * IMG, bufs + (size_t)(par ^ 1) * IMG, wave, lane);
+        }
+        if (!active) continue;
+        // ---- forward over all K ----
+        d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
+        d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+        {
+            const double* fa = reinterpret_cast<const double*>(cur) + col * RS + grp;
+            constexpr int PA = 4;
+            double ar[PA];
+#pragma unroll
+            for (int s = 0; s < PA; ++s) ar[s] = fa[4 * s];
+            if constexpr (WREG) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double a = ar[s % PA];
+                    if (s + PA < KS) ar[s % PA] = fa[4 * (s + PA)];
+                    if (s & 1)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                const double* wr_s = wrow;
+                asm volatile("" : "+s"(wr_s));
+                constexpr int PW2 = (KS / 2 < PGL_PW / 2) ? KS / 2 : PGL_PW / 2;
+                const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
+                pgl_d2 wr[PW2];
+#pragma unroll
+                for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double a = ar[s % PA];
+                    const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
+                    if (s + PA < KS) ar[s % PA] = fa[4 * (s + PA)];
+                    if ((s & 1) && (s / 2 + PW2 < KS / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
+                    if (s & 1)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                    else
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- epilogue on the accumulator registers ----
+        double rr[4];
+        {
+            bool done = false;
+            if ((long long)t0 + TT <= p.t_hi) {
+                double xs[4], term4 = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
+                const double* cg = PGL_C;
+                asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
+                done = pgl_rate4(xs, scb, p.nlin, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_DUMMY);
+                if (done) {
+                    ll_acc += valid_n ? term4 : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        rr[r] = valid_n ? rr[r] : 0.0;
+                        gb_acc += rr[r];
+                    }
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    double xe[2], se[2], terme[2], rese[2];
+                    bool vte[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * h2 + e;
+                        xe[e] = bias_l + (acc0[r] + acc1[r]);
+                        se[e] = (double)scb[r];
+                        const long long tg = (long long)t0 + grp + 4 * r;
+                        vte[e] = valid_n && (tg < p.t_hi);
+                    }
+                    pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                    asm volatile("" : "+v"(Cl));
+                    pgl_rate_terms_n<2>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double res = vte[e] ? rese[e] : 0.0;
+                        rr[2 * h2 + e] = res;
+                        ll_acc += vte[e] ? terme[e] : 0.0;
+                        gb_acc += res;
+                    }
+                }
+            }
+        }
+        // ---- backward over all K ----
+        if (p.want_grad) {
+            const double* fb = reinterpret_cast<const double*>(cur) + grp * RS + col;
+            constexpr int NS = 4 * KT;
+            constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
+            double ar[PD];
+#pragma unroll
+            for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KT)) * RS + 16 * (s % KT)];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const double a = ar[s % PD];
+                if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KT)) * RS + 16 * ((s + PD) % KT)];
+                G[s % KT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KT], G[s % KT], 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    if (active) {
+        const size_t slot = (size_t)chunk * p.nPT + pt;
+        p.llpart[slot * 64 + lane] = ll_acc;
+        p.gbpart[slot * 64 + lane] = gb_acc;
+        if (p.want_grad) {
+            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT) * 256 + lane;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
             }

@@ -35,9 +35,11 @@ print("| config | post neurons | nT | padded K | kernel | ll+grad total ms | fus
 print("|---|---|---|---|---|---|---|---|---|---|")
 run("C1 standard_glm", 4, 60.0, H.std_ibasis(), 'explinear')
 run("C2 standard_glm", 32, 300.0, H.std_ibasis(), 'explinear')
+run("C2 standard_glm (resident K-split)", 32, 300.0, H.std_ibasis(), 'explinear', kernel=6)
 run("C2 standard_glm (in-kernel features)", 32, 300.0, H.std_ibasis(), 'explinear', kernel=2)
 run("C3 standard_glm", 128, 600.0, H.std_ibasis(), 'explinear')
 run("C5 spatiotemporal (D_stim=3)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9)
+run("C5 (resident K-split)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9, kernel=6)
 run("C5 (in-kernel features)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9, kernel=2)
 for nh in (64, 32, 16):
     run("C3 neuron shard", 128, 600.0, H.std_ibasis(), 'explinear', n_hi=nh)

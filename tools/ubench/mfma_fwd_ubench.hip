@@ -7,13 +7,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) d2* g_cd2p;
 
-template <int NACC, int PW>
-__global__ __launch_bounds__(512, 2) void k(const double* W, double* out, int tiles, double seed)
+template <int NACC, int PW, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void k(const double* W, double* out, int tiles, double seed)
 {
     constexpr int KTH = 20, RSH = 322, KSH = 80, KS_ALL = 160;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* F = reinterpret_cast<double*>(smem);
-    for (int i = threadIdx.x; i < 2 * 16 * RSH; i += 512) F[i] = seed + 1e-9 * i;
+    for (int i = threadIdx.x; i < 2 * 16 * RSH; i += NWV * 64) F[i] = seed + 1e-9 * i;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, grp = lane >> 4;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512, 2) void k(const double* W, double* out, int ti
     out[blockIdx.x * 512 + threadIdx.x] = tot;
 }
 
-template <int NACC, int PW>
+template <int NACC, int PW, int NWV = 8>
 void run(const char* name, const double* W, double* d)
 {
     const int blocks = 256, tiles = 1000;
@@ -60,12 +60,12 @@ void run(const char* name, const double* W, double* d)
     const size_t lds = 2 * 16 * 322 * 8;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NACC, PW>), dim3(blocks), dim3(512), lds, 0, W, d, tiles, 1.0);
+        hipLaunchKernelGGL((k<NACC, PW, NWV>), dim3(blocks), dim3(NWV * 64), lds, 0, W, d, tiles, 1.0);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        const double fl = (double)blocks * 8 * tiles * 160 * 2048.0;
+        const double fl = (double)blocks * NWV * tiles * 160 * 2048.0;
         if (rep == 2) printf("%-40s %8.3f ms  %6.1f TFLOP/s\n", name, ms, fl / ms / 1e9);
     }
 }
@@ -80,5 +80,10 @@ int main()
     run<4, 8>("4 accumulators, W ring 8", W, d);
     run<2, 16>("2 accumulators, W ring 16", W, d);
     run<4, 16>("4 accumulators, W ring 16", W, d);
+    // one wave per SIMD: can a lone wave keep the f64 MFMA pipe full?
+    run<2, 8, 4>("4 waves/CU, 2 accumulators", W, d);
+    run<4, 8, 4>("4 waves/CU, 4 accumulators", W, d);
+    run<8, 8, 4>("4 waves/CU, 8 accumulators", W, d);
+    run<4, 16, 4>("4 waves/CU, 4 accumulators, ring 16", W, d);
     return 0;
 }
