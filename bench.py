@@ -432,11 +432,11 @@ def main():
         if alt is not None:
             out["roofline"]["alt_in_kernel_features"] = alt
         if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
-            tr = pmc_traffic(['void k_fused5<20, 1>', 'void k_fused5<20, 2>'])
+            tr = pmc_traffic(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
-            mb = pmc_mfma_busy(['void k_fused5<20, 1>', 'void k_fused5<20, 2>'])
+            mb = pmc_mfma_busy(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if mb is not None:
                 out["roofline"]["mfma_busy_pmc"] = mb
         if world == 1 and not args.no_map and not args.f32_features:

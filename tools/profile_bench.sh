@@ -5,6 +5,7 @@ set -u
 TAG=${1:-rXX}; shift || true
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+python3 -c "import __graft_entry__ as g; g.build_hip(); g.build_oracle()"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-map "$@" > $OUT/bench_trace.log 2>&1
