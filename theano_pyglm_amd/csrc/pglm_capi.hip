@@ -50,10 +50,19 @@ struct pgl_context {
                                          // when the basis support changes)
     int Rk = 0;                          // taps the kernels use: R minus trailing all-zero basis rows
     DevBuf theta, Weff, ll, grad, Wfrag, bias, Gpart, llpart, gbpart, Xbuf;
-    DevBuf fimg;                         // resident feature tiles (k_fused5)
+    // resident feature tiles (k_build_fimg): a few image sets side by side -- a masked MAP line search
+    // alternates between post-block widths whose kernels want different column paddings (e.g. k_fused6 with
+    // 10 or 12 k-tiles at C2), and rebuilding 0.4 GB of images per call would cost more than the call
+    struct ImgSlot {
+        DevBuf buf;
+        int key = 0, tile0 = 0, ntiles = 0;   // key = ktl << 8 | kth (kth = 0: one-part images); 0 = empty / stale
+        unsigned long long stamp = 0;
+    };
+    static constexpr int NIMG = 3;
+    ImgSlot imgs[NIMG];
+    int img_cur = 0;
+    unsigned long long img_clock = 0;
     double* pin_out = nullptr;           // pinned host buffer for small results (PGL_KMAX doubles)
-    int fimg_kth = 0;                    // widths (ktl << 8 | kth, k-tiles) the images were built for; 0 = stale
-    int fimg_tile0 = 0, fimg_ntiles = 0; // 16-bin tiles the images cover (the evaluated time range)
     DevBuf IimpT, Inet, Istim, tmpA, tmpB, tmpC, wsmall, part, outK, lam, wcol, thetan;
     // separable (rank-1) stimulus: theta rows are [bias, w_t(Bt), w_x(Bx), w_imp]; Dstim = Bt + Bx
     bool sep = false;
@@ -91,6 +100,31 @@ static void release(DevBuf& b)
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+static int find_img(const pgl_context* h, int key, int tile0, int ntiles)
+{
+    for (int i = 0; i < pgl_context::NIMG; ++i)
+        if (h->imgs[i].key == key && h->imgs[i].tile0 == tile0 && h->imgs[i].ntiles == ntiles && h->imgs[i].buf.p)
+            return i;
+    return -1;
+}
+static void invalidate_images(pgl_context* h)
+{
+    for (int i = 0; i < pgl_context::NIMG; ++i) h->imgs[i].key = 0;
+}
+// can a new image set of `want` bytes be placed (in a free slot, or over the least recently used one)?
+static bool img_room(const pgl_context* h, size_t want)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
+    size_t reclaim = 0;
+    int lru = 0;
+    for (int i = 1; i < pgl_context::NIMG; ++i)
+        if (h->imgs[i].stamp < h->imgs[lru].stamp) lru = i;
+    for (int i = 0; i < pgl_context::NIMG; ++i)
+        if (h->imgs[i].key == 0) reclaim = std::max(reclaim, h->imgs[i].buf.cap);
+    reclaim = std::max(reclaim, h->imgs[lru].buf.cap);
+    return want <= reclaim || want - reclaim <= free_b / 10 * 9;
 }
 #define ENSURE(buf, bytes)                       \
     do {                                         \
@@ -179,15 +213,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
     pl.ktl = pl.kth = 0;
     if (pl.version == 5 && !pick_pair(need, pl.ktl, pl.kth)) pl.version = 4;
-    if (pl.version == 5 && h->opt_kernel == 0 &&
-        !(h->fimg_kth == (pl.ktl << 8 | pl.kth) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
+    if (pl.version == 5 && h->opt_kernel == 0 && find_img(h, pl.ktl << 8 | pl.kth, pl.tile0, pl.nTiles) < 0) {
         // resident feature tiles need nTiles * (L + H image bytes) of HBM (3.1 GB at C3); in auto mode
         // fall back to on-the-fly generation (version 4) when the device cannot spare them
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t want = (size_t)pl.nTiles * img_pair_bytes(pl.ktl, pl.kth);
-            if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) pl.version = 4;
-        }
+        if (!img_room(h, (size_t)pl.nTiles * img_pair_bytes(pl.ktl, pl.kth))) pl.version = 4;
     }
     pl.RP = h->Rk + 32;
     if (pl.version == 3) {
@@ -269,14 +298,8 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             if (mt6 > 0) {
                 const int ktall = ktw6 * (nw6 / ptw6);
                 bool ok = true;
-                if (h->opt_kernel == 0 &&
-                    !(h->fimg_kth == (ktall << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
-                    size_t free_b = 0, total_b = 0;
-                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const size_t want = (size_t)pl.nTiles * pgl_img_bytes(ktall);
-                        if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) ok = false;
-                    }
-                }
+                if (h->opt_kernel == 0 && find_img(h, ktall << 8, pl.tile0, pl.nTiles) < 0)
+                    ok = img_room(h, (size_t)pl.nTiles * pgl_img_bytes(ktall));
                 if (ok) {
                     pl.version = 6;
                     pl.mt = mt6; pl.nw6 = nw6; pl.PTW = ptw6; pl.KTW = ktw6; pl.KSPLIT = nw6 / ptw6;
@@ -304,14 +327,8 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         const int nw7 = (pl.nPT >= 3) ? 4 : pl.nPT;
         const size_t lds7 = (size_t)2 * pgl_img_bytes(kt7) + 256 + (size_t)nw7 * 192 * 8;
         bool ok = kt7 > 0 && lds7 <= 160 * 1024;
-        if (ok && h->opt_kernel == 0 &&
-            !(h->fimg_kth == (kt7 << 8) && h->fimg_tile0 == pl.tile0 && h->fimg_ntiles == pl.nTiles)) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const size_t want = (size_t)pl.nTiles * pgl_img_bytes(kt7);
-                if (want > h->fimg.cap && want - h->fimg.cap > free_b / 10 * 9) ok = false;
-            }
-        }
+        if (ok && h->opt_kernel == 0 && find_img(h, kt7 << 8, pl.tile0, pl.nTiles) < 0)
+            ok = img_room(h, (size_t)pl.nTiles * pgl_img_bytes(kt7));
         if (ok) {
             pl.version = 7;
             pl.nw7 = nw7;
@@ -640,7 +657,7 @@ int pgl_destroy(pgl_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
-                      &h->gbpart, &h->Xbuf, &h->fimg, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
+                      &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
                       &h->spart};
@@ -751,7 +768,7 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     h->nnz = nnz;
     h->have_spikes = true;
     h->gibbs_npost = -1;
-    h->fimg_kth = 0;
+    invalidate_images(h);
     h->gx_xs = 0;
     return PGL_OK;
 }
@@ -803,7 +820,7 @@ int pgl_set_basis(pgl_handle h, const double* ibasis)
     }
     h->have_basis = true;
     h->gibbs_npost = -1;
-    h->fimg_kth = 0;
+    invalidate_images(h);
     h->gx_xs = 0;
     return PGL_OK;
 }
@@ -817,7 +834,7 @@ int pgl_set_stim_features(pgl_handle h, const double* fstim, int Dstim)
     h->Ktot = h->Kimp + Dstim;
     h->sep = false;
     h->gibbs_npost = -1;
-    h->fimg_kth = 0;
+    invalidate_images(h);
     h->gx_xs = 0;
     if (Dstim > 0) {
         const size_t bytes = (size_t)h->nT * Dstim * 8;
@@ -872,7 +889,7 @@ int pgl_set_stimulus(pgl_handle h, const double* stim, int64_t Tstim, int D, dou
     h->Ktot = h->Kimp + Dstim;
     h->sep = false;
     h->gibbs_npost = -1;
-    h->fimg_kth = 0;
+    invalidate_images(h);
     h->gx_xs = 0;
     return PGL_OK;
 }
@@ -925,7 +942,7 @@ int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, 
     h->Dstim = Bt + Bx;                       // layout of a theta row; NOT feature columns of the fused kernels
     h->Ktot = h->Kimp;
     h->gibbs_npost = -1;
-    h->fimg_kth = 0;
+    invalidate_images(h);
     h->gx_xs = 0;
     return PGL_OK;
 }
@@ -1075,8 +1092,8 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.t_hi = h->t_hi;
     fp.want_grad = want_grad ? 1 : 0;
     fp.dbg = h->opt_dbg;
-    fp.Fimg = (const unsigned char*)h->fimg.p;
-    fp.img_tile0 = h->fimg_tile0;
+    fp.Fimg = (const unsigned char*)h->imgs[h->img_cur].buf.p;
+    fp.img_tile0 = h->imgs[h->img_cur].tile0;
     fp.pidx = h->cur_pidx;
 }
 
@@ -1125,19 +1142,38 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
 static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles)
 {
     // kth == 0: one image per tile holding all ktl k-tiles (k_fused6); else the L / H pair of k_fused5
-    if (h->fimg_kth == (ktl << 8 | kth) && h->fimg_tile0 == tile0 && h->fimg_ntiles == ntiles && h->fimg.p)
+    const int key = ktl << 8 | kth;
+    int slot = find_img(h, key, tile0, ntiles);
+    if (slot >= 0) {
+        h->img_cur = slot;
+        h->imgs[slot].stamp = ++h->img_clock;
         return PGL_OK;
+    }
+    // an empty / stale slot first, else the least recently used one
+    slot = 0;
+    for (int i = 0; i < pgl_context::NIMG; ++i)
+        if (h->imgs[i].key == 0) { slot = i; break; }
+        else if (h->imgs[i].stamp < h->imgs[slot].stamp) slot = i;
+    pgl_context::ImgSlot& im = h->imgs[slot];
+    im.key = 0;
     const size_t bytes = (size_t)ntiles * (kth ? img_pair_bytes(ktl, kth) : (size_t)pgl_img_bytes(ktl));
-    ENSURE(h->fimg, bytes);
+    if (bytes > im.buf.cap) {
+        // make room before allocating: the other slots' stale buffers go first
+        for (int i = 0; i < pgl_context::NIMG; ++i)
+            if (i != slot && h->imgs[i].key == 0) release(h->imgs[i].buf);
+    }
+    ENSURE(im.buf, bytes);
     dim3 grid((unsigned)ntiles, kth ? 2 : 1);
     hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
-                       h->Rk, h->Dstim, ktl, kth, tile0, (unsigned char*)h->fimg.p);
+                       h->Rk, h->Dstim, ktl, kth, tile0, (unsigned char*)im.buf.p);
     HIPCHK(hipGetLastError());
-    h->fimg_kth = ktl << 8 | kth;
-    h->fimg_tile0 = tile0;
-    h->fimg_ntiles = ntiles;
+    im.key = key;
+    im.tile0 = tile0;
+    im.ntiles = ntiles;
+    im.stamp = ++h->img_clock;
+    h->img_cur = slot;
     return PGL_OK;
 }
 
