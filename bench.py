@@ -136,7 +136,12 @@ def map_wall_clock(S, N, dt):
             "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
             "bfgs_iterations": getattr(popn, 'last_fit_stats', {}).get('iterations'),
             "ll_grad_evaluations": getattr(popn, 'last_fit_stats', {}).get('evaluations'),
-            "optimizer": "lock-step batched BFGS, maxiter 225, GPU-resident state"}
+            "neuron_evaluations": getattr(popn, 'last_fit_stats', {}).get('neuron_evaluations'),
+            "neurons_converged_gtol": getattr(popn, 'last_fit_stats', {}).get('converged_gtol'),
+            "neurons_stalled": getattr(popn, 'last_fit_stats', {}).get('stalled'),
+            "neurons_at_maxiter": getattr(popn, 'last_fit_stats', {}).get('maxiter'),
+            "optimizer": "lock-step batched BFGS, maxiter 225, gtol 1e-5, GPU-resident state on one stream, "
+                         "finished neurons masked out of the launch"}
 
 
 def usable_cores():
