@@ -378,6 +378,12 @@ def test_c1_harness_end_to_end(tmp_path, capsys):
     assert np.allclose(lp_last, oracle_log_p(pop2, clean, x_last)[0], rtol=1e-9)
     # the chain stays in the neighbourhood of the MAP-initialised state (no collapse of the likelihood)
     assert lp_last > lps[0] - 0.01 * abs(lps[0])
+    # the network-only sweeps of harness/synth_mcmc.py (--network-only): reference-order column updates
+    from theano_pyglm_amd.harness.synth_mcmc import gibbs_network_sweeps
+    x_net = copy.deepcopy(x_last)
+    x_net, lps_net = gibbs_network_sweeps(pop2, x_net, N_samples=2, rng=np.random.RandomState(9))
+    assert len(lps_net) == 2 and np.all(np.isfinite(lps_net))
+    assert np.allclose(pop2.compute_log_p(x_net), oracle_log_p(pop2, clean, x_net)[0], rtol=1e-9)
     popn.release_data()
     pop2.release_data()
 
