@@ -2890,7 +2890,6 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
         __syncthreads();
         // ---- phase B: every (time split, weight, column) thread walks its bins ----
         const int nb = (int)((tb1 - ts < GTB) ? tb1 - ts : GTB);
-#pragma unroll 4
         for (int tt = worker ? ts_b : 0; tt < GTB; tt += TS) {
             const double x = fma(wk, IC[tt * CP + cb], X0[tt * CP + cb]);
             const double sv = SS[tt * CP + cb];
