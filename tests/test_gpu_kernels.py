@@ -438,3 +438,31 @@ def test_forced_kernels_on_tiny_shapes():
             ll2, _ = d.ll_grad(p.theta, p.Weff, want_grad=False)
             assert np.array_equal(ll, ll2)
             d.close()
+
+
+def test_batched_gibbs_columns_exp_nonlinearity_and_narrow_launches():
+    """pgl_gibbs_ll_cols with the exp nonlinearity (log lam = x), K = 1 ... 16 candidate weights, one
+    column per launch (the ARS probes) up to all columns, against the oracle and the one-pair path."""
+    N = 7
+    p = H.Problem(N, 2100, H.st_ibasis(), kind='exp', seed=71, weighted=True, w_scale=0.02, rate_hz=30.0)
+    d = p.device()
+    d.gibbs_prepare_all(p.theta, p.Weff)
+    A = (p.Weff != 0).astype(float)
+    for K in (1, 5, 16, 23):
+        for cols in (np.arange(N), np.array([4]), np.array([6, 1, 3])):
+            pre = (cols * 3 + 2) % N
+            ws = np.linspace(-1.5, 1.5, K)[None, :] * np.ones((len(cols), 1)) + 0.1 * cols[:, None]
+            got = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+            assert got.shape == (len(cols), K)
+            for i, c in enumerate(cols):
+                w = p.theta[c, 1:].reshape(N, p.B)
+                I_imp = O.impulse_currents(p.fS, w)
+                I_other = O.other_current(I_imp, A, p.Weff, pre[i], c)
+                ref = O.mcmc_inner_ll(ws[i], p.theta[c, 0], 0.0, I_other, I_imp[:, pre[i]], p.S[:, c].astype(float),
+                                      p.dt, p.kind)
+                assert np.allclose(got[i], ref, rtol=1e-10)
+    # the currents kept on the device equal the oracle's total current (without the bias)
+    xcur = d.gibbs_currents(2)
+    w = p.theta[2, 1:].reshape(N, p.B)
+    assert np.max(np.abs(xcur - O.impulse_currents(p.fS, w).dot(p.Weff[:, 2]))) < 1e-10
+    d.close()
