@@ -52,6 +52,10 @@ def _worker(rank, world, port, data0, out):
     x = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
     lp1, _ = parallel_compute_log_p(popn, x)
     rows, _, _ = _pack_state(popn, x)
+    # the time-sharded form: every rank evaluates all neurons on its own bins, all-reduce per evaluation
+    xt = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch', shard='time')
+    lpt = popn.compute_log_p(xt)                     # full recording again (the shard is lifted on return)
+    rows_t, _, _ = _pack_state(popn, xt)
     # sharded Gibbs on the sparse_weighted_model
     m2 = make_model('sparse_weighted_model', N=N, dt=0.001)
     stabilize_sparsity(m2)
@@ -62,7 +66,7 @@ def _worker(rank, world, port, data0, out):
     smpls = parallel_gibbs_sample(pop2, N_samples=2, x0=copy.deepcopy(y0), seed=5, verbose=False)
     y = smpls[-1]
     lpy, _ = parallel_compute_log_p(pop2, y)
-    out.put((rank, lp0, lp_n, lp1, rows, _pack_state(pop2, y), lpy, pop2.compute_log_p(y)))
+    out.put((rank, lp0, lp_n, lp1, rows, _pack_state(pop2, y), lpy, pop2.compute_log_p(y), lpt, rows_t))
     dist.destroy_process_group()
 
 
@@ -90,15 +94,19 @@ def test_world2_sharded_map_and_gibbs_on_one_gpu():
     x_ref = coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
     lp_ref = popn.compute_log_p(x_ref)
     rows_ref, _, _ = _pack_state(popn, x_ref)
-    for rank, lp0_r, lp_n, lp1, rows, ystate, lpy, lpy_single in res:
+    for rank, lp0_r, lp_n, lp1, rows, ystate, lpy, lpy_single, lpt, rows_t in res:
         assert np.isclose(lp0_r, lp0, rtol=1e-12)
         assert lp_n.shape == (N,)
         assert np.isclose(lp1, lp_ref, rtol=1e-9)
         # each rank ran its own 3-neuron batched BFGS: same optimum as the 6-neuron lock-step run
         assert np.allclose(rows, rows_ref, rtol=1e-4, atol=1e-5)
         assert np.isfinite(lpy) and np.isclose(lpy, lpy_single, rtol=1e-12)
+        # time-sharded MAP: the same 6-neuron lock-step run on all-reduced values
+        assert np.isclose(lpt, lp_ref, rtol=1e-9)
+        assert np.allclose(rows_t, rows_ref, rtol=1e-4, atol=1e-5)
     # both ranks hold the same state after the sharded sweeps (MAP rows, Gibbs rows, A and W columns)
     assert np.array_equal(res[0][4], res[1][4])
+    assert np.array_equal(res[0][9], res[1][9])           # identical optimizer trajectories on both ranks
     for a, b in zip(res[0][5], res[1][5]):
         assert np.array_equal(a, b)
     A = res[0][5][1]

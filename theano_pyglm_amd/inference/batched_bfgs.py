@@ -54,7 +54,8 @@ def _prior_terms(population, torch, X):
     return lp, G
 
 
-def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False):
+def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False,
+                           reduce=None):
     """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations).
 
     Everything runs on one dedicated torch stream: the device handles are switched to it
@@ -64,7 +65,11 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     already succeeded are masked out of the launch (pgl_ll_grad_list_dev evaluates an arbitrary
     list of neurons), so late, poorly conditioned neurons do not pay for the whole population.
     A neuron whose backtracking fails restarts once from steepest descent before it is frozen
-    (scipy's BFGS stops there with "precision loss", coord_descent.py:194-199)."""
+    (scipy's BFGS stops there with "precision loss", coord_descent.py:194-199).
+
+    `reduce`: optional callable applied in place to the packed device tensor [ll | grad] of every
+    evaluation before the priors are added -- the all-reduce of a time-sharded multi-GPU fit (every rank
+    evaluates its own bins of all neurons and runs the identical optimizer on the reduced values)."""
     import torch
     if not supported(population):
         raise Exception("batched GPU BFGS needs LinearBasisImpulses and No/Basis stimulus")
@@ -81,7 +86,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         h.set_stream(stream.cuda_stream)
     try:
         with torch.cuda.stream(stream):
-            out = _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose)
+            out = _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce)
             stream.synchronize()
     finally:
         for h in handles:
@@ -89,7 +94,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     return out
 
 
-def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose):
+def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce=None):
     X = torch.tensor(population.theta_matrix(x, n_lo, n_hi), dtype=torch.float64, device=dev)
     P = X.shape[1]
     Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
@@ -104,13 +109,15 @@ def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi
         lp, G = _prior_terms(population, torch, Xt)
         idx = None if rows is None or cnt == M else (rows + n_lo).to(torch.int32).contiguous()
         for h in handles:
-            ll = torch.empty(cnt, dtype=torch.float64, device=dev)
-            gr = torch.empty((cnt, P), dtype=torch.float64, device=dev)
+            buf = torch.empty(cnt * (1 + P), dtype=torch.float64, device=dev)     # [ll | grad]: one all-reduce
+            ll, gr = buf[:cnt], buf[cnt:].view(cnt, P)
             if idx is None:
                 h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(), gr.data_ptr(), n_lo, n_hi)
             else:
                 h.ll_grad_list_dev(idx.data_ptr(), cnt, Xt.data_ptr(), Weff.data_ptr(), ll.data_ptr(),
                                    gr.data_ptr())
+            if reduce is not None:
+                reduce(buf)
             lp = lp + ll
             G = G + gr
         n_evals[0] += 1

@@ -16,6 +16,13 @@ neurons and summing (:16-55).  Here rank r
     every rank from the replicated state (the reference does it on the master only, X5).
 
 Every rank returns the same state dict.
+
+`shard='time'` is the alternative split for populations whose per-rank neuron blocks would be narrow
+(at N = 128 on 8 GPUs a rank owns 16 neurons and the MFMA tiles run a third full): every
+rank evaluates ALL neurons on its own range of time bins (`Population.set_time_shard`; the likelihood
+is additive over time segments, population.py:41-43), one all-reduce of the packed (ll, grad) block per
+evaluation replaces the end-of-sweep gathers, and all ranks run the identical lock-step optimizer on
+the reduced values.
 """
 import numpy as np
 
@@ -33,11 +40,23 @@ def _device_of(population):
     return None if dist.get_backend() == 'gloo' else 'cuda:%d' % population.device
 
 
-def parallel_compute_log_p(population, x):
+def parallel_compute_log_p(population, x, shard='neurons'):
     """parallel_coord_descent.py:16-55: log p = latent + network prior + sum_n (glm prior_n + ll_n), the
-    per-neuron terms computed by the rank that owns the neuron and all-gathered (N doubles)."""
+    per-neuron terms computed by the rank that owns the neuron and all-gathered (N doubles); with
+    shard='time' every rank evaluates all neurons on its bins and the ll vector is all-reduced."""
     N = population.N
     world, rank = PL.world_rank()
+    if shard == 'time' and world > 1:
+        lp_n = np.zeros(N)
+        for data in population.data_sequences:
+            population.set_data(data)
+            lp_n += population.compute_ll_vector(x)
+        lp_n = PL.allreduce_sum(lp_n, _device_of(population))
+        for n in range(N):
+            population._check_vars(x, n)
+            lp_n[n] += population.glm.log_prior(x['glms'][n])
+        lp = population.latent.log_p(x.get('latent', {})) + population.network.log_p(x['net'])
+        return float(lp + np.sum(lp_n)), lp_n
     lo, hi = PL.shard_bounds(N, rank, world)
     lp_n = np.zeros(hi - lo)
     for i, n in enumerate(range(lo, hi)):
@@ -68,13 +87,46 @@ def gather_glms(population, x, lo, hi):
     return x
 
 
-def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched='torch', verbose=False):
+def _time_sharded_sweeps(population, x, maxiter, atol, verbose):
+    """shard='time': all ranks run the same lock-step BFGS; each evaluation = local bins + one all-reduce."""
+    import torch
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    world, rank = PL.world_rank()
+    population.set_time_shard(rank, world)
+    try:
+        lp_prev, _ = parallel_compute_log_p(population, x, shard='time')
+        net_inf_prms = cd.prep_first_order_network_inference(population)
+        converged, it = False, 0
+        while not converged and it < maxiter:
+            it += 1
+            fit_glms_batched_torch(population, x, reduce=PL.allreduce_sum_t)
+            cd.fit_network(x, net_inf_prms)
+            lp, _ = parallel_compute_log_p(population, x, shard='time')
+            if verbose and rank == 0:
+                print("Iteration %d: LP=%.2f. Change in LP: %.2f" % (it, lp, lp - lp_prev))
+            converged = np.abs(lp - lp_prev) < atol
+            lp_prev = lp
+    finally:
+        population.set_time_shard(None)
+    return x
+
+
+def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched='torch', verbose=False,
+                           shard='neurons'):
     """parallel_coord_descent.py:57-156.  Call on every rank of an initialised process group with the
-    same x0 (e.g. drawn from the same seed); without a process group this is coord_descent."""
+    same x0 (e.g. drawn from the same seed); without a process group this is coord_descent.
+    shard: 'neurons' (the reference's split) or 'time' (see the module docstring; needs batched='torch')."""
     N = population.N
     world, rank = PL.world_rank()
     if world == 1:
         return cd.coord_descent(population, x0=x0, maxiter=maxiter, atol=atol, batched=batched, verbose=verbose)
+    if shard == 'time':
+        if x0 is None:
+            raise ValueError("parallel_coord_descent needs the same x0 on every rank")
+        if batched != 'torch':
+            raise ValueError("shard='time' runs the lock-step GPU optimizer (batched='torch')")
+        initialize_with_data(population, population.data_sequences[-1], x0)
+        return _time_sharded_sweeps(population, x0, maxiter, atol, verbose)
     lo, hi = PL.shard_bounds(N, rank, world)
     if x0 is None:
         raise ValueError("parallel_coord_descent needs the same x0 on every rank")

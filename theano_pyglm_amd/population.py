@@ -38,6 +38,7 @@ class Population(object):
         self._handles = []        # (data dict, _lib.DeviceGlm) pairs: the pair keeps the dict alive, so a
                                   # recycled id() can never alias a stale handle; lookup is by identity
         self._current = None      # data dict conditioned on (set_data)
+        self._time_shard = None   # (rank, world): every handle evaluates only its share of the bins
 
     # -- variables ------------------------------------------------------------
     def get_variables(self):
@@ -113,8 +114,27 @@ class Population(object):
                     h.set_stim_features(data['fstim'])      # caller-supplied dense features
                 else:
                     self.glm.bkgd_model.upload(h, data)     # built on the device from data['stim']
+            if self._time_shard is not None:
+                self._apply_time_shard(h)
             self._handles.append((data, h))
         return h
+
+    def _apply_time_shard(self, h):
+        from theano_pyglm_amd.parallel import time_shard_bounds
+        if self._time_shard is None:
+            h.set_time_range(0, h.nT)
+        else:
+            rank, world = self._time_shard
+            h.set_time_range(*time_shard_bounds(h.nT, rank, world))
+
+    def set_time_shard(self, rank=None, world=None):
+        """Restrict every data sequence to the bins of time shard `rank` of `world` (boundaries on the
+        kernels' 16-bin tile grid; the likelihood is additive over time segments, population.py:41-43, so
+        the partial (ll, grad) of the shards all-reduce to the full evaluation).  None: the whole
+        recording.  Used by the time-sharded multi-GPU MAP (inference/parallel_coord_descent.py)."""
+        self._time_shard = None if rank is None or world in (None, 1) else (int(rank), int(world))
+        for _, h in self._handles:
+            self._apply_time_shard(h)
 
     def set_data(self, data):
         """population.py:223-231: condition on `data` (switches the device-resident handle)."""
