@@ -1208,7 +1208,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         const Plan& pl = plans[0];
         int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
-        if (pl.version >= 4 && d_grad) {                        // residual slab of the two-pass kernels
+        if ((pl.version == 4 || pl.version == 5) && d_grad) {   // residual slab of the two-pass kernels
             const size_t need = (size_t)pl.nTiles * pl.nPT * 256 * 8;
             const bool fresh = need > h->Xbuf.cap || !h->Xbuf.p;
             ENSURE(h->Xbuf, need);
@@ -1763,6 +1763,9 @@ int pgl_gibbs_update_cols(pgl_handle h, int ncols, const int* n_post, const int*
     const size_t lds = (size_t)h->B * h->Rk * 8;
     hipLaunchKernelGGL(k_gibbs_update_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp, (double*)h->GX.p);
     HIPCHK(hipGetLastError());
+    // the column arguments were staged in the handle's pinned block: the next call refills it, so the
+    // asynchronous upload must have happened before this one returns
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PGL_OK;
 }
 
