@@ -174,7 +174,11 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel (on the fly)
 // resident-tile kernel: (L, H) k-tile pairs; pass 1 (forward + L columns of G) gets the smaller share
-static const int kKTP[][2] = {{1, 1}, {2, 2}, {3, 3}, {5, 5}, {7, 7}, {9, 11}, {12, 14}, {14, 18}, {18, 22}};
+#ifndef PGL_SPLIT_L
+#define PGL_SPLIT_L 18       // L / H k-tiles of the 40-k-tile (K = 640) split; measured: 18/22
+#endif
+static const int kKTP[][2] = {{1, 1}, {2, 2}, {3, 3}, {5, 5}, {7, 7}, {9, 11}, {12, 14}, {14, 18},
+                              {PGL_SPLIT_L, 40 - PGL_SPLIT_L}};
 static bool pick_pair(int need, int& ktl, int& kth)
 {
     for (const auto& pr : kKTP)
@@ -487,7 +491,7 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
     case 9 << 8 | 11: return launch_fused5_t<9, 11>(pl, fp, s, pass);
     case 12 << 8 | 14: return launch_fused5_t<12, 14>(pl, fp, s, pass);
     case 14 << 8 | 18: return launch_fused5_t<14, 18>(pl, fp, s, pass);
-    case 18 << 8 | 22: return launch_fused5_t<18, 22>(pl, fp, s, pass);
+    case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L>(pl, fp, s, pass);
     }
     return hipErrorInvalidValue;
 }
