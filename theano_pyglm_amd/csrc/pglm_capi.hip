@@ -755,9 +755,13 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     h->h_ptr = cnt;
     h->h_ev.swap(ev);
     const std::vector<int2>& evr = h->h_ev;
-    ENSURE(h->S, (size_t)nT * N);
+    // S is padded with zero rows up to the 16-row tile grid: the fused kernels read the counts of whole
+    // tiles through incremented pointers, without clamping the row index
+    const size_t s_rows = (size_t)h->nT16 * 16;
+    ENSURE(h->S, s_rows * N);
     ENSURE(h->ST, (size_t)nT * N);
     ENSURE(h->spk, evr.size() * sizeof(int2));
+    HIPCHK(hipMemsetAsync((uint8_t*)h->S.p + (size_t)nT * N, 0, (s_rows - (size_t)nT) * N, h->stream));
     HIPCHK(hipMemcpyAsync(h->S.p, S, (size_t)nT * N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->spk.p, evr.data(), evr.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
     {

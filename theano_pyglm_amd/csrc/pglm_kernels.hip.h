@@ -1482,9 +1482,12 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
     typedef __attribute__((address_space(3))) void lvoid;
     constexpr int NCH = pgl_img_bytes(KT) / 1024;
     const int c = round * 8 + wave;
-    if (c < NCH)
-        __builtin_amdgcn_global_load_lds((gvoid*)(gimg + (size_t)c * 1024 + lane * 16),
-                                         (lvoid*)(lds_dst + (size_t)c * 1024), 16, 0, 0);
+    if (c < NCH) {
+        // wave-uniform piece address in SGPRs + the lane's 16 bytes: saddr form, no 64-bit VALU arithmetic
+        const unsigned char* gs = gimg + (size_t)c * 1024;
+        asm volatile("" : "+s"(gs));
+        __builtin_amdgcn_global_load_lds((gvoid*)(gs + lane * 16), (lvoid*)(lds_dst + (size_t)c * 1024), 16, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1639,15 +1642,16 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         // ahead -- issued at the head of a tile these byte loads (HBM misses) would sit in front of the
         // Wmat ring in the in-order vmcnt queue and delay every forward pass
         unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
-        auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
+        // S is zero-padded to whole tiles (upload_spikes): one pointer per lane, advanced by a tile per
+        // request; the four rows of a lane are 4 * Nall bytes apart
+        const uint8_t* cnt_ptr = p.S + ((size_t)tile_beg * TT + grp) * p.Nall + nglob;
+        const int cnt_r1 = 4 * p.Nall, cnt_tile = TT * p.Nall;
+        auto load_counts = [&](unsigned (&dst)[4]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long tg = (long long)tile * TT + grp + 4 * r;
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                dst[r] = p.S[tc * p.Nall + nglob];
-            }
+            for (int r = 0; r < 4; ++r) dst[r] = cnt_ptr[r * cnt_r1];
+            cnt_ptr += cnt_tile;
         };
-        if (tile_beg < tile_end) load_counts(tile_beg, scn);
+        if (tile_beg < tile_end) load_counts(scn);
         if (PGL_V2 && tid < 4) hdone[tid] = 0u;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
         __syncthreads();
@@ -1683,8 +1687,19 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     const int s = (q + KOFF) % KS_ALL;
                     return (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
                 };
+                // scalar bases of the Wmat fragment stream, one per 4 KB (four pairs of k-steps)
+                pgl_glb_cd2p wr_base[KS_ALL / 8 + 1];
 #pragma unroll
-                for (int q = 0; q < PW2; ++q) wr[q] = wr2[(((2 * q + KOFF) % KS_ALL) / 2) * 64 + lane];
+                for (int b4 = 0; b4 < KS_ALL / 8 + 1; ++b4) {
+                    const double* bs = wr_s + (size_t)b4 * 512;
+                    asm volatile("" : "+s"(bs));
+                    wr_base[b4] = (pgl_glb_cd2p)bs;
+                }
+#pragma unroll
+                for (int q = 0; q < PW2; ++q) {
+                    const int pair = (((2 * q + KOFF) % KS_ALL) / 2);
+                    wr[q] = wr_base[pair / 4][(pair % 4) * 64 + lane];
+                }
 #pragma unroll
                 for (int q = 0; q < PA; ++q) ar[q] = afrag(q);
                 if (PGL_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -1694,8 +1709,12 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     const double a = ar[q % PA];
                     const double b = (q & 1) ? wr[(q / 2) % PW2].y : wr[(q / 2) % PW2].x;
                     if (q + PA < KS_ALL) ar[q % PA] = afrag(q + PA);
-                    if ((q & 1) && (q / 2 + PW2 < KS_ALL / 2))
-                        wr[(q / 2) % PW2] = wr2[(((2 * (q / 2 + PW2) + KOFF) % KS_ALL) / 2) * 64 + lane];
+                    if ((q & 1) && (q / 2 + PW2 < KS_ALL / 2)) {
+                        // scalar base + lane offset + small immediate: the base moves on in SGPRs every four
+                        // fragment pairs (4 KB), no 64-bit VALU address arithmetic
+                        const int pair = ((2 * (q / 2 + PW2) + KOFF) % KS_ALL) / 2;      // compile-time (unrolled)
+                        wr[(q / 2) % PW2] = wr_base[pair / 4][(pair % 4) * 64 + lane];
+                    }
                     if (q & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
                     else
@@ -1778,7 +1797,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             PGL_PROF_MARK(1);
             if (PGL_V2 != 0 && PGL_EPRIO != 0) __builtin_amdgcn_s_setprio(0);
             if (PGL_EBAR && !PGL_V2) __syncthreads();     // both epilogues of a SIMD end before any backward MFMA
-            if (more) load_counts(tile + 1, scn);         // retired by the closing vmcnt(0) of this tile
+            if (more) load_counts(scn);                   // retired by the closing vmcnt(0) of this tile
             if (!do_bwd && more) {
                 if (PGL_V2 == 2) wait_ticket(2, h_target - NW);
                 pgl_dma_half<KTL>(fimg + (size_t)(tile + 1) * IMGS, Ln, wave, lane);
