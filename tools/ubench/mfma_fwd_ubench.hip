@@ -3,6 +3,7 @@
 // the same register rings; NACC independent accumulators.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) d2* g_cd2p;
@@ -13,7 +14,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void k(const double* W, double* out, i
     constexpr int KTH = 20, RSH = 322, KSH = 80, KS_ALL = 160;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* F = reinterpret_cast<double*>(smem);
-    for (int i = threadIdx.x; i < 2 * 16 * RSH; i += NWV * 64) F[i] = seed + 1e-9 * i;
+    for (int i = threadIdx.x; i < 2 * 16 * RSH; i += NWV * 64) {
+        // seed < 0: pseudo-random operands (bit patterns toggle like real features); else nearly constant
+        unsigned long long h = (unsigned long long)(i + 1) * 6364136223846793005ull + 1442695040888963407ull;
+        h ^= h >> 29;
+        F[i] = (seed < 0) ? (double)(h >> 11) * (1.0 / 9007199254740992.0) * 4.0 - 2.0 : seed + 1e-9 * i;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, grp = lane >> 4;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k(const double* W, double* out, i
 }
 
 template <int NACC, int PW, int NWV = 8>
-void run(const char* name, const double* W, double* d)
+void run(const char* name, const double* W, double* d, double seed = 1.0)
 {
     const int blocks = 256, tiles = 1000;
     hipEvent_t e0, e1;
@@ -60,7 +66,7 @@ void run(const char* name, const double* W, double* d)
     const size_t lds = 2 * 16 * 322 * 8;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NACC, PW, NWV>), dim3(blocks), dim3(NWV * 64), lds, 0, W, d, tiles, 1.0);
+        hipLaunchKernelGGL((k<NACC, PW, NWV>), dim3(blocks), dim3(NWV * 64), lds, 0, W, d, tiles, seed);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -77,6 +83,20 @@ int main()
     (void)hipMemset(W, 0, 8 * 160 * 64 * 8);
     (void)hipMalloc(&d, sizeof(double) * 256 * 512);
     run<2, 8>("2 accumulators, W ring 8", W, d);
+    {
+        // the same loop on random operands: the MFMA array's power draw depends on the data
+        std::vector<double> hw(8 * 160 * 64);
+        unsigned long long x = 88172645463325252ull;
+        for (auto& v : hw) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+        double* Wr;
+        (void)hipMalloc(&Wr, hw.size() * 8);
+        (void)hipMemcpy(Wr, hw.data(), hw.size() * 8, hipMemcpyHostToDevice);
+        run<2, 8>("2 acc, ring 8, RANDOM W, const F", Wr, d);
+        run<2, 8>("2 acc, ring 8, zero W, RANDOM F", W, d, -1.0);
+        run<2, 8>("2 acc, ring 8, RANDOM W and F", Wr, d, -1.0);
+        run<2, 8>("2 acc, ring 8, RANDOM W and F (again)", Wr, d, -1.0);
+        run<2, 8, 4>("4 waves/CU, RANDOM W and F", Wr, d, -1.0);
+    }
     run<4, 8>("4 accumulators, W ring 8", W, d);
     run<2, 16>("2 accumulators, W ring 16", W, d);
     run<4, 16>("4 accumulators, W ring 16", W, d);
