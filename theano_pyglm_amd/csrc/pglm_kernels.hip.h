@@ -38,6 +38,11 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifndef PGL_EBAR
 #define PGL_EBAR 1           // k_fused5: barrier between the epilogue and the backward loop
 #endif
+#ifndef PGL_DS1
+#define PGL_DS1 4            // k_fused5: cap on the MFMAs between two DMA rounds of a backward pass (0 = spread evenly over it).
+                             // 4: the requests leave in the first half of the pass and have the second half to land (A/B over
+                             // four interleaved runs each: 3.23-3.26 ms against 3.27-3.30 ms spread evenly, 2: 3.20-3.35)
+#endif
 #ifndef PGL_V2
 #define PGL_V2 0             // k_fused5 pass 1 (A/B variants, measured equal within noise: 3.28-3.37 ms): 1 = without the two mid-tile barriers: the H part of the forward pass
                              // runs first and an LDS ticket (not a barrier) tells the DMA when every wave is done
@@ -1587,7 +1592,9 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         constexpr int NS = 4 * KTG;
         constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
         constexpr int NRT = NR0 + NR1;
-        constexpr int DSTEP = (NS >= 2 * NRT) ? NS / NRT : 0;                   // MFMAs between rounds
+        constexpr int DSFULL = NS / NRT;
+        constexpr int DSCAP = (PGL_DS1 > 0) ? PGL_DS1 : NS;
+        constexpr int DSTEP = (NS >= 2 * NRT) ? ((DSFULL < DSCAP) ? DSFULL : DSCAP) : 0;   // MFMAs between rounds
         double ar[PD];
 #pragma unroll
         for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTG)) * RSG + 16 * (s % KTG)];
