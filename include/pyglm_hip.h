@@ -57,6 +57,11 @@ typedef struct pgl_context* pgl_handle;
                                 * post-synaptic neurons and the device can hold the tiles
                                 * (nT/16 * 2 * ~41 KB at K = 640: 3.1 GB for nT = 600 000) */
 
+#define PGL_OPT_GIBBS_KERNEL 4 /* pgl_gibbs_ll_cols with the explinear nonlinearity: 0 = auto (regime-split kernels: single
+                                * precision for the log1p(exp(-|x|)) term where |x| > 12, compacted f64 elsewhere,
+                                * spike terms from the event lists); 1 = the all-f64 one-thread-per-(column, weight)
+                                * kernel (always used for the exp nonlinearity) */
+
 const char* pgl_last_error(void);
 int pgl_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */

@@ -466,3 +466,69 @@ def test_batched_gibbs_columns_exp_nonlinearity_and_narrow_launches():
     w = p.theta[2, 1:].reshape(N, p.B)
     assert np.max(np.abs(xcur - O.impulse_currents(p.fS, w).dot(p.Weff[:, 2]))) < 1e-10
     d.close()
+
+
+@pytest.mark.gpu
+def test_batched_gibbs_regime_split_kernels_match_f64_kernel_and_oracle():
+    """explinear pgl_gibbs_ll_cols: the regime-split kernels (f32 log1p term where |x| > 12, compacted f64
+    band, spike terms from the event lists) against the all-f64 kernel (PGL_OPT_GIBBS_KERNEL = 1) and the
+    oracle, with currents that put bins into every regime: x >> 12, x << -12, the band |x| <= 12, and
+    x < -745 (lam underflows: NaN by glm.py:52).  Narrow (1-2 columns: time-split items), wide and ragged
+    launches; a recording that is not a multiple of the 256-bin block; a time sub-range."""
+    from theano_pyglm_amd import _lib
+    N = 11
+    p = H.Problem(N, 2100 + 77, H.std_ibasis(), kind='explinear', seed=93, weighted=True, w_scale=1.0,
+                  rate_hz=25.0, bias_mu=6.0)
+    p.theta[:4, 0] = [20.0, -3.0, 14.0, 0.5]
+    d = p.device()
+    A = (p.Weff != 0).astype(float)
+
+    def oracle(cols, pre, ws, t_lo=0, t_hi=None):
+        out = np.zeros((len(cols), ws.shape[1]))
+        for i, c in enumerate(cols):
+            w = p.theta[c, 1:].reshape(N, p.B)
+            I_imp = O.impulse_currents(p.fS, w)
+            I_other = O.other_current(I_imp, A, p.Weff, pre[i], c)
+            sl = slice(t_lo, t_hi)
+            out[i] = O.mcmc_inner_ll(ws[i], p.theta[c, 0], 0.0, I_other[sl], I_imp[sl, pre[i]],
+                                     p.S[sl, c].astype(float), p.dt, p.kind)
+        return out
+
+    d.gibbs_prepare_all(p.theta, p.Weff)
+    seen_nan = seen_finite = False
+    for K in (1, 11, 16):
+        for cols in (np.arange(N), np.array([2]), np.array([7, 0]), np.array([3, 9, 1]), np.arange(N)[::-1][:9]):
+            pre = (cols * 5 + 1) % N
+            # weights from tiny to huge: w*ic spans the band, the deep tails and the underflow
+            base = np.concatenate(([0.0], np.geomspace(0.01, 300.0, 15)))[:K]
+            ws = np.where(np.arange(K)[None, :] % 2 == 0, 1.0, -1.0) * base[None, :] * (1.0 + 0.05 * cols[:, None])
+            d.set_option(_lib.OPT_GIBBS_KERNEL, 1)
+            old = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+            d.set_option(_lib.OPT_GIBBS_KERNEL, 0)
+            new = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+            again = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+            assert np.array_equal(new, again, equal_nan=True)            # fixed summation order
+            # (the all-f64 kernel flushes lam in the last binade above the underflow, x in (-745.13, -744.4),
+            #  to 0 -> NaN; the regime-split kernel and the oracle keep the denormal: compare where both are finite)
+            both = np.isfinite(new) & np.isfinite(old)
+            assert both.sum() >= 0.8 * np.isfinite(old).sum()
+            assert np.allclose(new[both], old[both], rtol=1e-11, atol=0)
+            with np.errstate(all='ignore'):
+                ref = oracle(cols, pre, ws)
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(new), fin)
+            assert np.allclose(new[fin], ref[fin], rtol=1e-10, atol=0)
+            seen_nan |= bool((~fin).any())
+            seen_finite |= bool(fin.any())
+    assert seen_nan and seen_finite
+    # a time sub-range (partial last block, first block not at bin 0)
+    d.set_time_range(512, 1999)
+    d.gibbs_prepare_all(p.theta, p.Weff)
+    cols = np.array([0, 5, 10, 2])
+    pre = np.array([3, 5, 0, 2])
+    ws = np.linspace(-2.0, 2.0, 7)[None, :] * np.ones((4, 1))
+    new = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+    with np.errstate(all='ignore'):
+        ref = oracle(cols, pre, ws, 512, 1999)
+    assert np.allclose(new, ref, rtol=1e-10, atol=0, equal_nan=True)
+    d.close()

@@ -18,6 +18,7 @@ NLIN_EXPLINEAR = 1
 OPT_FEATURE_F32 = 1
 OPT_NCHUNKS = 2
 OPT_KERNEL = 3
+OPT_GIBBS_KERNEL = 4
 
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [

@@ -74,12 +74,12 @@ struct pgl_context {
     int gibbs_npost = -1;
     double gibbs_bias = 0;
     // batched column Gibbs (pgl_gibbs_prepare_all / _ll_cols / _update_cols)
-    DevBuf GX, gtheta, gargs, gpart, gout;
+    DevBuf GX, gtheta, gargs, gpart, gout, ghs;
     int gx_xs = 0;                       // row stride of GX (16 * post tiles); 0 = not prepared
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0;
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
 };
@@ -663,7 +663,7 @@ int pgl_destroy(pgl_handle h)
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
-                      &h->gargs, &h->gpart, &h->gout, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
+                      &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
                       &h->spart};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
@@ -697,6 +697,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
+    case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -1673,7 +1674,8 @@ int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff)
 
 // stage the column arguments in one pinned block, one H2D copy: [cols | pre | aw | w]
 static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_pre, const double* aw,
-                      const double* w, int nw, GibbsColsParams& gp, size_t extra_out_bytes)
+                      const double* w, int nw, GibbsColsParams& gp, size_t extra_out_bytes,
+                      bool with_events = false, int* max_events = nullptr)
 {
     if (h->gx_xs == 0) return fail(PGL_ERR_STATE, "pgl_gibbs_prepare_all has not been called");
     if (h->gx_t_lo != h->t_lo || h->gx_t_hi != h->t_hi)
@@ -1683,7 +1685,9 @@ static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         if (n_post[c] < 0 || n_post[c] >= h->N || n_pre[c] < 0 || n_pre[c] >= h->N)
             return fail(PGL_ERR_ARG, "neuron index out of range");
     const size_t o_pre = (size_t)ncols * 4, o_aw = ((o_pre + (size_t)ncols * 4 + 7) / 8) * 8;
-    const size_t o_w = o_aw + (size_t)ncols * 8, bytes = o_w + (size_t)ncols * nw * 8;
+    const size_t o_w = o_aw + (size_t)ncols * 8, o_elo = o_w + (size_t)ncols * nw * 8;
+    const size_t o_ehi = o_elo + (size_t)ncols * 4;
+    const size_t bytes = with_events ? ((o_ehi + (size_t)ncols * 4 + 7) / 8) * 8 : o_elo;
     const size_t need = std::max(bytes, extra_out_bytes);
     if (need > h->pin_args_cap) {
         if (h->pin_args) (void)hipHostFree(h->pin_args);
@@ -1697,6 +1701,22 @@ static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     std::memcpy(h->pin_args + o_pre, n_pre, (size_t)ncols * 4);
     for (int c = 0; c < ncols; ++c) reinterpret_cast<double*>(h->pin_args + o_aw)[c] = aw ? aw[c] : 0.0;
     std::memcpy(h->pin_args + o_w, w, (size_t)ncols * nw * 8);
+    if (with_events) {
+        // events of every listed post-synaptic neuron inside the evaluated time range
+        const int2* evb = h->h_ev.data();
+        const auto before = [](const int2& e, int64_t t) { return (int64_t)e.x < t; };
+        int mx = 0;
+        for (int c = 0; c < ncols; ++c) {
+            const int2* b = evb + h->h_ptr[n_post[c]];
+            const int2* e = evb + h->h_ptr[n_post[c] + 1];
+            const int lo = (int)(std::lower_bound(b, e, h->t_lo, before) - evb);
+            const int hi = (int)(std::lower_bound(b, e, h->t_hi, before) - evb);
+            reinterpret_cast<int*>(h->pin_args + o_elo)[c] = lo;
+            reinterpret_cast<int*>(h->pin_args + o_ehi)[c] = hi;
+            mx = std::max(mx, hi - lo);
+        }
+        if (max_events) *max_events = mx;
+    }
     HIPCHK(hipMemcpyAsync(h->gargs.p, h->pin_args, bytes, hipMemcpyHostToDevice, h->stream));
     const unsigned char* d = (const unsigned char*)h->gargs.p;
     gp.GX = (const double*)h->GX.p; gp.xs = h->gx_xs; gp.S = (const uint8_t*)h->S.p;
@@ -1709,6 +1729,13 @@ static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     gp.t_lo = h->t_lo; gp.t_hi = h->t_hi;
     gp.CP = std::max(1, std::min(ncols, 256 / std::max(1, nw)));   // columns per workgroup (ll) / per sweep (update)
     gp.part = nullptr;
+    gp.nsplit = 1;
+    gp.elo = with_events ? (const int*)(d + o_elo) : nullptr;
+    gp.ehi = with_events ? (const int*)(d + o_ehi) : nullptr;
+    gp.partS = nullptr;
+    gp.nloop = 1;
+    gp.hs = nullptr;
+    gp.dbg = 0;
     return PGL_OK;
 }
 
@@ -1720,6 +1747,48 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     if (K <= 0 || K > PGL_KMAX || !ll_out) return fail(PGL_ERR_ARG, "K must be in 1..16");
     HIPCHK(hipSetDevice(h->device));
     GibbsColsParams gp;
+    if (h->nlin == PGL_NLIN_EXPLINEAR && h->opt_gibbs != 1) {
+        // regime-split path: rate terms by k_gibbs_rate_cols (single precision for the log1p term where
+        // |x| > 12, compacted f64 elsewhere), spike terms from the event lists
+        int max_ev = 0;
+        rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8, true, &max_ev);
+        if (rc) return rc;
+        gp.CP = std::min(ncols, 8);
+        gp.nsplit = (gp.CP >= 3) ? 1 : (gp.CP == 2) ? 2 : 4;
+        const int ygroups = (ncols + gp.CP - 1) / gp.CP;
+        const long long nrows = h->t_hi - h->t_lo;
+        const long long nsub = (nrows + PGL_GRB - 1) / PGL_GRB;
+        gp.nloop = (int)std::max<long long>(1, std::min<long long>(PGL_GNL, nsub * ygroups / (8LL * h->numCU)));
+        const int nblk = (int)((nsub + gp.nloop - 1) / gp.nloop);
+        const int sblk = std::max(1, (max_ev + 255) / 256);
+        ENSURE(h->gpart, (size_t)(nblk + sblk) * ncols * PGL_KMAX * 8);
+        ENSURE(h->gout, (size_t)ncols * K * 8);
+        ENSURE(h->ghs, (size_t)ncols * h->Rk * 8);
+        gp.part = (double*)h->gpart.p;
+        gp.partS = gp.part + (size_t)nblk * ncols * PGL_KMAX;
+        gp.hs = (double*)h->ghs.p;
+        gp.dbg = h->opt_dbg;
+        const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
+                            (size_t)4 * K * PGL_GTS + (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
+                           (size_t)4 * PGL_GQ * 4 + (size_t)gp.CP * PGL_GECAP * 8 +
+                           (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gibbs_rate_cols),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
+        hipLaunchKernelGGL(k_gibbs_cols_setup, dim3((ncols * h->Rk + 255) / 256), dim3(256), 0, h->stream, gp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_gibbs_rate_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), (size_t)h->B * h->Rk * 8, h->stream, gp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_gibbs_reduce_cols2, dim3(ncols), dim3(64), 0, h->stream, (const double*)gp.part, nblk,
+                           (const double*)gp.partS, sblk, ncols, K, h->dt, (double*)h->gout.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->pin_args, h->gout.p, (size_t)ncols * K * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::memcpy(ll_out, h->pin_args, (size_t)ncols * K * 8);
+        return PGL_OK;
+    }
     rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8);
     if (rc) return rc;
     // enough blocks for a few per CU, at most 384 bins each (the block's presynaptic events -- window of

@@ -2806,6 +2806,14 @@ struct GibbsColsParams {
     int rows;                            // bins per block
     int gtb;                             // bins per sub-block (multiple of 32, gtb * CP >= 256)
     double* __restrict__ part;
+    // regime-split path (k_gibbs_rate_cols + k_gibbs_spike_cols)
+    int nsplit;                          // time splits of a block's bins over the waves (narrow launches)
+    const int* __restrict__ elo;         // [ncols] events of n_post inside [t_lo, t_hi): first ...
+    const int* __restrict__ ehi;         // ... and one past the last index into spk
+    double* __restrict__ partS;          // spike-term partials
+    int nloop;                           // sub-blocks of PGL_GRB bins per workgroup
+    double* __restrict__ hs;             // [ncols][R] impulse response of every listed pair (k_gibbs_cols_setup)
+    int dbg;                             // dev: 1 no event loop, 2 no phase B, 4 no event staging, 8 no GX loads
 };
 
 #define PGL_GECAP 24          // staged presynaptic events per column and block (k_gibbs_ll_cols)
@@ -2938,6 +2946,318 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
         }
     }
     if (b_valid && ts_b == 0) p.part[((size_t)blockIdx.x * p.ncols + ccb) * PGL_KMAX + kb] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Regime-split form of the batched inner ll (explinear only).  softplus(x) = max(x,0) + log1p(exp(-|x|)):
+//   * |x| > 12 (the operating regime: bias ~ 20, and the deeply inhibited bins behind a presynaptic spike
+//     for the negative quadrature nodes): the log1p term is < 6.2e-6 and only needs single precision --
+//     e = v_exp_f32(-|x| log2 e), log1p(e) = e (1 - e/2) (+O(e^3) < 8e-17); its absolute error
+//     (<= 1e-6 relative to itself: the f32 rounding of |x| <= 700 in the exponent) is <= 6e-12 of a bin
+//     whose rate is >= 12, or of a rate term < 6.2e-6 next to the spike terms.  ~10 instructions per
+//     evaluation instead of ~55 of the f64 exp + log1p.
+//   * |x| <= 12 ("band", ~13 % of the evaluations at C4), x < -700 (lam underflows: reference NaN
+//     semantics) and NaN: the f64 path, on COMPACTED lanes -- band elements are queued per wave in LDS
+//     with their weight index and evaluated 64 at a time.
+//   * S*log(lam) only exists at the spike bins of n_post (2 % of the bins): k_gibbs_spike_cols walks the
+//     event list of the post-synaptic neuron instead of testing every bin.
+// Lanes of a wave are 64 consecutive bins of one column; a wave keeps x0 / ic of its bins in registers
+// and loops over the K weights (wave-uniform scalar).  Lane partials go to a per-wave transposed LDS
+// accumulator T[k][lane] (own address per lane: no atomics, fixed order), reduced once per column.
+//   part[blk][c][k] = sum_t lam_k(t)   (k_gibbs_reduce_cols2 applies -dt and adds the spike terms)
+// ---------------------------------------------------------------------------
+#define PGL_GRB 256           // bins per sub-block
+#define PGL_GQ 320            // band-queue entries per wave: < 64 left over + 4 x 64 pushed before the queue is served
+#define PGL_GTS 66            // row stride of T (doubles)
+
+// h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
+__global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.ncols * p.R) return;
+    const int c = i / p.R, d = i - c * p.R;
+    const double* bt = p.theta + (size_t)p.cols[c] * p.P + p.woff + p.pre[c] * p.B;
+    double hh = 0.0;
+    for (int b = 0; b < p.B; ++b) hh = fma(p.phi[b * p.R + d], bt[b], hh);
+    p.hs[i] = hh;
+}
+
+#define PGL_GNL 8             // at most this many sub-blocks per workgroup
+
+__global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RB = PGL_GRB, XS = RB + 2, NJ = 8;
+    const int K = p.K, CP = p.CP, NSPLIT = p.nsplit, RPB = 256 / CP, R = p.R;
+    double* HS = reinterpret_cast<double*>(smem);                   // [CP][R] impulse response of the pair
+    double* X0 = HS + CP * R;                                       // [CP][XS] bias + I_stim + I_net of the sub-block
+    double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
+    double* T = Wl + CP * PGL_KMAX;                                 // [4][K][PGL_GTS]
+    double* Qx = T + 4 * K * PGL_GTS;                               // [4][PGL_GQ]
+    double* PS = Qx + 4 * PGL_GQ;                                   // [CP * NSPLIT][PGL_KMAX]
+    int* Qk = reinterpret_cast<int*>(PS + CP * NSPLIT * PGL_KMAX);  // [4][PGL_GQ]
+    int2* evS = reinterpret_cast<int2*>(Qk + 4 * PGL_GQ);           // [CP][PGL_GECAP]
+    int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP); // [CP][PGL_GNL] first event of the sub-block's window
+    int* WH = WL + CP * PGL_GNL;                                    // [CP][PGL_GNL] one past its last event
+    const int tid = threadIdx.x;
+    const long long tw0 = p.t_lo + (long long)blockIdx.x * RB * p.nloop;
+    // ---- once per workgroup: impulse responses, candidate weights, event windows of every sub-block ----
+    for (int i = tid; i < CP * R; i += 256) {
+        const int ci = i / R;
+        const int cc = blockIdx.y * CP + ci;
+        HS[i] = (cc < p.ncols) ? p.hs[(size_t)cc * R + (i - ci * R)] : 0.0;
+    }
+    for (int i = tid; i < CP * PGL_KMAX; i += 256) {
+        const int cc = blockIdx.y * CP + i / PGL_KMAX, k = i % PGL_KMAX;
+        Wl[i] = (cc < p.ncols && k < K) ? p.w[(size_t)cc * K + k] : 0.0;
+    }
+    for (int i = tid; i < CP * NSPLIT * PGL_KMAX; i += 256) PS[i] = 0.0;
+    for (int i = tid; i < CP * PGL_GNL; i += 256) {
+        const int ci = i / PGL_GNL, sb = i % PGL_GNL;
+        const int cc = blockIdx.y * CP + ci;
+        const long long tb0 = tw0 + (long long)sb * RB;
+        int lo = 0, hi = 0;
+        if (cc < p.ncols && sb < p.nloop && tb0 < p.t_hi) {
+            long long tb1 = tb0 + RB;
+            if (tb1 > p.t_hi) tb1 = p.t_hi;
+            const int npc = p.pre[cc];
+            lo = p.wlo[(size_t)(tb0 >> 4) * p.N + npc];
+            hi = p.whi[(size_t)((tb1 - 1) >> 4) * p.N + npc];
+        }
+        WL[i] = lo;
+        WH[i] = hi;
+    }
+    // staging role: column ca, bins ra + j*RPB (j < NJ): eight post neurons of one bin share a 64-byte line
+    const int ca = tid % CP, ra = tid / CP;
+    const int cca = blockIdx.y * CP + ca;
+    const bool a_valid = (ra < RPB) && (cca < p.ncols);
+    const int na = a_valid ? p.cols[cca] : 0;
+    const double biasa = a_valid ? p.theta[(size_t)na * p.P] : 0.0;
+    // evaluation role: a wave owns whole columns; its lanes are consecutive bins
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* const Tw = T + (size_t)wave * K * PGL_GTS;
+    double* const Qxw = Qx + wave * PGL_GQ;
+    int* const Qkw = Qk + wave * PGL_GQ;
+    const int nseg = RB / NSPLIT / 64;                              // 4, 2 or 1 segments of 64 bins per item
+    // f64 evaluation of n <= 64 queued elements [base, base + n)
+    auto pop = [&](const int base, const int n) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();
+        const bool v = lane < n;
+        const double xq = v ? Qxw[base + lane] : 20.0;
+        const int kq = v ? Qkw[base + lane] : 0;
+        const double lam = pgl_lambda_only(xq, 1, PGL_C);
+        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
+        const double val = (lam == 0.0) ? __builtin_nan("") : lam;
+        if (v) Tw[kq * PGL_GTS + lane] += val;
+        __builtin_amdgcn_wave_barrier();
+    };
+    __syncthreads();
+
+    for (int sb = 0; sb < p.nloop; ++sb) {
+        const long long tb0 = tw0 + (long long)sb * RB;
+        if (tb0 >= p.t_hi) break;
+        long long tb1 = tb0 + RB;
+        if (tb1 > p.t_hi) tb1 = p.t_hi;
+        const int nb = (int)(tb1 - tb0);
+        // ---- staging: the presynaptic events that can reach the sub-block (per column) and
+        //      X0 = bias + I_stim + I_net of its bins, [column][bin] ----
+        for (int i = tid; i < CP * PGL_GECAP; i += 256) {
+            const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
+            const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
+            if (cnt <= PGL_GECAP && j < cnt && !(p.dbg & 4)) evS[i] = p.spk[lo + j];
+        }
+        if (ra < RPB) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int tt = ra + j * RPB;
+                if (tt < RB)
+                    X0[ca * XS + tt] = (a_valid && tt < nb && !(p.dbg & 8)) ? biasa + p.GX[(tb0 + tt) * p.xs + na] : 0.0;
+            }
+        }
+        __syncthreads();
+        // ---- evaluation ----
+        for (int item = wave; item < CP * NSPLIT; item += 4) {
+            const int c = item / NSPLIT, sp = item % NSPLIT;
+            const int cc = blockIdx.y * CP + c;
+            if (cc >= p.ncols || (p.dbg & 2)) continue;
+            const int tseg = sp * nseg * 64 + lane;                 // bin of segment 0 inside the sub-block
+            // pair current of the lane's bins: every event of the column's window adds count * h[t - s - 1]
+            double icr[4] = {0.0, 0.0, 0.0, 0.0};
+            {
+                const int lo = WL[c * PGL_GNL + sb], cnt = WH[c * PGL_GNL + sb] - lo;
+                const bool staged = cnt <= PGL_GECAP;
+                const double* hs = HS + c * R;
+                const int tr = (int)tb0 + tseg - 1;                 // d = tr + 64*sg - e.x
+                if (!(p.dbg & 1)) {
+                    for (int q = 0; q < cnt; ++q) {
+                        const int2 e = staged ? evS[c * PGL_GECAP + q] : p.spk[lo + q];
+                        const double ecnt = (double)e.y;
+#pragma unroll
+                        for (int sg = 0; sg < 4; ++sg) {
+                            const int d = tr + 64 * sg - e.x;
+                            if ((unsigned)d < (unsigned)R) icr[sg] = fma(ecnt, hs[d], icr[sg]);
+                        }
+                    }
+                }
+            }
+            const double awc = p.aw[cc];
+            double x0r[4];
+            unsigned long long vm[4];
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const int tt = tseg + 64 * sg;
+                const bool v = (sg < nseg) && (tt < nb);
+                vm[sg] = __ballot(v);
+                x0r[sg] = X0[c * XS + (v ? tt : 0)] - awc * icr[sg];
+            }
+            int qn = 0;
+            double w_next = Wl[c * PGL_KMAX];
+            for (int k = 0; k < K; ++k) {
+                Tw[k * PGL_GTS + lane] = 0.0;
+                const double wk = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(w_next)),
+                                                   __builtin_amdgcn_readfirstlane(__double2loint(w_next)));
+                w_next = Wl[c * PGL_KMAX + ((k + 1 < K) ? k + 1 : k)];  // in flight during this iteration
+                // all four segments side by side: four independent chains
+                double x[4];
+                unsigned long long fm[4], bm[4];
+                float corr[4];
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const unsigned long long f = __ballot((fabs(x[sg]) > 12.0) && (x[sg] > -700.0));
+                    fm[sg] = f & vm[sg];
+                    bm[sg] = ~f & vm[sg];
+                }
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const float e = __builtin_amdgcn_exp2f((float)fabs(x[sg]) * -1.44269504088896340736f);
+                    corr[sg] = e * fmaf(e, -0.5f, 1.0f);
+                }
+                double accl = 0.0;
+                float accc = 0.0f;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const bool f = (fm[sg] >> lane) & 1ull;
+                    accc += f ? corr[sg] : 0.0f;
+                    accl += f ? fmax(x[sg], 0.0) : 0.0;
+                }
+                bool popped = false;
+                if ((bm[0] | bm[1] | bm[2] | bm[3]) != 0ull) {
+#pragma unroll
+                    for (int sg = 0; sg < 4; ++sg) {
+                        const unsigned long long m = bm[sg];
+                        if (m != 0ull) {
+                            const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if ((m >> lane) & 1ull) {
+                                Qxw[idx] = x[sg];
+                                Qkw[idx] = k;
+                            }
+                            qn += __popcll(m);
+                        }
+                    }
+                    while (qn >= 64) {                              // one call site: the f64 code exists once in the loop
+                        qn -= 64;
+                        pop(qn, 64);
+                        popped = true;
+                    }
+                }
+                const double tot = accl + (double)accc;
+                if (popped)
+                    Tw[k * PGL_GTS + lane] += tot;                  // a pop of this iteration may have added to row k
+                else
+                    Tw[k * PGL_GTS + lane] = tot;
+            }
+            if (qn > 0) pop(0, qn);
+            __builtin_amdgcn_wave_barrier();
+            // sum over the lanes: lane (k, q) adds T[k][16q .. 16q+15], the four quarters in fixed order
+            const int kf = lane >> 2, qf = lane & 3;
+            double sacc = 0.0;
+            if (kf < K) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc += Tw[kf * PGL_GTS + 16 * qf + j];
+            }
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            if (kf < K && qf == 0) PS[(c * NSPLIT + sp) * PGL_KMAX + kf] += sacc;   // slot owned by this wave
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                            // X0 / events are rewritten by the next sub-block
+    }
+    for (int i = tid; i < CP * PGL_KMAX; i += 256) {
+        const int c = i / PGL_KMAX, k = i % PGL_KMAX;
+        const int cc = blockIdx.y * CP + c;
+        if (cc < p.ncols && k < K) {
+            double a = 0.0;
+            for (int sp = 0; sp < NSPLIT; ++sp) a += PS[(c * NSPLIT + sp) * PGL_KMAX + k];
+            p.part[((size_t)blockIdx.x * p.ncols + cc) * PGL_KMAX + k] = a;
+        }
+    }
+}
+
+// spike terms of the listed columns: sum over the events (t, count) of n_post inside the evaluated range of
+// count * log(lam_k(t)); grid = (event chunks of 256, ncols), one event per thread, f64 throughout.
+__global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[4][PGL_KMAX];
+    double* phiS = reinterpret_cast<double*>(smem);
+    const int tid = threadIdx.x, c = blockIdx.y, K = p.K;
+    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
+    __syncthreads();
+    const int n = p.cols[c], np = p.pre[c];
+    const int i = p.elo[c] + blockIdx.x * 256 + tid;
+    double acc[PGL_KMAX];
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
+    if (i < p.ehi[c]) {
+        double beta[PGL_MAXB];
+#pragma unroll
+        for (int b = 0; b < PGL_MAXB; ++b)
+            beta[b] = (b < p.B) ? p.theta[(size_t)n * p.P + p.woff + np * p.B + b] : 0.0;
+        const int2 e = p.spk[i];
+        const long long t = e.x;
+        const int tile = (int)(t >> 4);
+        const double ic = pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + np], p.whi[(size_t)tile * p.N + np],
+                                           (int)t, p.R, p.B, phiS, beta);
+        const double x0 = (p.theta[(size_t)n * p.P] + p.GX[t * p.xs + n]) - p.aw[c] * ic;
+        const double sv = (double)e.y;
+#pragma unroll
+        for (int k = 0; k < PGL_KMAX; ++k) {
+            if (k < K) {
+                const double x = fma(p.w[(size_t)c * K + k], ic, x0);
+                acc[k] = sv * pgl_log(pgl_lambda_only(x, 1, PGL_C), PGL_C);
+            }
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < PGL_KMAX; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < K)
+        p.partS[((size_t)blockIdx.x * p.ncols + c) * PGL_KMAX + tid] =
+            red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// out[c][k] = -dt * sum_b part[b][c][k] + sum_b partS[b][c][k] (fixed order); grid = ncols, block = 64
+__global__ __launch_bounds__(64) void k_gibbs_reduce_cols2(const double* __restrict__ part, int nblk,
+                                                           const double* __restrict__ partS, int nblkS,
+                                                           int ncols, int K, double dt, double* __restrict__ out)
+{
+    const int c = blockIdx.x;
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0, q = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += 64) s += part[((size_t)b * ncols + c) * PGL_KMAX + k];
+        for (int b = threadIdx.x; b < nblkS; b += 64) q += partS[((size_t)b * ncols + c) * PGL_KMAX + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (threadIdx.x == 0) out[(size_t)c * K + k] = fma(-dt, s, q);
+    }
 }
 
 // out[c][k] = sum over the time blocks (fixed order); grid = ncols, block = 64
