@@ -116,8 +116,17 @@ def test_ars_weight_draw_matches_inverse_cdf(swm4):
     log_L = h.gibbs_ll(n_pre, aw, W_nns)
     ars = np.array([upd._adaptive_rejection_sample_w(lambda w: h.gibbs_ll(n_pre, aw, np.array([w]))[0],
                                                      mu_w, sigma_w, W_nns, log_L)
-                    for _ in range(400)])
-    assert upd.n_ars_evals < 400 * 12                   # a handful of extra abscissae per draw (sharp posterior)
+                    for _ in range(200)])
+    assert upd.n_ars_evals < 200 * 12                   # a handful of extra abscissae per draw (sharp posterior)
+    # with the batched refinement of the hull around the mode (14 weights per launch): fewer launches per draw
+    n0 = upd.n_ars_evals
+    ars2 = np.array([upd._adaptive_rejection_sample_w(lambda w: h.gibbs_ll(n_pre, aw, np.array([w]))[0],
+                                                      mu_w, sigma_w, W_nns, log_L,
+                                                      ll_of_ws=lambda wv: h.gibbs_ll(n_pre, aw, np.asarray(wv)))
+                     for _ in range(200)])
+    assert upd.n_ars_evals - n0 <= n0
+    ars = np.concatenate((ars, ars2))
+    assert stats.ks_2samp(ars[:200], ars2).pvalue > 1e-3
     grid = mu_w + sigma_w * np.linspace(-5.0, 5.0, 801)
     ll_grid = np.concatenate([h.gibbs_ll(n_pre, aw, grid[i:i + 16]) for i in range(0, 801, 16)])
     icdf = np.array([upd._inverse_cdf_sample_w(mu_w, sigma_w, grid, ll_grid) for _ in range(4000)])

@@ -1769,9 +1769,8 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.hs = (double*)h->ghs.p;
         gp.dbg = h->opt_dbg;
         const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
-                            (size_t)4 * K * PGL_GTS + (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
-                           (size_t)4 * PGL_GQ * 4 + (size_t)gp.CP * PGL_GECAP * 8 +
-                           (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
+                            (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
+                           (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gibbs_rate_cols),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));

@@ -2962,13 +2962,13 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 //   * S*log(lam) only exists at the spike bins of n_post (2 % of the bins): k_gibbs_spike_cols walks the
 //     event list of the post-synaptic neuron instead of testing every bin.
 // Lanes of a wave are 64 consecutive bins of one column; a wave keeps x0 / ic of its bins in registers
-// and loops over the K weights (wave-uniform scalar).  Lane partials go to a per-wave transposed LDS
-// accumulator T[k][lane] (own address per lane: no atomics, fixed order), reduced once per column.
+// and loops over the K weights (wave-uniform scalar); the band elements of one weight are queued in LDS
+// and served before the next weight, the lane partials of a (column, weight) pair are summed by DPP row
+// scans (fixed order, no atomics).  ~41 KB of LDS per workgroup: three workgroups per CU.
 //   part[blk][c][k] = sum_t lam_k(t)   (k_gibbs_reduce_cols2 applies -dt and adds the spike terms)
 // ---------------------------------------------------------------------------
 #define PGL_GRB 256           // bins per sub-block
-#define PGL_GQ 320            // band-queue entries per wave: < 64 left over + 4 x 64 pushed before the queue is served
-#define PGL_GTS 66            // row stride of T (doubles)
+#define PGL_GQ 256            // band-queue entries per wave (the band elements of one weight: <= 4 x 64)
 
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
 __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
@@ -2984,6 +2984,26 @@ __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams 
 
 #define PGL_GNL 8             // at most this many sub-blocks per workgroup
 
+// sum of v over the 64 lanes of a wave, valid in lane 63: row scans by DPP shifts (zero fill), then the row
+// totals travel with row_bcast15 / row_bcast31 -- fixed order, no LDS
+__device__ __forceinline__ double pgl_wave_sum_to_last(double v)
+{
+#define PGL_DPP_ADD(CTRL, ROWMASK)                                                                            \
+    {                                                                                                         \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);           \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);           \
+        v += __hiloint2double(hi, lo);                                                                        \
+    }
+    PGL_DPP_ADD(0x111, 0xf)      // row_shr:1
+    PGL_DPP_ADD(0x112, 0xf)      // row_shr:2
+    PGL_DPP_ADD(0x114, 0xf)      // row_shr:4
+    PGL_DPP_ADD(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds the row total
+    PGL_DPP_ADD(0x142, 0xa)      // row_bcast15 -> rows 1 and 3 add the total of the row before
+    PGL_DPP_ADD(0x143, 0xc)      // row_bcast31 -> rows 2 and 3 add the total of rows 0-1
+#undef PGL_DPP_ADD
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2992,11 +3012,9 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
     double* HS = reinterpret_cast<double*>(smem);                   // [CP][R] impulse response of the pair
     double* X0 = HS + CP * R;                                       // [CP][XS] bias + I_stim + I_net of the sub-block
     double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
-    double* T = Wl + CP * PGL_KMAX;                                 // [4][K][PGL_GTS]
-    double* Qx = T + 4 * K * PGL_GTS;                               // [4][PGL_GQ]
+    double* Qx = Wl + CP * PGL_KMAX;                                // [4][PGL_GQ]
     double* PS = Qx + 4 * PGL_GQ;                                   // [CP * NSPLIT][PGL_KMAX]
-    int* Qk = reinterpret_cast<int*>(PS + CP * NSPLIT * PGL_KMAX);  // [4][PGL_GQ]
-    int2* evS = reinterpret_cast<int2*>(Qk + 4 * PGL_GQ);           // [CP][PGL_GECAP]
+    int2* evS = reinterpret_cast<int2*>(PS + CP * NSPLIT * PGL_KMAX);   // [CP][PGL_GECAP]
     int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP); // [CP][PGL_GNL] first event of the sub-block's window
     int* WH = WL + CP * PGL_GNL;                                    // [CP][PGL_GNL] one past its last event
     const int tid = threadIdx.x;
@@ -3035,22 +3053,8 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
     const double biasa = a_valid ? p.theta[(size_t)na * p.P] : 0.0;
     // evaluation role: a wave owns whole columns; its lanes are consecutive bins
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double* const Tw = T + (size_t)wave * K * PGL_GTS;
     double* const Qxw = Qx + wave * PGL_GQ;
-    int* const Qkw = Qk + wave * PGL_GQ;
     const int nseg = RB / NSPLIT / 64;                              // 4, 2 or 1 segments of 64 bins per item
-    // f64 evaluation of n <= 64 queued elements [base, base + n)
-    auto pop = [&](const int base, const int n) __attribute__((always_inline)) {
-        __builtin_amdgcn_wave_barrier();
-        const bool v = lane < n;
-        const double xq = v ? Qxw[base + lane] : 20.0;
-        const int kq = v ? Qkw[base + lane] : 0;
-        const double lam = pgl_lambda_only(xq, 1, PGL_C);
-        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
-        const double val = (lam == 0.0) ? __builtin_nan("") : lam;
-        if (v) Tw[kq * PGL_GTS + lane] += val;
-        __builtin_amdgcn_wave_barrier();
-    };
     __syncthreads();
 
     for (int sb = 0; sb < p.nloop; ++sb) {
@@ -3110,10 +3114,9 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                 vm[sg] = __ballot(v);
                 x0r[sg] = X0[c * XS + (v ? tt : 0)] - awc * icr[sg];
             }
-            int qn = 0;
+            double colsum = 0.0;                                    // lane k: sum over the bins of lam_k
             double w_next = Wl[c * PGL_KMAX];
             for (int k = 0; k < K; ++k) {
-                Tw[k * PGL_GTS + lane] = 0.0;
                 const double wk = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(w_next)),
                                                    __builtin_amdgcn_readfirstlane(__double2loint(w_next)));
                 w_next = Wl[c * PGL_KMAX + ((k + 1 < K) ? k + 1 : k)];  // in flight during this iteration
@@ -3142,46 +3145,37 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                     accc += f ? corr[sg] : 0.0f;
                     accl += f ? fmax(x[sg], 0.0) : 0.0;
                 }
-                bool popped = false;
+                // band elements of this weight: queued per wave, evaluated in f64 on full waves
                 if ((bm[0] | bm[1] | bm[2] | bm[3]) != 0ull) {
+                    int qn = 0;
+                    double accq = 0.0;
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg) {
                         const unsigned long long m = bm[sg];
                         if (m != 0ull) {
                             const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            if ((m >> lane) & 1ull) {
-                                Qxw[idx] = x[sg];
-                                Qkw[idx] = k;
-                            }
+                            if ((m >> lane) & 1ull) Qxw[idx] = x[sg];
                             qn += __popcll(m);
                         }
                     }
-                    while (qn >= 64) {                              // one call site: the f64 code exists once in the loop
-                        qn -= 64;
-                        pop(qn, 64);
-                        popped = true;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < qn; base += 64) {     // one call site: the f64 code exists once
+                        const bool v = base + lane < qn;
+                        const double xq = v ? Qxw[base + lane] : 20.0;
+                        const double lam = pgl_lambda_only(xq, 1, PGL_C);
+                        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
+                        accq += v ? ((lam == 0.0) ? __builtin_nan("") : lam) : 0.0;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    accl += accq;
                 }
-                const double tot = accl + (double)accc;
-                if (popped)
-                    Tw[k * PGL_GTS + lane] += tot;                  // a pop of this iteration may have added to row k
-                else
-                    Tw[k * PGL_GTS + lane] = tot;
+                const double tot = pgl_wave_sum_to_last(accl + (double)accc);
+                const double totb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 63),
+                                                     __builtin_amdgcn_readlane(__double2loint(tot), 63));
+                colsum = (lane == k) ? totb : colsum;
             }
-            if (qn > 0) pop(0, qn);
-            __builtin_amdgcn_wave_barrier();
-            // sum over the lanes: lane (k, q) adds T[k][16q .. 16q+15], the four quarters in fixed order
-            const int kf = lane >> 2, qf = lane & 3;
-            double sacc = 0.0;
-            if (kf < K) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) sacc += Tw[kf * PGL_GTS + 16 * qf + j];
-            }
-            sacc += __shfl_xor(sacc, 1, 64);
-            sacc += __shfl_xor(sacc, 2, 64);
-            if (kf < K && qf == 0) PS[(c * NSPLIT + sp) * PGL_KMAX + kf] += sacc;   // slot owned by this wave
-            __builtin_amdgcn_wave_barrier();
+            if (lane < K) PS[(c * NSPLIT + sp) * PGL_KMAX + lane] += colsum;   // slots owned by this wave
         }
         __syncthreads();                                            // X0 / events are rewritten by the next sub-block
     }

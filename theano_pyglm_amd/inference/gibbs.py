@@ -318,13 +318,23 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         F = F / F[-1]
         return float(np.interp(self.rng.random_sample(), F, ws))
 
-    def _adaptive_rejection_sample_w(self, ll_of_w, mu_w, sigma_w, ws, log_L):
+    def _adaptive_rejection_sample_w(self, ll_of_w, mu_w, sigma_w, ws, log_L, ll_of_ws=None):
         """gibbs.py:1087-1126: ARS on log N(w; mu_w, sigma_w) + ll(w), started from the quadrature
         nodes with finite, moderate values; the density is shifted by its maximum over the nodes.
-        ll_of_w(w) is one more device inner-ll evaluation of the pair."""
+        ll_of_w(w) is one more device inner-ll evaluation of the pair.
+
+        ll_of_ws (optional, vector of <= 14 weights -> vector of ll): with T ~ 10^5 bins the posterior
+        of a weight is far narrower than the spacing of the quadrature nodes, and an ARS started from
+        them spends ~9 evaluations = device launches per draw on rejections near the mode.  A launch of
+        14 candidate weights costs what a launch of one does, so the hull is first refined around its
+        maximum -- 14 abscissae between the neighbours of the best node, repeated while the density
+        still drops by more than e^3 to a neighbour -- and the rejection loop starts from a tight hull.
+        Any set of abscissae gives an exact sampler (the reference's own ARS lives in the un-vendored
+        hips package: its abscissa sequence is not pinned)."""
         log_post = -0.5 / sigma_w ** 2 * (ws - mu_w) ** 2 + log_L
         Z = np.amax(log_post[np.isfinite(log_post)])
         valid = np.isfinite(log_post) & (log_post > -1e8) & (log_post < 1e8)
+        xs, vs = np.asarray(ws, dtype=float)[valid], (log_post - Z)[valid]
 
         def f(w):
             self.n_ars_evals += 1
@@ -332,7 +342,27 @@ class CollapsedGibbsNetworkColumnUpdate(object):
             v = -0.5 / sigma_w ** 2 * (w - mu_w) ** 2 + ll - Z
             return v if np.isfinite(v) else -np.inf
 
-        return float(adaptive_rejection_sample(f, ws[valid], log_post[valid] - Z, (-np.inf, np.inf),
+        if ll_of_ws is not None and len(xs) >= 2:
+            order = np.argsort(xs)
+            xs, vs = xs[order], vs[order]
+            for _ in range(4):
+                i = int(np.argmax(vs))
+                lo = xs[i - 1] if i > 0 else xs[i] - (xs[i + 1] - xs[i])
+                hi = xs[i + 1] if i + 1 < len(xs) else xs[i] + (xs[i] - xs[i - 1])
+                v_lo = vs[i - 1] if i > 0 else -np.inf
+                v_hi = vs[i + 1] if i + 1 < len(xs) else -np.inf
+                if vs[i] - min(v_lo, v_hi) < 3.0 or not hi - lo > 1e-9 * max(1.0, abs(xs[i])):
+                    break
+                cand = np.linspace(lo, hi, 16)[1:-1]
+                cand = cand[np.abs(cand - xs[i]) > 1e-12 * max(1.0, abs(xs[i]))]
+                self.n_ars_evals += 1                                       # one launch
+                vc = -0.5 / sigma_w ** 2 * (cand - mu_w) ** 2 + np.asarray(ll_of_ws(cand), dtype=float) - Z
+                ok = np.isfinite(vc)
+                xs = np.concatenate((xs, cand[ok]))
+                vs = np.concatenate((vs, vc[ok]))
+                order = np.argsort(xs)
+                xs, vs = xs[order], vs[order]
+        return float(adaptive_rejection_sample(f, xs, vs, (-np.inf, np.inf),
                                                stepsz=sigma_w / 2.0, rng=self.rng))
 
     def update_all(self, x, cols=None):
@@ -394,7 +424,8 @@ class CollapsedGibbsNetworkColumnUpdate(object):
                 if self.w_sampler == 'ars':
                     w_new[i] = self._adaptive_rejection_sample_w(
                         lambda w: float(h.gibbs_ll_cols(c1, p1, aw1, np.array([[w]]))[0, 0]),
-                        mu[i], sg[i], W_nns[i], log_L[i])
+                        mu[i], sg[i], W_nns[i], log_L[i],
+                        ll_of_ws=lambda wv: h.gibbs_ll_cols(c1, p1, aw1, np.asarray(wv)[None, :])[0])
                 else:
                     grid = mu[i] + sg[i] * np.linspace(-4.0, 4.0, self.n_grid)
                     w_new[i] = self._inverse_cdf_sample_w(mu[i], sg[i], grid,
@@ -457,7 +488,8 @@ class CollapsedGibbsNetworkColumnUpdate(object):
             a_new = 0 if rnd() * (p0 + np.exp(log_pr_A - m2)) < p0 else 1
             if a_new == 1 and self.w_sampler == 'ars':
                 w_new = self._adaptive_rejection_sample_w(
-                    lambda w: h.gibbs_ll(n_pre, aw_cur, np.array([w]))[0], mu_w, sigma_w, W_nns, log_L)
+                    lambda w: h.gibbs_ll(n_pre, aw_cur, np.array([w]))[0], mu_w, sigma_w, W_nns, log_L,
+                    ll_of_ws=lambda wv: h.gibbs_ll(n_pre, aw_cur, np.asarray(wv)))
             elif a_new == 1:
                 grid = mu_w + sigma_w * np.linspace(-4.0, 4.0, self.n_grid)
                 w_new = self._inverse_cdf_sample_w(mu_w, sigma_w, grid,

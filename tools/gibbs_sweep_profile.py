@@ -43,7 +43,32 @@ for _ in range(20): h.gibbs_update_cols(cols[:3], pre[:3], np.array([0.1, -0.1, 
 h.sync(); t_upd = (time.time() - t0) / 20
 print("theta_matrix %.1f ms | prepare_all first %.1f ms, again %.1f ms | ll_cols(%d cols x 11) %.3f ms | "
       "ll_cols(1 col x 1) %.3f ms | update_cols(3) %.3f ms" % (t_theta * 1e3, t_prep * 1e3, t_prep2 * 1e3, N, t_ll * 1e3, t_one * 1e3, t_upd * 1e3))
+acc = {'wide': 0.0, 'narrow': 0.0, 'update': 0.0, 'n_narrow': 0}
+_ll, _up = h.gibbs_ll_cols, h.gibbs_update_cols
+
+
+def ll_timed(c, p_, a, w):
+    t = time.perf_counter()
+    r = _ll(c, p_, a, w)
+    k = 'wide' if len(c) > 4 else 'narrow'
+    acc[k] += time.perf_counter() - t
+    acc['n_narrow'] += k == 'narrow'
+    return r
+
+
+def up_timed(*a):
+    t = time.perf_counter()
+    r = _up(*a)
+    acc['update'] += time.perf_counter() - t
+    return r
+
+
+h.gibbs_ll_cols, h.gibbs_update_cols = ll_timed, up_timed
 for rep in range(2):
     upd.n_ars_evals = 0
+    for k in acc: acc[k] = 0
     t0 = time.time(); upd.update_all(x); t_sw = time.time() - t0
-    print("sweep %d: %.3f s, ARS evals %d, edges %d" % (rep, t_sw, upd.n_ars_evals, int(np.asarray(x['net']['graph']['A']).sum())))
+    print("sweep %d: %.3f s (wide launches %.3f s, %d narrow launches %.3f s, current updates %.3f s, host rest %.3f s), "
+          "ARS evals %d, edges %d" % (rep, t_sw, acc['wide'], acc['n_narrow'], acc['narrow'], acc['update'],
+                                      t_sw - acc['wide'] - acc['narrow'] - acc['update'], upd.n_ars_evals,
+                                      int(np.asarray(x['net']['graph']['A']).sum())))
