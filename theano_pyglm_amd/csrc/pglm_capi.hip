@@ -1778,12 +1778,13 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_gibbs_rate_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), (size_t)h->B * h->Rk * 8, h->stream, gp);
+        hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_gibbs_reduce_cols2, dim3(ncols), dim3(64), 0, h->stream, (const double*)gp.part, nblk,
-                           (const double*)gp.partS, sblk, ncols, K, h->dt, (double*)h->gout.p);
+        hipLaunchKernelGGL(k_gibbs_reduce_cols2, dim3(ncols, K), dim3(64), 0, h->stream, (const double*)gp.part, nblk,
+                           (const double*)gp.partS, sblk, ncols, K, h->dt, (double*)h->pin_args);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h->pin_args, h->gout.p, (size_t)ncols * K * 8, hipMemcpyDeviceToHost, h->stream));
+        // the results land in the pinned host block directly (its argument bytes were consumed by the upload
+        // that precedes the kernels on the stream): no device-to-host copy call
         HIPCHK(hipStreamSynchronize(h->stream));
         std::memcpy(ll_out, h->pin_args, (size_t)ncols * K * 8);
         return PGL_OK;

@@ -2956,8 +2956,8 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 //     (<= 1e-6 relative to itself: the f32 rounding of |x| <= 700 in the exponent) is <= 6e-12 of a bin
 //     whose rate is >= 12, or of a rate term < 6.2e-6 next to the spike terms.  ~10 instructions per
 //     evaluation instead of ~55 of the f64 exp + log1p.
-//   * |x| <= 12 ("band", ~13 % of the evaluations at C4), x < -700 (lam underflows: reference NaN
-//     semantics) and NaN: the f64 path, on COMPACTED lanes -- band elements are queued per wave in LDS
+//   * |x| < 12 ("band", ~13 % of the evaluations at C4), |x| >= 700 (lam underflows: reference NaN
+//     semantics), inf and NaN: the f64 path, on COMPACTED lanes -- band elements are queued per wave in LDS
 //     with their weight index and evaluated 64 at a time.
 //   * S*log(lam) only exists at the spike bins of n_post (2 % of the bins): k_gibbs_spike_cols walks the
 //     event list of the post-synaptic neuron instead of testing every bin.
@@ -3106,13 +3106,12 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
             }
             const double awc = p.aw[cc];
             double x0r[4];
-            unsigned long long vm[4];
+            bool vl[4];
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
                 const int tt = tseg + 64 * sg;
-                const bool v = (sg < nseg) && (tt < nb);
-                vm[sg] = __ballot(v);
-                x0r[sg] = X0[c * XS + (v ? tt : 0)] - awc * icr[sg];
+                vl[sg] = (sg < nseg) && (tt < nb);
+                x0r[sg] = X0[c * XS + (vl[sg] ? tt : 0)] - awc * icr[sg];
             }
             double colsum = 0.0;                                    // lane k: sum over the bins of lam_k
             double w_next = Wl[c * PGL_KMAX];
@@ -3122,15 +3121,18 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                 w_next = Wl[c * PGL_KMAX + ((k + 1 < K) ? k + 1 : k)];  // in flight during this iteration
                 // all four segments side by side: four independent chains
                 double x[4];
-                unsigned long long fm[4], bm[4];
+                bool fl[4], bl[4];
                 float corr[4];
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
-                    const unsigned long long f = __ballot((fabs(x[sg]) > 12.0) && (x[sg] > -700.0));
-                    fm[sg] = f & vm[sg];
-                    bm[sg] = ~f & vm[sg];
+                    // fast regime: 12 <= |x| < 700, read off the high word of |x| (monotonic for non-negative
+                    // doubles; NaN, inf and |x| >= 700 fall outside and take the f64 path)
+                    const unsigned hx = (unsigned)__double2hiint(x[sg]) & 0x7fffffffu;
+                    const bool f = (hx - 0x40280000u) < (0x4085e000u - 0x40280000u);
+                    fl[sg] = f && vl[sg];
+                    bl[sg] = !f && vl[sg];
                 }
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
@@ -3141,21 +3143,20 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                 float accc = 0.0f;
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
-                    const bool f = (fm[sg] >> lane) & 1ull;
-                    accc += f ? corr[sg] : 0.0f;
-                    accl += f ? fmax(x[sg], 0.0) : 0.0;
+                    accc += fl[sg] ? corr[sg] : 0.0f;
+                    accl += (fl[sg] && __double2hiint(x[sg]) > 0) ? x[sg] : 0.0;      // max(x, 0) of a fast element
                 }
                 // band elements of this weight: queued per wave, evaluated in f64 on full waves
-                if ((bm[0] | bm[1] | bm[2] | bm[3]) != 0ull) {
+                if (__ballot(bl[0] || bl[1] || bl[2] || bl[3]) != 0ull) {
                     int qn = 0;
                     double accq = 0.0;
 #pragma unroll
                     for (int sg = 0; sg < 4; ++sg) {
-                        const unsigned long long m = bm[sg];
+                        const unsigned long long m = __ballot(bl[sg]);
                         if (m != 0ull) {
                             const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            if ((m >> lane) & 1ull) Qxw[idx] = x[sg];
+                            if (bl[sg]) Qxw[idx] = x[sg];
                             qn += __popcll(m);
                         }
                     }
@@ -3194,28 +3195,27 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
 // count * log(lam_k(t)); grid = (event chunks of 256, ncols), one event per thread, f64 throughout.
 __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[4][PGL_KMAX];
-    double* phiS = reinterpret_cast<double*>(smem);
     const int tid = threadIdx.x, c = blockIdx.y, K = p.K;
-    for (int i = tid; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
-    __syncthreads();
     const int n = p.cols[c], np = p.pre[c];
     const int i = p.elo[c] + blockIdx.x * 256 + tid;
     double acc[PGL_KMAX];
 #pragma unroll
     for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
     if (i < p.ehi[c]) {
-        double beta[PGL_MAXB];
-#pragma unroll
-        for (int b = 0; b < PGL_MAXB; ++b)
-            beta[b] = (b < p.B) ? p.theta[(size_t)n * p.P + p.woff + np * p.B + b] : 0.0;
         const int2 e = p.spk[i];
-        const long long t = e.x;
-        const int tile = (int)(t >> 4);
-        const double ic = pgl_pair_current(p.spk, p.wlo[(size_t)tile * p.N + np], p.whi[(size_t)tile * p.N + np],
-                                           (int)t, p.R, p.B, phiS, beta);
-        const double x0 = (p.theta[(size_t)n * p.P] + p.GX[t * p.xs + n]) - p.aw[c] * ic;
+        const int t = e.x;
+        const int tile = t >> 4;
+        // pair current at the spike bin from the impulse response of the pair (k_gibbs_cols_setup)
+        const double* hs = p.hs + (size_t)c * p.R;
+        const int lo = p.wlo[(size_t)tile * p.N + np], hi = p.whi[(size_t)tile * p.N + np];
+        double ic = 0.0;
+        for (int q = lo; q < hi; ++q) {
+            const int2 ev = p.spk[q];
+            const int d = t - ev.x - 1;
+            if ((unsigned)d < (unsigned)p.R) ic = fma((double)ev.y, hs[d], ic);
+        }
+        const double x0 = (p.theta[(size_t)n * p.P] + p.GX[(long long)t * p.xs + n]) - p.aw[c] * ic;
         const double sv = (double)e.y;
 #pragma unroll
         for (int k = 0; k < PGL_KMAX; ++k) {
@@ -3238,20 +3238,18 @@ __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams 
             red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// out[c][k] = -dt * sum_b part[b][c][k] + sum_b partS[b][c][k] (fixed order); grid = ncols, block = 64
+// out[c][k] = -dt * sum_b part[b][c][k] + sum_b partS[b][c][k] (fixed order); grid = (ncols, K), block = 64
 __global__ __launch_bounds__(64) void k_gibbs_reduce_cols2(const double* __restrict__ part, int nblk,
                                                            const double* __restrict__ partS, int nblkS,
                                                            int ncols, int K, double dt, double* __restrict__ out)
 {
-    const int c = blockIdx.x;
-    for (int k = 0; k < K; ++k) {
-        double s = 0.0, q = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 64) s += part[((size_t)b * ncols + c) * PGL_KMAX + k];
-        for (int b = threadIdx.x; b < nblkS; b += 64) q += partS[((size_t)b * ncols + c) * PGL_KMAX + k];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        if (threadIdx.x == 0) out[(size_t)c * K + k] = fma(-dt, s, q);
-    }
+    const int c = blockIdx.x, k = blockIdx.y;
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[((size_t)b * ncols + c) * PGL_KMAX + k];
+    for (int b = threadIdx.x; b < nblkS; b += 64) q += partS[((size_t)b * ncols + c) * PGL_KMAX + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (threadIdx.x == 0) out[(size_t)c * K + k] = fma(-dt, s, q);
 }
 
 // out[c][k] = sum over the time blocks (fixed order); grid = ncols, block = 64

@@ -1,4 +1,5 @@
-"""Ablation of the regime-split batched Gibbs kernel at the C4 shape (dev tool): option 99 bits 1 = no pair-current\nloop, 2 = no evaluation, 4 = no event staging, 8 = no current loads."""
+"""Ablation of the regime-split batched Gibbs kernel at the C4 shape (dev tool): option 99 bits 1 = no pair-current
+loop, 2 = no evaluation, 4 = no event staging, 8 = no current loads."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')

@@ -39,6 +39,9 @@ t0 = time.time()
 for _ in range(50): h.gibbs_ll_cols(cols[:1], pre[:1], aw[:1], ws[:1, :1])
 t_one = (time.time() - t0) / 50
 t0 = time.time()
+for _ in range(50): h.gibbs_ll_cols(cols[:1], pre[:1], aw[:1], np.linspace(-0.2, 0.2, 14)[None, :])
+print("  ll_cols(1 col x 14): %.3f ms" % ((time.time() - t0) / 50 * 1e3))
+t0 = time.time()
 for _ in range(20): h.gibbs_update_cols(cols[:3], pre[:3], np.array([0.1, -0.1, 0.2]))
 h.sync(); t_upd = (time.time() - t0) / 20
 print("theta_matrix %.1f ms | prepare_all first %.1f ms, again %.1f ms | ll_cols(%d cols x 11) %.3f ms | "
