@@ -14,7 +14,7 @@ python3 - <<PY
 import json
 d=json.load(open('$OUT/pmc.json'))
 for k,v in d.items():
-    if 'gibbs_ll' in k: print(k, {kk:(vv.get('avg') if isinstance(vv,dict) and 'avg' in vv else vv) for kk,vv in v.items()})
+    if 'gibbs_' in k: print(k, {kk:(vv.get('avg') if isinstance(vv,dict) and 'avg' in vv else vv) for kk,vv in v.items()})
 PY
 tail -3 $OUT/log3.txt
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2
