@@ -532,3 +532,41 @@ def test_batched_gibbs_regime_split_kernels_match_f64_kernel_and_oracle():
         ref = oracle(cols, pre, ws, 512, 1999)
     assert np.allclose(new, ref, rtol=1e-10, atol=0, equal_nan=True)
     d.close()
+
+
+@pytest.mark.gpu
+def test_batched_gibbs_sub_block_loop_and_event_bursts():
+    """k_gibbs_rate_cols: several 256-bin sub-blocks per workgroup (forced through the debug option, as the
+    full-size launches have them) with a ragged tail, and presynaptic bursts that overflow the LDS event
+    staging (> 24 events per window -> the window tables are walked in global memory)."""
+    from theano_pyglm_amd import _lib
+    N = 9
+    for rate, nT in ((20.0, 256 * 7 + 100), (160.0, 256 * 5 + 3)):
+        p = H.Problem(N, nT, H.std_ibasis(), kind='explinear', seed=int(rate), weighted=True, w_scale=0.4,
+                      rate_hz=rate, bias_mu=15.0)
+        d = p.device()
+        A = (p.Weff != 0).astype(float)
+        d.gibbs_prepare_all(p.theta, p.Weff)
+        cols = np.arange(N)
+        pre = (cols * 2 + 3) % N
+        ws = np.concatenate((np.sqrt(2) * np.polynomial.hermite.hermgauss(10)[0], [0.0]))[None, :] * np.ones((N, 1))
+        ref = np.zeros((N, 11))
+        for i, c in enumerate(cols):
+            w = p.theta[c, 1:].reshape(N, p.B)
+            I_imp = O.impulse_currents(p.fS, w)
+            I_other = O.other_current(I_imp, A, p.Weff, pre[i], c)
+            with np.errstate(all='ignore'):
+                ref[i] = O.mcmc_inner_ll(ws[i], p.theta[c, 0], 0.0, I_other, I_imp[:, pre[i]],
+                                         p.S[:, c].astype(float), p.dt, p.kind)
+        fin = np.isfinite(ref)
+        assert fin.mean() > 0.5
+        base = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+        assert np.array_equal(np.isfinite(base), fin) and np.allclose(base[fin], ref[fin], rtol=1e-10, atol=0)
+        for nloop in (2, 3, 8):
+            d.set_option(99, nloop << 8)
+            got = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+            assert np.array_equal(np.isfinite(got), fin) and np.allclose(got[fin], ref[fin], rtol=1e-10, atol=0)
+            one = d.gibbs_ll_cols(cols[4:5], pre[4:5], p.Weff[pre[4:5], cols[4:5]], ws[4:5])
+            assert np.allclose(one[0][fin[4]], ref[4][fin[4]], rtol=1e-10, atol=0)
+        d.set_option(99, 0)
+        d.close()

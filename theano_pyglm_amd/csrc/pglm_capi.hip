@@ -1759,6 +1759,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         const long long nrows = h->t_hi - h->t_lo;
         const long long nsub = (nrows + PGL_GRB - 1) / PGL_GRB;
         gp.nloop = (int)std::max<long long>(1, std::min<long long>(PGL_GNL, nsub * ygroups / (8LL * h->numCU)));
+        if ((h->opt_dbg >> 8) & 0xf) gp.nloop = std::min(PGL_GNL, (h->opt_dbg >> 8) & 0xf);      // tests: force the sub-block loop
         const int nblk = (int)((nsub + gp.nloop - 1) / gp.nloop);
         const int sblk = std::max(1, (max_ev + 255) / 256);
         ENSURE(h->gpart, (size_t)(nblk + sblk) * ncols * PGL_KMAX * 8);
@@ -1767,7 +1768,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.part = (double*)h->gpart.p;
         gp.partS = gp.part + (size_t)nblk * ncols * PGL_KMAX;
         gp.hs = (double*)h->ghs.p;
-        gp.dbg = h->opt_dbg;
+        gp.dbg = h->opt_dbg & 0xff;
         const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
                             (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
                            (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
