@@ -144,6 +144,54 @@ def map_wall_clock(S, N, dt):
                          "finished neurons masked out of the launch"}
 
 
+def mcmc_inner_ll(S, N, dt):
+    """Secondary metric for the MCMC configuration ("inner-ll batches/s, one batch = the 11 ll
+    values -- 10 Gauss-Hermite nodes + w = 0 -- of one (n_pre, n_post) pair", gibbs.py:1002-1032) on the same
+    spike matrix with sparse_weighted_model (Dirichlet impulses, Erdos-Renyi graph), and the wall-clock of one
+    collapsed-Gibbs sweep over all N^2 pairs (gibbs.py:1229-1250 for every column)."""
+    from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity
+    from theano_pyglm_amd.population import Population
+    from theano_pyglm_amd.inference import gibbs as G
+    model = make_model('sparse_weighted_model', N=N, dt=dt)
+    stabilize_sparsity(model)
+    popn = Population(model)
+    popn.add_data({'S': S, 'N': N, 'dt': dt, 'T': S.shape[0] * dt, 'stim': None, 'dt_stim': 0.1})
+    x = popn.sample(np.random.RandomState(4))
+    # a raw prior draw W ~ N(0, 1) times the tall normalised impulses drives quadrature nodes to lam = 0
+    # (the reference's "log_G not finie"); shrink the weights like harness/synth_mcmc.py does
+    x['net']['weights']['W'] = 0.2 * np.asarray(x['net']['weights']['W'])
+    upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(2))
+    upd.preprocess(popn)
+    h = popn._handle(popn._current)
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+    W = np.asarray(x['net']['weights']['W'], dtype=float).reshape(N, N)
+    h.gibbs_prepare_all(popn.theta_matrix(x), A * W)
+    cols = np.arange(N)
+    pre = (cols * 37 + 11) % N
+    nodes = np.concatenate((np.sqrt(2) * upd.sigma_w * upd.GAUSS_HERMITE_ABSCISSAE + upd.mu_w, [0.0]))
+    ws = np.tile(nodes, (N, 1))
+    aw = (A * W)[pre, cols]
+    h.gibbs_ll_cols(cols, pre, aw, ws)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ll = h.gibbs_ll_cols(cols, pre, aw, ws)
+    per_launch = (time.perf_counter() - t0) / reps
+    sweeps = []
+    for _ in range(2):
+        upd.n_ars_evals = 0
+        t0 = time.perf_counter()
+        upd.update_all(x)
+        sweeps.append(time.perf_counter() - t0)
+    popn.release_data()
+    return {"metric": "MCMC inner-ll batches/s (11 ll values per (n_pre, n_post) pair, sparse_weighted_model)",
+            "value": N / per_launch, "unit": "batches/s", "pairs_per_launch": N, "ms_per_launch": per_launch * 1e3,
+            "finite_fraction": float(np.isfinite(ll).mean()),
+            "sweep_s": sweeps[1], "first_sweep_s": sweeps[0], "pairs_per_sweep": N * N,
+            "ars_launches_last_sweep": upd.n_ars_evals,
+            "kernels": "k_gibbs_rate_cols (f32 log1p term where |x| >= 12, compacted f64 band) + k_gibbs_spike_cols"}
+
+
 def usable_cores():
     """Host cores this process may actually use: the scheduler affinity mask capped by the cgroup CPU
     quota (a container that sees 256 logical CPUs may be limited to a few cores' worth of time)."""
@@ -230,6 +278,7 @@ def main():
     ap.add_argument('--f32-features', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
+    ap.add_argument('--no-mcmc', action='store_true', help='skip the secondary MCMC inner-ll measurement')
     ap.add_argument('--shard', choices=['time', 'neurons'], default='time')
     # dev-only: exercise the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo collectives)
     ap.add_argument('--debug-single-device', action='store_true')
@@ -446,6 +495,8 @@ def main():
                 out["roofline"]["mfma_busy_pmc"] = mb
         if world == 1 and not args.no_map and not args.f32_features:
             out["secondary"] = map_wall_clock(S, N, dt)
+        if world == 1 and not args.no_mcmc and not args.f32_features:
+            out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         print(json.dumps(out))
