@@ -355,7 +355,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     const size_t esz = pl.f32 ? 4 : 8;
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
     if (pl.version == 5) {
-        pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8 + 16;   // + per-wave spike scratch + H ticket
+        pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8;   // + per-wave spike scratch
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }

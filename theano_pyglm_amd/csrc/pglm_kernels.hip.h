@@ -43,16 +43,6 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
                              // 4: the requests leave in the first half of the pass and have the second half to land (A/B over
                              // four interleaved runs each: 3.23-3.26 ms against 3.27-3.30 ms spread evenly, 2: 3.20-3.35)
 #endif
-#ifndef PGL_V2
-#define PGL_V2 0             // k_fused5 pass 1 (A/B variants, measured equal within noise: 3.28-3.37 ms): 1 = without the two mid-tile barriers: the H part of the forward pass
-                             // runs first and an LDS ticket (not a barrier) tells the DMA when every wave is done
-                             // with H_i; the epilogue runs at raised wave priority beside the partner's MFMAs;
-                             // 2 = the closing barrier is a ticket too: a wave only ever waits for the data it
-                             // is about to touch (tile landed / buffer free), the waves drift by up to a tile
-#endif
-#ifndef PGL_EPRIO
-#define PGL_EPRIO 3          // wave priority during the rate epilogue (PGL_V2)
-#endif
 #ifndef PGL_ENE
 #define PGL_ENE 4            // elements a lane carries through the rate epilogue together (k_fused5):
                              // 4 = pgl_rate4 (fixed instruction order), 2 = pgl_rate_terms_n<2> only
@@ -1572,20 +1562,6 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int NRL = (IMGL / 1024 + 7) / 8, NRH = (IMGH / 1024 + 7) / 8;
     constexpr int NR0 = (PASS == 1) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
     constexpr int RSG = (PASS == 1) ? RSL : RSH;
-    // ticket counter of pass 1 (PGL_V2): wave w adds 1 per tile once its forward pass has consumed H_i
-    volatile unsigned* const hdone = reinterpret_cast<volatile unsigned*>(smem + 2 * IMGL + IMGH + 256 + 8 * 192 * 8);
-    // hdone[1]: tiles whose images have landed (one count per wave after its vmcnt(0)); hdone[2]: waves
-    // that are done with the L buffer of the tile (PGL_V2 == 2)
-    unsigned h_target = 0;
-    auto wait_h = [&]() {
-        while (*hdone < h_target) __builtin_amdgcn_s_sleep(1);
-    };
-    auto wait_ticket = [&](const int which, const unsigned target) {
-        while (hdone[which] < target) __builtin_amdgcn_s_sleep(1);
-    };
-    auto add_ticket = [&](const int which) {
-        if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone) + which, 1u);
-    };
     auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
                         unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
         const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSG + col;
@@ -1600,11 +1576,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTG)) * RSG + 16 * (s % KTG)];
         auto round = [&](const int j) {
             if (j < NR0) {
-                // the L image of the next tile goes over the one of the previous tile: every wave has left it
-                if (PASS == 1 && PGL_V2 == 2 && j == 0) wait_ticket(2, h_target - NW);
                 pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
             } else {
-                if (PASS == 1 && PGL_V2 && j == NR0) wait_h();       // every wave is done reading H_i
                 pgl_dma_round<KTH>(g1, l1, j - NR0, wave, lane);
             }
         };
@@ -1659,14 +1632,10 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             cnt_ptr += cnt_tile;
         };
         if (tile_beg < tile_end) load_counts(scn);
-        if (PGL_V2 && tid < 4) hdone[tid] = 0u;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): the DMAs have landed
         __syncthreads();
         PGL_PROF_DECL
         for (int tile = tile_beg; tile < tile_end; ++tile) {
-            h_target += NW;
-            if (PGL_V2 && !active && lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);
-            if (PGL_V2 == 2 && tile > tile_beg) wait_ticket(1, h_target - NW);     // L_i, H_i landed (all waves' pieces)
             const int t0 = tile * TT;
             const int par = (tile - tile_beg) & 1;
             const unsigned char* Lb = par ? buf2 : buf0;     // L alternates buf0 / buf2, H lives in buf1
@@ -1687,11 +1656,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
                 double ar[PA];
-                // k-step order: with PGL_V2 the H columns go first (step q is k-step (q + KSL) % KS_ALL), so
-                // that H_i is dead -- and its buffer free for the DMA of H_{i+1} -- early in the pass
-                constexpr int KOFF = PGL_V2 ? KSL : 0;
-                auto afrag = [&](const int q) -> double {
-                    const int s = (q + KOFF) % KS_ALL;
+                auto afrag = [&](const int s) -> double {
                     return (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
                 };
                 // scalar bases of the Wmat fragment stream, one per 4 KB (four pairs of k-steps)
@@ -1704,7 +1669,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 }
 #pragma unroll
                 for (int q = 0; q < PW2; ++q) {
-                    const int pair = (((2 * q + KOFF) % KS_ALL) / 2);
+                    const int pair = q;
                     wr[q] = wr_base[pair / 4][(pair % 4) * 64 + lane];
                 }
 #pragma unroll
@@ -1719,7 +1684,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     if ((q & 1) && (q / 2 + PW2 < KS_ALL / 2)) {
                         // scalar base + lane offset + small immediate: the base moves on in SGPRs every four
                         // fragment pairs (4 KB), no 64-bit VALU address arithmetic
-                        const int pair = ((2 * (q / 2 + PW2) + KOFF) % KS_ALL) / 2;      // compile-time (unrolled)
+                        const int pair = q / 2 + PW2;      // compile-time (unrolled)
                         wr[(q / 2) % PW2] = wr_base[pair / 4][(pair % 4) * 64 + lane];
                     }
                     if (q & 1)
@@ -1727,25 +1692,15 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     else
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
                     if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                    // the last A fragment of H was requested PA steps before the first L step was issued
-                    if (PGL_V2 && q == KS_ALL - KSL + PA - 1) {
-                        if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
-            } else if (PGL_V2 && active) {
-                if (lane == 0) atomicAdd(const_cast<unsigned*>(hdone), 1u);      // dbg & 8: no forward pass
             }
             PGL_PROF_MARK(0);
             const bool do_bwd = active && p.want_grad && !(p.dbg & 16);
-            // (without PGL_V2) every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The
-            // barrier also lines the waves up for the epilogue.
-            if (!PGL_V2) __syncthreads();
+            // every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The barrier also lines
+            // the waves up for the epilogue.
+            __syncthreads();
             PGL_PROF_MARK(2);
             // ---- epilogue on the accumulator registers ----
-            // PGL_V2: at raised priority -- its dependent f64 chains take the issue slots they can use and
-            // the partner wave's MFMAs fill the rest of the shared DP pipe
-            if (PGL_V2 != 0 && PGL_EPRIO != 0) __builtin_amdgcn_s_setprio(PGL_EPRIO);
             double rr[4];
             if (active) {
                 bool done = false;
@@ -1802,13 +1757,10 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 for (int r = 0; r < 4; ++r) rr[r] = 0.0;
             }
             PGL_PROF_MARK(1);
-            if (PGL_V2 != 0 && PGL_EPRIO != 0) __builtin_amdgcn_s_setprio(0);
-            if (PGL_EBAR && !PGL_V2) __syncthreads();     // both epilogues of a SIMD end before any backward MFMA
+            if (PGL_EBAR) __syncthreads();     // both epilogues of a SIMD end before any backward MFMA
             if (more) load_counts(scn);                   // retired by the closing vmcnt(0) of this tile
             if (!do_bwd && more) {
-                if (PGL_V2 == 2) wait_ticket(2, h_target - NW);
                 pgl_dma_half<KTL>(fimg + (size_t)(tile + 1) * IMGS, Ln, wave, lane);
-                if (PGL_V2) wait_h();
                 pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, wave, lane);
             }
             PGL_PROF_MARK(3);
@@ -1820,13 +1772,9 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                          fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, more);
             }
             PGL_PROF_MARK(4);
-            if (PGL_V2 == 2) add_ticket(2);              // done with L_i (forward and backward)
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
             PGL_PROF_MARK(5);
-            if (PGL_V2 == 2)
-                add_ticket(1);
-            else
-                __syncthreads();
+            __syncthreads();
             PGL_PROF_MARK(6);
         }
         PGL_PROF_STORE(1);
