@@ -24,6 +24,23 @@ def _log_piece_mass(y_a, m, length):
     return y_a + np.log(-np.expm1(z)) - np.log(-m)
 
 
+def _log_piece_masses(y_a, m, length):
+    """_log_piece_mass for arrays of pieces (same formulas, element by element)."""
+    y_a, m, length = np.asarray(y_a, dtype=float), np.asarray(m, dtype=float), np.asarray(length, dtype=float)
+    out = np.empty_like(y_a)
+    inf = np.isinf(length)
+    with np.errstate(all='ignore'):
+        z = m * length
+        small = ~inf & (np.abs(z) < 1e-8)
+        pos = ~inf & ~small & (z > 0)
+        neg = ~inf & ~small & ~pos
+        out[inf] = y_a[inf] - np.log(-m[inf])
+        out[small] = y_a[small] + np.log(length[small]) + 0.5 * z[small]
+        out[pos] = y_a[pos] + z[pos] + np.log(-np.expm1(-z[pos])) - np.log(m[pos])
+        out[neg] = y_a[neg] + np.log(-np.expm1(z[neg])) - np.log(-m[neg])
+    return out
+
+
 def _sample_piece(y_a, m, length, u):
     """inverse CDF on one exponential piece, offset from its left end."""
     if np.isinf(length):
@@ -152,7 +169,7 @@ def adaptive_rejection_sample(func, xs, v_xs, domain=(-np.inf, np.inf), stepsz=1
 
     while True:
         pieces = hull.pieces()
-        logm = np.array([_log_piece_mass(p[2], p[3], p[1]) for p in pieces])
+        logm = _log_piece_masses([p[2] for p in pieces], [p[3] for p in pieces], [p[1] for p in pieces])
         w = np.exp(logm - np.max(logm))
         i = int(np.searchsorted(np.cumsum(w), rng.random_sample() * np.sum(w)))
         i = min(i, len(pieces) - 1)
