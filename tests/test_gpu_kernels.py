@@ -570,3 +570,33 @@ def test_batched_gibbs_sub_block_loop_and_event_bursts():
             assert np.allclose(one[0][fin[4]], ref[4][fin[4]], rtol=1e-10, atol=0)
         d.set_option(99, 0)
         d.close()
+
+
+@pytest.mark.gpu
+def test_batched_gibbs_random_shapes_against_f64_kernel():
+    """Random population sizes (incl. N = 1 and N not a multiple of 8 or 16), recording lengths below and
+    above one 256-bin block, 1..16 weights, arbitrary column lists with repeats: the regime-split kernels
+    and the all-f64 kernel agree wherever both are finite, and the NaN pattern only differs inside the last
+    binade above the underflow (see the regime-split test)."""
+    from theano_pyglm_amd import _lib
+    rng = np.random.RandomState(77)
+    for N, nT in ((1, 37), (3, 300), (17, 1000), (40, 257), (9, 4099)):
+        p = H.Problem(N, nT, H.std_ibasis(), kind='explinear', seed=N + nT, weighted=True, w_scale=0.7,
+                      rate_hz=30.0, bias_mu=float(rng.uniform(-2.0, 22.0)))
+        d = p.device()
+        d.gibbs_prepare_all(p.theta, p.Weff)
+        for _ in range(4):
+            K = int(rng.randint(1, 17))
+            nc = int(rng.randint(1, 2 * N + 2))
+            cols = rng.randint(0, N, size=nc)
+            pre = rng.randint(0, N, size=nc)
+            ws = rng.standard_normal((nc, K)) * rng.choice([0.1, 1.0, 20.0])
+            aw = p.Weff[pre, cols]
+            d.set_option(_lib.OPT_GIBBS_KERNEL, 1)
+            old = d.gibbs_ll_cols(cols, pre, aw, ws)
+            d.set_option(_lib.OPT_GIBBS_KERNEL, 0)
+            new = d.gibbs_ll_cols(cols, pre, aw, ws)
+            both = np.isfinite(new) & np.isfinite(old)
+            assert both.sum() >= 0.9 * np.isfinite(old).sum()
+            assert np.allclose(new[both], old[both], rtol=1e-11, atol=0)
+        d.close()
