@@ -1128,7 +1128,7 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
     if (nkt < 0) nkt = pl.KT;
     if (!stream) stream = h->stream;
     const long long nfrag = (long long)pl.nPT * nkt * 256;
-    int blocks = (int)((nfrag + 255) / 256);
+    int blocks = (int)((nfrag + 63) / 64);                // one block per 64 elements: its four waves share the chunks
     if (with_ll) blocks += (pl.npost + 3) / 4;            // trailing blocks reduce ll and d ll / d bias
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, (const double*)h->Gpart.p,
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,

@@ -2367,7 +2367,7 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
     // kernels are reduced by separate launches: the first one runs beside pass 2)
     const int P = 1 + DsAll + Nall * B;
     const long long nfrag = (long long)nPT * nkt * 256;
-    const int gblocks = (int)((nfrag + 255) / 256);
+    const int gblocks = (int)((nfrag + 63) / 64);          // one block per 64 G elements, its four waves share the chunks
     if ((int)blockIdx.x >= gblocks) {
         // trailing blocks: ll_n and d ll_n / d bias (one wave per neuron), when the caller folded the
         // ll reduction into this launch (nsub > 0) -- it then runs beside the G reduction
@@ -2395,33 +2395,42 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
         }
         return;
     }
-    const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (grad_out != nullptr && gid < nfrag) {
-        const int lane = (int)(gid & 63);
-        const int r = (int)((gid >> 6) & 3);
-        const int kt = kt0 + (int)((gid >> 8) % nkt);
-        const int pt = (int)((gid >> 8) / nkt);
-        const int k = 16 * kt + (lane >> 4) + 4 * r;
-        const int n = 16 * pt + (lane & 15);
-        if (n < npost && k < Ktot) {
-            // eight interleaved partial sums (fixed order -> deterministic): eight loads in flight
-            // per lane instead of one dependent add chain over up to 256 chunks
-            const size_t cstride = (size_t)nPT * KT * 256;
-            const double* gp = Gpart + (size_t)pt * KT * 256 + (size_t)(kt * 4 + r) * 64 + lane;
-            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int c = 0;
-            for (; c + 8 <= nChunks; c += 8) {
+    if (grad_out == nullptr) return;
+    __shared__ double red[4][64];
+    const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
+    const long long gid = blockIdx.x * 64LL + lane;
+    const int r = (int)((gid >> 6) & 3);
+    const int kt = kt0 + (int)((gid >> 8) % nkt);
+    const int pt = (int)((gid >> 8) / nkt);
+    const int k = 16 * kt + (lane >> 4) + 4 * r;
+    const int n = 16 * pt + (lane & 15);
+    const bool live = gid < nfrag && n < npost && k < Ktot;
+    double s = 0.0;
+    if (live) {
+        // wave w sums the chunks [c0, c1) with eight interleaved partial sums (eight loads in flight per
+        // lane); the four waves' sums are combined in a fixed order: deterministic for a given geometry
+        const int per = (nChunks + 3) / 4;
+        const int c0 = w * per, c1 = (c0 + per < nChunks) ? c0 + per : nChunks;
+        const size_t cstride = (size_t)nPT * KT * 256;
+        const double* gp = Gpart + (size_t)pt * KT * 256 + (size_t)(kt * 4 + r) * 64 + lane;
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] += gp[(size_t)(c + j) * cstride];
-            }
-            for (int j = 0; c < nChunks; ++c, ++j) a[j] += gp[(size_t)c * cstride];
-            const double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-            if (k < Kimp) {
-                const int npre = np0 + k / B;
-                grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (pidx ? pidx[n] : n_lo + n)];
-            } else {
-                grad_out[(size_t)n * P + 1 + ds0 + (k - Kimp)] = s;
-            }
+            for (int j = 0; j < 8; ++j) a[j] += gp[(size_t)(c + j) * cstride];
+        }
+        for (int j = 0; c < c1; ++c, ++j) a[j] += gp[(size_t)c * cstride];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (k < Kimp) {
+            const int npre = np0 + k / B;
+            grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (pidx ? pidx[n] : n_lo + n)];
+        } else {
+            grad_out[(size_t)n * P + 1 + ds0 + (k - Kimp)] = s;
         }
     }
 }
