@@ -131,17 +131,19 @@ def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi
     f, g = evaluate(X)
     eye = torch.eye(P, dtype=torch.float64, device=dev)
     H = eye.repeat(M, 1, 1)
+    Hg = g.clone()                                              # H g, carried along: one pass over H per iteration
     active = g.abs().amax(1) > gtol
     frozen = torch.zeros(M, dtype=torch.bool, device=dev)       # line search failed twice in a row
     restarts = torch.zeros(M, dtype=torch.int64, device=dev)
     it = 0
     while it < maxiter and bool(active.any()):
         it += 1
-        p = -torch.bmm(H, g[:, :, None])[:, :, 0]
+        p = -Hg
         slope = (p * g).sum(1)
         bad = slope >= 0
         if bool(bad.any()):
             H[bad] = eye
+            Hg = torch.where(bad[:, None], g, Hg)
             p = torch.where(bad[:, None], -g, p)
             slope = (p * g).sum(1)
         alpha = torch.ones(M, dtype=torch.float64, device=dev)
@@ -167,17 +169,25 @@ def _lockstep_bfgs(population, torch, dev, handles, x, maxiter, gtol, n_lo, n_hi
         y = gn - g
         sy = (s * y).sum(1)
         upd = active & (~stalled) & (sy > 1e-12)
+        # H g_new: the one full read of H (M x P x P) of the iteration; H y = H g_new - H g follows from it
+        t = torch.bmm(H, gn[:, :, None])[:, :, 0]
         if bool(upd.any()):
             rho = torch.where(upd, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy))
-            Hy = torch.bmm(H, y[:, :, None])[:, :, 0]
+            Hy = t - Hg
             yHy = (y * Hy).sum(1)
             c = (1.0 + rho * yHy) * rho
-            H += c[:, None, None] * (s[:, :, None] * s[:, None, :])
-            H -= rho[:, None, None] * (Hy[:, :, None] * s[:, None, :] + s[:, :, None] * Hy[:, None, :])
-        X, f, g = Xn, fn, gn
+            # H += c s s^T - rho (Hy s^T + s Hy^T) as ONE rank-3 update: a single read-modify-write of H
+            # instead of a dozen (M, P, P) temporaries
+            U = torch.stack((c[:, None] * s, -rho[:, None] * Hy, -rho[:, None] * s), dim=2)       # (M, P, 3)
+            V = torch.stack((s, s, Hy), dim=2)                                                    # (M, P, 3)
+            H.baddbmm_(U, V.transpose(1, 2))
+            t = t + torch.bmm(U, torch.bmm(V.transpose(1, 2), gn[:, :, None]))[:, :, 0]          # H_new g_new
+        X, f, g, Hg = Xn, fn, gn, t
         # a failed line search: one restart from steepest descent, then the neuron is frozen
         again = stalled & (restarts == 0)
-        H[again] = eye
+        if bool(again.any()):
+            H[again] = eye
+            Hg = torch.where(again[:, None], g, Hg)
         restarts = torch.where(again, restarts + 1, torch.where(stalled, restarts, torch.zeros_like(restarts)))
         frozen = frozen | (stalled & ~again)
         active = active & (~frozen) & (g.abs().amax(1) > gtol)

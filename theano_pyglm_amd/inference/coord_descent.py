@@ -224,7 +224,7 @@ def coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=False, ver
     net_inf_prms = prep_first_order_network_inference(population)
     glm_inf_prms = prep_first_order_glm_inference(population)
     x = x0
-    lp_prev = population.compute_log_p(x)
+    lp_prev = lp                                      # x is x0: the value just computed
     converged = False
     it = 0
     while not converged and it < maxiter:
