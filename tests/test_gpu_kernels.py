@@ -600,3 +600,29 @@ def test_batched_gibbs_random_shapes_against_f64_kernel():
             assert both.sum() >= 0.9 * np.isfinite(old).sum()
             assert np.allclose(new[both], old[both], rtol=1e-11, atol=0)
         d.close()
+
+
+@pytest.mark.gpu
+def test_denormal_rate_of_one_neuron_does_not_leak_into_its_post_tile():
+    """A neuron whose rate is denormal at its spike bins (x ~ -730: 1/lam overflows) gets a non-finite
+    gradient of its own -- but the compacted spike terms of pgl_rate4 must not carry 0 * inf into the other
+    fifteen neurons of its post tile (every kernel family; regression: k_fused5 / k_fused7 did)."""
+    from theano_pyglm_amd import _lib
+    for N in (48, 128):
+        p = H.Problem(N, 4000, H.std_ibasis(), seed=5, w_scale=0.5)
+        base_ll = base_g = None
+        for bias in (20.0, -730.0, 800.0, -900.0):
+            th = p.theta.copy()
+            th[5, 0] = bias
+            for kern in (0, 2, 3, 4, 6, 7):
+                d = p.device()
+                d.set_option(_lib.OPT_KERNEL, kern)
+                ll, g = d.ll_grad(th, p.Weff)
+                ver = d.info()['kernel_version']
+                d.close()
+                others = np.arange(N) != 5
+                assert np.all(np.isfinite(ll[others])) and np.all(np.isfinite(g[others])), (N, bias, kern, ver)
+                if bias == 20.0 and kern == 0:
+                    base_ll, base_g = ll, g
+                assert np.allclose(ll[others], base_ll[others], rtol=1e-12, atol=0)
+                assert np.allclose(g[others], base_g[others], rtol=1e-10, atol=1e-9 * np.abs(base_g).max())

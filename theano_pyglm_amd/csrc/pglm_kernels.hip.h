@@ -480,9 +480,12 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
         for (int i = 0; i < 4; ++i) g[i] = so[slot[i]];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // elements without a spike read slot 0 with weight 0 -- but 0 * (log, 1/lam) of ANOTHER neuron's
+            // spike is NaN when that rate is denormal or infinite (1/lam = inf): select, do not multiply
             const double sd = (double)sc[i];
-            t = fma(g[i].x, sd, t);
-            res[i] = fma(sd, g[i].y, -dt) * sig[i];
+            const bool has = sc[i] != 0u;
+            t = has ? fma(g[i].x, sd, t) : t;
+            res[i] = (has ? fma(sd, g[i].y, -dt) : -dt) * sig[i];
         }
     } else {
 #pragma unroll
