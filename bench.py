@@ -140,8 +140,8 @@ def map_wall_clock(S, N, dt):
             "neurons_converged_gtol": getattr(popn, 'last_fit_stats', {}).get('converged_gtol'),
             "neurons_stalled": getattr(popn, 'last_fit_stats', {}).get('stalled'),
             "neurons_at_maxiter": getattr(popn, 'last_fit_stats', {}).get('maxiter'),
-            "optimizer": "lock-step batched BFGS, maxiter 225, gtol 1e-5, GPU-resident state on one stream, "
-                         "finished neurons masked out of the launch"}
+            "optimizer": "lock-step batched BFGS (per-neuron line-search state machines, one launch per pending trial of "
+                         "all active neurons), maxiter 225, gtol 1e-5, GPU-resident state on one stream"}
 
 
 def mcmc_inner_ll(S, N, dt):
