@@ -457,7 +457,7 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
     if (total == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) res[i] = -dt * sig[i];
-    } else if (total <= 64) {
+    } else if (total < 64) {
         const int base[4] = {0, n0, n0 + n1, n0 + n1 + n2};
         int slot[4];
 #pragma unroll
@@ -465,7 +465,7 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
             slot[i] = base[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[i] >> 32),
                                          __builtin_amdgcn_mbcnt_lo((unsigned)m[i], 0u));
             if (sc[i] != 0u) scratch[slot[i]] = lam[i];
-            slot[i] = (sc[i] != 0u) ? slot[i] : 0;        // lanes without a spike read slot 0, weight 0
+            slot[i] = (sc[i] != 0u) ? slot[i] : 63;       // lanes without a spike read the unused slot 63, weight 0
         }
         __builtin_amdgcn_wave_barrier();               // one wave: its LDS operations execute in order
         const double lc = (lane < total) ? scratch[lane] : 1.0;
@@ -480,12 +480,12 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
         for (int i = 0; i < 4; ++i) g[i] = so[slot[i]];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // elements without a spike read slot 0 with weight 0 -- but 0 * (log, 1/lam) of ANOTHER neuron's
-            // spike is NaN when that rate is denormal or infinite (1/lam = inf): select, do not multiply
+            // elements without a spike read slot 63 with weight 0: that slot is never a real spike here
+            // (total < 64) and holds (log 1, 1/1) -- slot 0 would be ANOTHER neuron's spike, and 0 * (1/lam)
+            // of a denormal or infinite rate is NaN
             const double sd = (double)sc[i];
-            const bool has = sc[i] != 0u;
-            t = has ? fma(g[i].x, sd, t) : t;
-            res[i] = (has ? fma(sd, g[i].y, -dt) : -dt) * sig[i];
+            t = fma(g[i].x, sd, t);
+            res[i] = fma(sd, g[i].y, -dt) * sig[i];
         }
     } else {
 #pragma unroll
