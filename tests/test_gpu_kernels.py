@@ -626,3 +626,54 @@ def test_denormal_rate_of_one_neuron_does_not_leak_into_its_post_tile():
                     base_ll, base_g = ll, g
                 assert np.allclose(ll[others], base_ll[others], rtol=1e-12, atol=0)
                 assert np.allclose(g[others], base_g[others], rtol=1e-10, atol=1e-9 * np.abs(base_g).max())
+
+
+@pytest.mark.gpu
+def test_kernel_families_agree_on_wild_parameters():
+    """Seeded short run of tools/fuzz_kernels.py: every kernel family against the K-split kernel with in-kernel
+    features on random shapes with a few neurons at extreme biases / weights per trial (rates at the underflow
+    and overflow edges): same finite pattern per neuron, same values where finite."""
+    from theano_pyglm_amd import _lib
+    rng = np.random.RandomState(2024)
+    seen_nonfinite = 0
+    for trial in range(14):
+        N = int(rng.choice([17, 48, 64, 80, 128, 130]))
+        kind = str(rng.choice(['explinear', 'exp']))
+        nT = int(rng.choice([700, 2500]))
+        Dstim = int(rng.choice([0, 0, 3]))
+        p = H.Problem(N, nT, H.std_ibasis(), kind=kind, seed=int(rng.randint(1 << 30)), weighted=bool(rng.rand() < 0.5),
+                      Dstim=Dstim, rate_hz=float(rng.choice([5.0, 20.0, 60.0])))
+        th = p.theta.copy()
+        for n in rng.choice(N, size=int(rng.randint(1, 5)), replace=False):
+            mode = rng.randint(4)
+            if mode == 0:
+                th[n, 0] = rng.uniform(-800, 800)
+            elif mode == 1:
+                th[n, 1:] *= rng.choice([20.0, 200.0, 2000.0])
+            elif mode == 2:
+                th[n, 0] = rng.choice([-730.0, -745.0, -746.0, -709.0, 709.0, 745.0])
+            else:
+                th[n, 1 + Dstim:1 + Dstim + p.B] = rng.choice([1e3, -1e3, 1e5])
+        if kind == 'exp':
+            th[:, 0] = np.clip(th[:, 0], -800, 700)
+        res = {}
+        for kern in (2, 0, 3, 4, 6, 7):
+            d = p.device()
+            d.set_option(_lib.OPT_KERNEL, kern)
+            ll, g = d.ll_grad(th, p.Weff)
+            res[kern] = (ll, g, d.info()['kernel_version'])
+            d.close()
+        ll0, g0, _ = res[2]
+        for kern in (0, 3, 4, 6, 7):
+            ll, g, ver = res[kern]
+            if ver == 2:
+                continue
+            f0, f1 = np.isfinite(ll0), np.isfinite(ll)
+            gf0, gf1 = np.isfinite(g0).all(1), np.isfinite(g).all(1)
+            assert np.array_equal(f0, f1) and np.array_equal(gf0, gf1), (trial, N, kind, kern, ver)
+            assert np.allclose(ll[f0], ll0[f0], rtol=1e-9, atol=0), (trial, N, kind, kern, ver)
+            if gf0.any():
+                scale = np.abs(g0[gf0]).max()
+                assert np.allclose(g[gf0], g0[gf0], rtol=1e-8, atol=1e-9 * scale), (trial, N, kind, kern, ver)
+            seen_nonfinite += int((~gf1).sum())
+    assert seen_nonfinite > 0
