@@ -2648,11 +2648,12 @@ __device__ __forceinline__ double pgl_lambda_only(const double x, const int nlin
     if (__all(e < C[23])) {                        // |x| > 9.25: alternating series, error < e^6
         l1p = e * fma(-e, fma(-e, fma(-e, fma(-e, 0.2, 0.25), C[22]), 0.5), 1.0);
     } else if (__all(e < 0.1)) {                   // |x| > 2.3: log1p(e) = 2 atanh(s), s = e/(2+e) < 0.048
-        const double s = e * pgl_rcp(2.0 + e);
+        const double rc = pgl_rcp(2.0 + e);
+        const double s = e * rc;
         const double z = s * s;                    // z < 2.3e-3: z^7/15 < 2.3e-20
         const double q = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.0 / 13.0, 1.0 / 11.0), 1.0 / 9.0), 1.0 / 7.0),
                                            0.2), C[22]), 1.0);
-        l1p = 2.0 * s * q;
+        l1p = e * ((rc + rc) * q);                 // e last: a denormal e (x ~ -745) must not be halved to zero on the way
     } else {
         const double u = 1.0 + e;
         l1p = pgl_log(u, C) + (e - (u - 1.0)) * pgl_rcp(u);
