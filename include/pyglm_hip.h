@@ -178,6 +178,8 @@ int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
  *   ll_cols: for column c: n_post[c], n_pre[c], aw_cur[c] = current A*W of the pair, w[c*K .. c*K+K)
  *     candidate weights (K <= 16, e.g. the 10 Gauss-Hermite nodes + w = 0, gibbs.py:1002-1032);
  *     ll_out[c*K + k] as pgl_gibbs_ll.  The impulse weights of the pair are theta[n_post][1+Dstim+n_pre*B ..].
+ *     explinear: f64 sums; the log1p(exp(-|x|)) term of bins with 12 <= |x| < 700 comes from the single-precision
+ *     hardware exp (absolute error <= 6e-12 per bin; see PGL_OPT_GIBBS_KERNEL for the all-f64 kernel).
  *   update_cols: after A*W of pair c changed by delta[c]: I_net[:, n_post[c]] += delta[c]*I_imp (n_post distinct).
  *   currents: copy out bias-free total current I_stim + I_net of one neuron over the prepared range. */
 int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff);
