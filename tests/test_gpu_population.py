@@ -442,3 +442,26 @@ def test_separable_stimulus_matches_dense_and_oracle():
             sep.get_stim_features()
         dense.close()
         sep.close()
+
+
+def test_two_data_sequences_log_p_and_lockstep_map():
+    """population.py:80-86 sums the likelihood over every data sequence (add_data twice).  log p is the oracle's
+    prior + sum over both sequences; the lock-step optimizer (one device handle per sequence, both on one
+    stream) reaches the optimum of the sequential reference-style fit on the same two sequences."""
+    model, popn, data1 = make_dataset('standard_glm', 4, 5.0, seed=31)
+    _, _, data2 = make_dataset('standard_glm', 4, 3.0, seed=32)
+    popn.add_data(data2)
+    assert len(popn.data_sequences) == 2
+    x0 = popn.sample(np.random.RandomState(33))
+    lp = popn.compute_log_p(x0)
+    lp1, ll1 = oracle_log_p(popn, data1, x0)
+    lp2, ll2 = oracle_log_p(popn, data2, x0)
+    assert np.isclose(lp, lp1 + np.sum(ll2), rtol=1e-10)          # the prior counts once
+    x_seq = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    x_t = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+    lp_seq, lp_t = popn.compute_log_p(x_seq), popn.compute_log_p(x_t)
+    assert lp_t > lp + 1.0
+    assert abs(lp_t - lp_seq) < 1e-2 * max(1.0, abs(lp_seq) * 1e-3)
+    st = popn.last_fit_stats
+    assert st['converged_gtol'] + st['stalled'] + st['maxiter'] == 4
+    popn.release_data()
