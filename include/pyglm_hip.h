@@ -62,6 +62,10 @@ typedef struct pgl_context* pgl_handle;
                                 * spike terms from the event lists); 1 = the all-f64 one-thread-per-(column, weight)
                                 * kernel (always used for the exp nonlinearity) */
 
+#define PGL_OPT_EPI_F64 5      /* 1 = all-f64 rate epilogue of the fused ll+grad kernels.  Default 0: in waves whose currents
+                                * are all > 12 the exp(-x) < 6.2e-6 inside softplus / sigmoid comes from the single-precision
+                                * hardware exp (rate and residual within 5e-13 relative of the all-f64 form) */
+
 const char* pgl_last_error(void);
 int pgl_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
@@ -133,6 +137,11 @@ int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
 int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double* d_theta,
                          const double* d_Weff, double* d_ll, double* d_grad);
 int pgl_sync(pgl_handle h);
+/* Helper of the lock-step optimiser around pgl_ll_grad_list_dev (the reference restarts a failed per-neuron
+ * BFGS by calling scipy again, coord_descent.py:194-199): rows m of the batch d_H (M, P, P) of inverse-Hessian
+ * estimates with d_scale[m] != 0 are set to d_scale[m] * identity on the handle's stream; other rows are not
+ * touched. */
+int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int M, int P);
 
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
  * fS_out (nT,N,B) row-major, float64. */

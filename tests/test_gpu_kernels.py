@@ -245,10 +245,31 @@ def test_full_size_properties_c3():
     dev.set_time_range(0, nsub)
     q = H.Problem(N, nsub, H.std_ibasis(), seed=0)
     q.S, q.theta, q.Weff, q._fS = p.S[:nsub], p.theta, p.Weff, None
+    oracle = {}
     for n in (0, 77, 127):
         a, b = dev.ll_grad(p.theta[n:n + 1], p.Weff, n, n + 1)
         a0, b0 = q.oracle_ll_grad(n, n + 1)
+        oracle[n] = (a0[0], b0[0])
         assert np.allclose(a, a0, rtol=LL_RTOL) and H.rel_err(b, b0) < G_RTOL
+    # ... and the block call on the same full-size handle: all 128 neurons in ONE launch of the two-pass
+    # resident-tile kernel (the bench workload's kernel), restricted to the oracle's bins
+    assert dev.info()['kernel_version'] == 5
+    a, b = dev.ll_grad(p.theta, p.Weff)
+    for n, (a0, b0) in oracle.items():
+        assert np.allclose(a[n], a0, rtol=LL_RTOL) and H.rel_err(b[n], b0) < G_RTOL
+    # a second sub-range in the middle of the recording (tile-aligned start; features reach back across it)
+    lo = 16 * 20000
+    dev.set_time_range(lo, lo + 8000)
+    a, b = dev.ll_grad(p.theta, p.Weff)
+    from oracle import glm_oracle as O
+    S2 = p.S[lo - 2000:lo + 8000].astype(float)              # 2000 bins of history >> R = 200 taps
+    fS = O.convolve_with_basis_fft(S2, p.ibasis)[2000:]
+    for n in (5, 100):
+        th = p.theta[n]
+        ll0, gb0, _, gw0 = O.glm_ll_grad(n, S2[2000:], fS, th[1:].reshape(N, p.B),
+                                         p.Weff[:, n], th[0], p.dt, p.kind, None, None)
+        assert np.allclose(a[n], ll0, rtol=LL_RTOL)
+        assert H.rel_err(b[n], np.concatenate(([gb0], gw0.reshape(-1)))) < G_RTOL
     dev.close()
 
 

@@ -182,3 +182,79 @@ def test_dirichlet_impulse_update_respects_graph(swm4):
     for n in range(4):
         for k in range(4):
             assert x['glms'][n]['imp']['g_%d' % k].shape == (5,)
+
+
+def test_collapsed_gibbs_over_two_data_sequences():
+    """gibbs.py:899-903, 931-935: the inner ll of the collapsed (A, W) column update is the SUM over the
+    population's data sequences.  Two sequences of different length on one population: the batched and the
+    single-column device paths against the oracle's inner ll summed over both, a full column sweep, and the
+    gibbs_sample driver on the two-sequence population."""
+    from oracle import glm_oracle as O
+
+    def tame(x):
+        x['net']['weights']['W'] = 0.3 * np.asarray(x['net']['weights']['W'])
+    N = 4
+    model = make_model('sparse_weighted_model', N=N, dt=0.001)
+    model['network']['graph']['rho'] = 0.4
+    model, popn, d1 = make_dataset(model, N, 5.0, seed=21, adjust=tame, check=False)
+    _, _, d2 = make_dataset(model, N, 3.0, seed=22, adjust=tame, check=False)
+    popn.add_data(d1)
+    popn.add_data(d2)
+    assert len(popn.data_sequences) == 2
+    x = copy.deepcopy(d1['vars'])
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N).astype(float)
+    W = np.asarray(x['net']['weights']['W'], float).reshape(N, N)
+    glm = popn.glm
+    rng = np.random.RandomState(23)
+
+    def oracle_inner(n_pre, n_post, ws):
+        out = np.zeros(len(ws))
+        xn = x['glms'][n_post]
+        beta = glm.imp_model.flat_weights(xn['imp']).reshape(N, -1)
+        for d in (d1, d2):
+            S = np.asarray(d['S'], float)
+            I_imp = O.impulse_currents(O.convolve_with_basis_fft(S, glm.imp_model.ibasis), beta)
+            I_other = O.other_current(I_imp, A, W, n_pre, n_post)
+            out += O.mcmc_inner_ll(ws, glm.bias_model.I_bias(xn['bias']), 0.0, I_other, I_imp[:, n_pre],
+                                   S[:, n_post], glm.dt, glm.nlin_model.kind)
+        return out
+
+    hs = G._SequenceSum(popn)
+    assert len(hs.hs) == 2
+    # batched path: one pair of every column per launch
+    hs.gibbs_prepare_all(popn.theta_matrix(x), A * W)
+    cols, n_pre = np.arange(N), np.array([1, 2, 3, 0])
+    aw = (A * W)[n_pre, cols]
+    ws = rng.standard_normal((N, 11))
+    ll = hs.gibbs_ll_cols(cols, n_pre, aw, ws)
+    for c in range(N):
+        assert np.allclose(ll[c], oracle_inner(n_pre[c], c, ws[c]), rtol=1e-10), c
+    # single-column path
+    n_post = 2
+    hs.gibbs_prepare(n_post, glm.theta_row(x['glms'][n_post]), (A * W)[:, n_post])
+    for k in (0, 2, 3):
+        got = hs.gibbs_ll(k, float((A * W)[k, n_post]), ws[0])
+        assert np.allclose(got, oracle_inner(k, n_post, ws[0]), rtol=1e-10), k
+    # rank-1 updates reach both handles: changing one pair == re-preparing with the new weights
+    delta = 0.37
+    hs.gibbs_prepare_all(popn.theta_matrix(x), A * W)
+    hs.gibbs_update_cols(np.array([1]), np.array([3]), np.array([delta]))
+    AW2 = (A * W).copy()
+    AW2[3, 1] += delta
+    ll_upd = hs.gibbs_ll_cols(cols, n_pre, AW2[n_pre, cols], ws)
+    hs.gibbs_prepare_all(popn.theta_matrix(x), AW2)
+    assert np.allclose(ll_upd, hs.gibbs_ll_cols(cols, n_pre, AW2[n_pre, cols], ws), rtol=1e-11)
+    # a sweep of all columns (lock step) and one reference-order column update on the two sequences
+    upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(24))
+    upd.preprocess(popn)
+    xs = copy.deepcopy(x)
+    upd.update_all(xs)
+    st = upd.update(xs, 0)
+    assert len(st) == N
+    lp = popn.compute_log_p(xs)
+    lp1, _ = oracle_log_p(popn, d1, xs)
+    _, ll2 = oracle_log_p(popn, d2, xs)
+    assert np.isclose(lp, lp1 + np.sum(ll2), rtol=1e-9)
+    smpls = G.gibbs_sample(popn, N_samples=2, x0=copy.deepcopy(xs), rng=np.random.RandomState(25), verbose=False)
+    assert len(smpls) == 3 and np.isfinite(popn.compute_log_p(smpls[-1]))
+    popn.release_data()

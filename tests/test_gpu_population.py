@@ -100,7 +100,7 @@ def test_fit_glm_and_coord_descent(std4):
     model, popn, data = std4
     x0 = popn.sample(np.random.RandomState(7))
     lp0 = popn.compute_log_p(x0)
-    x_seq = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    x_seq = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched=False)
     lp_seq = popn.compute_log_p(x_seq)
     x_bat = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched=True)
     lp_bat = popn.compute_log_p(x_bat)
@@ -457,7 +457,7 @@ def test_two_data_sequences_log_p_and_lockstep_map():
     lp1, ll1 = oracle_log_p(popn, data1, x0)
     lp2, ll2 = oracle_log_p(popn, data2, x0)
     assert np.isclose(lp, lp1 + np.sum(ll2), rtol=1e-10)          # the prior counts once
-    x_seq = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    x_seq = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched=False)
     x_t = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
     lp_seq, lp_t = popn.compute_log_p(x_seq), popn.compute_log_p(x_t)
     assert lp_t > lp + 1.0

@@ -19,6 +19,7 @@ OPT_FEATURE_F32 = 1
 OPT_NCHUNKS = 2
 OPT_KERNEL = 3
 OPT_GIBBS_KERNEL = 4
+OPT_EPI_F64 = 5
 
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -29,6 +30,7 @@ SYMBOLS = [
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
+    'pgl_identity_rows_dev',
 ]
 
 
@@ -101,6 +103,8 @@ def load():
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_list_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
+    if hasattr(lib, 'pgl_identity_rows_dev'):                 # (older dev A/B builds named by PYGLM_HIP_LIB lack it)
+        lib.pgl_identity_rows_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.pgl_features.argtypes = [vp, vp]
     lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
     lib.pgl_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
@@ -117,6 +121,8 @@ def load():
     lib.pgl_simulate.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, vp, vp, vp,
                                  C.c_int64, C.c_uint64, vp, vp]
     for name in SYMBOLS:
+        if 'PYGLM_HIP_LIB' in os.environ and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if name not in ('pgl_last_error',):
             fn.restype = C.c_int
@@ -297,6 +303,11 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_ll_grad_list_dev(self.h, C.c_void_p(d_idx), int(count), C.c_void_p(d_theta),
                                            C.c_void_p(d_Weff), C.c_void_p(d_ll),
                                            C.c_void_p(d_grad) if d_grad else None))
+
+    def reset_identity_dev(self, d_H, d_scale, M, P):
+        """Rows m of the device batch d_H (M, P, P) with d_scale[m] != 0 (device float64) become d_scale[m] * I
+        (asynchronous)."""
+        _chk(self.lib.pgl_identity_rows_dev(self.h, C.c_void_p(d_H), C.c_void_p(d_scale), int(M), int(P)))
 
     def sync(self):
         _chk(self.lib.pgl_sync(self.h))

@@ -79,7 +79,7 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_epi64 = 0;
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
 };
@@ -191,6 +191,8 @@ static bool pick_pair(int need, int& ktl, int& kth)
 }
 static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(ktl) + pgl_img_bytes(kth); }
 
+static int fused6_wg_per_cu(const Plan& pl);
+
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
                      bool single_slice = true)
 {
@@ -287,7 +289,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             const int kt6 = ktw6 * (nw6 / ptw6);
             int mt6 = 0;
             for (int mt = (nw6 == 4 ? 1 : 2); mt >= 1 && mt6 == 0; --mt) {
-                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt6) + (size_t)mt * (nw6 + ptw6) * 2048 + 256;
+                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt6) + (size_t)mt * nw6 * 2048 + 256;
                 const size_t cap = (nw6 == 4) ? 80 * 1024 : 160 * 1024;      // two 4-wave workgroups per CU
                 if (lds6 <= cap && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
             }
@@ -295,7 +297,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
                 nw6 = 8; ptw6 = pl.PTW; ktw6 = pl.KTW;
                 const int kt8 = ktw6 * (8 / ptw6);
                 for (int mt = 2; mt >= 1 && mt6 == 0; --mt) {
-                    const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt8) + (size_t)mt * (8 + ptw6) * 2048 + 256;
+                    const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt8) + (size_t)mt * 8 * 2048 + 256;
                     if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
                 }
             }
@@ -345,9 +347,20 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.KS = pl.KT * 4;
     const int kpad = pl.KT * 16;
     pl.rsf = pl.f32 ? kpad + 4 : kpad + 2;
-    const int wgPerCU = (pl.version == 7) ? pl.wg7 : (pl.version == 6 && pl.nw6 == 4) ? 2 : 1;
+    int wgPerCU = (pl.version == 7) ? pl.wg7 : 1;
+    if (pl.version == 6) {
+        // as many workgroups per CU as registers and LDS allow (4-wave form at C2: three)
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256;
+        wgPerCU = fused6_wg_per_cu(pl);
+    }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
+    if (h->opt_nchunks == 0 && wgPerCU > 1) {
+        // short recordings: a chunk keeps >= 8 tiles as long as every CU still gets a workgroup (per-chunk
+        // prologue, partial write-out and the reduction over chunks are paid per chunk)
+        const int floor_t = std::min(std::max(1, h->numCU / pl.nPB), pl.nTiles);
+        target = std::min(target, std::max(floor_t, pl.nTiles / 8));
+    }
     pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
     pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
     pl.blocks = pl.nChunks * pl.nPB;
@@ -364,7 +377,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         return PGL_OK;
     }
     if (pl.version == 6) {
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * (pl.nw6 + pl.PTW) * 2048 + 256;
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256;
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -496,15 +509,17 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
     return hipErrorInvalidValue;
 }
 
+// occ != nullptr: no launch, *occ = workgroups of this instantiation a CU holds with pl.lds bytes of LDS
 template <int KTW, int PTW, int MT, int NW>
-static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ)
 {
-    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * (NW + PTW) * 2048 + 256;
+    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256;
     if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
         auto kern = k_fused6<KTW, PTW, MT, NW>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
         if (e != hipSuccess) return e;
+        if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, NW * 64, pl.lds);
         hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NW * 64), pl.lds, s, fp);
         return hipGetLastError();
     } else {
@@ -513,37 +528,51 @@ static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStre
 }
 
 template <int PTW, int MT, int NW>
-static hipError_t launch_fused6_k(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused6_k(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ)
 {
     switch (pl.KTW) {
-    case 1: return launch_fused6_t<1, PTW, MT, NW>(pl, fp, s);
-    case 2: return launch_fused6_t<2, PTW, MT, NW>(pl, fp, s);
-    case 3: return launch_fused6_t<3, PTW, MT, NW>(pl, fp, s);
-    case 5: return launch_fused6_t<5, PTW, MT, NW>(pl, fp, s);
-    case 7: return launch_fused6_t<7, PTW, MT, NW>(pl, fp, s);
-    case 10: return launch_fused6_t<10, PTW, MT, NW>(pl, fp, s);
+    case 1: return launch_fused6_t<1, PTW, MT, NW>(pl, fp, s, occ);
+    case 2: return launch_fused6_t<2, PTW, MT, NW>(pl, fp, s, occ);
+    case 3: return launch_fused6_t<3, PTW, MT, NW>(pl, fp, s, occ);
+    case 5: return launch_fused6_t<5, PTW, MT, NW>(pl, fp, s, occ);
+    case 7: return launch_fused6_t<7, PTW, MT, NW>(pl, fp, s, occ);
+    case 10: return launch_fused6_t<10, PTW, MT, NW>(pl, fp, s, occ);
     }
     return hipErrorInvalidValue;
 }
 
-static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ = nullptr)
 {
     if (pl.nw6 == 4) {
         switch (pl.PTW * 4 + pl.mt) {
-        case 1 * 4 + 1: return launch_fused6_k<1, 1, 4>(pl, fp, s);
-        case 2 * 4 + 1: return launch_fused6_k<2, 1, 4>(pl, fp, s);
+        case 1 * 4 + 1: return launch_fused6_k<1, 1, 4>(pl, fp, s, occ);
+        case 2 * 4 + 1: return launch_fused6_k<2, 1, 4>(pl, fp, s, occ);
         }
         return hipErrorInvalidValue;
     }
     switch (pl.PTW * 4 + pl.mt) {
-    case 1 * 4 + 1: return launch_fused6_k<1, 1, 8>(pl, fp, s);
-    case 1 * 4 + 2: return launch_fused6_k<1, 2, 8>(pl, fp, s);
-    case 2 * 4 + 1: return launch_fused6_k<2, 1, 8>(pl, fp, s);
-    case 2 * 4 + 2: return launch_fused6_k<2, 2, 8>(pl, fp, s);
-    case 4 * 4 + 1: return launch_fused6_k<4, 1, 8>(pl, fp, s);
-    case 4 * 4 + 2: return launch_fused6_k<4, 2, 8>(pl, fp, s);
+    case 1 * 4 + 1: return launch_fused6_k<1, 1, 8>(pl, fp, s, occ);
+    case 1 * 4 + 2: return launch_fused6_k<1, 2, 8>(pl, fp, s, occ);
+    case 2 * 4 + 1: return launch_fused6_k<2, 1, 8>(pl, fp, s, occ);
+    case 2 * 4 + 2: return launch_fused6_k<2, 2, 8>(pl, fp, s, occ);
+    case 4 * 4 + 1: return launch_fused6_k<4, 1, 8>(pl, fp, s, occ);
+    case 4 * 4 + 2: return launch_fused6_k<4, 2, 8>(pl, fp, s, occ);
     }
     return hipErrorInvalidValue;
+}
+
+// workgroups per CU of the k_fused6 instantiation a plan selects (registers and LDS), cached per shape
+static int fused6_wg_per_cu(const Plan& pl)
+{
+    static int cache[11][5][3][9];             // [KTW][PTW][mt][nw6]; 0 = not asked yet
+    int& c = cache[pl.KTW][pl.PTW][pl.mt][pl.nw6];
+    if (c == 0) {
+        int occ = 0;
+        FusedParams fp{};
+        if (launch_fused6(pl, fp, nullptr, &occ) != hipSuccess || occ < 1) occ = (pl.nw6 == 4) ? 2 : 1;
+        c = occ;
+    }
+    return c;
 }
 
 template <int KT, int NWV>
@@ -696,8 +725,10 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
+    case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
+    case PGL_OPT_EPI_F64: h->opt_epi64 = value ? 1 : 0; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -1104,6 +1135,14 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.Fimg = (const unsigned char*)h->imgs[h->img_cur].buf.p;
     fp.img_tile0 = h->imgs[h->img_cur].tile0;
     fp.pidx = h->cur_pidx;
+    fp.theta = nullptr; fp.Weff = nullptr; fp.P = 1 + h->Dstim + h->Kimp;
+    fp.epi64 = h->opt_epi64 ? 2 : 0;
+}
+
+// kernels with register-resident Wmat fragments read theta / Weff themselves (no k_prep_w launch)
+static bool plan_reads_theta(const Plan& pl)
+{
+    return pl.version == 6 || (pl.version == 7 && pl.KS <= 40);
 }
 
 static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
@@ -1128,9 +1167,12 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
     if (nkt < 0) nkt = pl.KT;
     if (!stream) stream = h->stream;
     const long long nfrag = (long long)pl.nPT * nkt * 256;
-    int blocks = (int)((nfrag + 63) / 64);                // one block per 64 elements: its four waves share the chunks
-    if (with_ll) blocks += (pl.npost + 3) / 4;            // trailing blocks reduce ll and d ll / d bias
-    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, stream, (const double*)h->Gpart.p,
+    // one block per 64-element fragment, its waves share the chunks (>= 32 chunks = 16 KB per wave, at most 8 waves)
+    int nwf = h->opt_finw > 0 ? h->opt_finw : std::max(4, std::min(8, pl.nChunks / 32));
+    if (with_ll) nwf = std::max(nwf, 4);                  // the ll blocks reduce with 256 threads (pgl_reduce_ll)
+    int blocks = (int)((nfrag + 63) / 64);
+    if (with_ll) blocks += pl.npost;                      // trailing blocks (one per neuron) reduce ll and d ll / d bias
+    hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(64 * nwf), 0, stream, (const double*)h->Gpart.p,
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
                        sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
                        pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0, kt0,
@@ -1215,7 +1257,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (!sliced) {
         const Plan& pl = plans[0];
-        int rc = launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
+        const bool direct = plan_reads_theta(pl);
+        int rc = direct ? PGL_OK : launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
         if ((pl.version == 4 || pl.version == 5) && d_grad) {   // residual slab of the two-pass kernels
             const size_t need = (size_t)pl.nTiles * pl.nPT * 256 * 8;
@@ -1234,6 +1277,10 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         }
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
+        if (direct) {
+            fp.theta = d_theta;
+            fp.Weff = d_Weff;
+        }
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if (pl.version == 5 && d_grad) {
             // pass 1 | fork: the side stream reduces the first G half and ll while pass 2 runs (it is
@@ -1264,7 +1311,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
             if (rc) return rc;
         } else {
-            hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(64), 0, h->stream,
+            hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(256), 0, h->stream,
                                (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
                                pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
             HIPCHK(hipGetLastError());
@@ -1360,6 +1407,18 @@ int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double
     rc = enqueue_ll_grad(h, 0, count, d_theta, d_Weff, d_ll, d_grad);
     h->cur_pidx = nullptr;
     return rc;
+}
+
+int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int M, int P)
+{
+    if (!h || !d_H || !d_scale) return fail(PGL_ERR_ARG, "null argument");
+    if (M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad shape");
+    HIPCHK(hipSetDevice(h->device));
+    const long long PP = (long long)P * P;
+    const unsigned bx = (unsigned)std::min<long long>((PP + 256 * 8 - 1) / (256 * 8), 64);
+    hipLaunchKernelGGL(k_identity_rows, dim3(bx, (unsigned)M), dim3(256), 0, h->stream, d_H, d_scale, P);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
 }
 
 int pgl_sync(pgl_handle h)
@@ -1980,12 +2039,19 @@ int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col
 }  // extern "C"
 
 #ifdef PGL_PROF
-// dev builds only (tools/phase_profile.py): copy out the per-wave phase cycle sums of k_fused5
+// dev builds only (tools/phase_profile.py): copy out the per-wave phase cycle sums of k_fused5 / 6 / 7
 extern "C" int pgl_debug_prof(long long* out, int n_ll)
 {
-    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 2 * 4096 * 8 * 8);
+    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 2 * 4096 * 8 * 12);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pgl_prof), bytes, 0, hipMemcpyDeviceToHost));
+    return PGL_OK;
+}
+extern "C" int pgl_debug_prof_ts(long long* out, int n_ll)
+{
+    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 4096 * 4);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pgl_prof_ts), bytes, 0, hipMemcpyDeviceToHost));
     return PGL_OK;
 }
 #endif

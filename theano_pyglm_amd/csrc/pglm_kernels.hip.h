@@ -51,6 +51,36 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
                              // 4 = pgl_rate4 (fixed instruction order), 2 = pgl_rate_terms_n<2> only
 #endif
 
+#ifndef PGL_DMA_IL
+#define PGL_DMA_IL 1         // k_fused6 / k_fused7: the LDS-DMA pieces of the next tile go out BETWEEN the MFMAs of the forward
+                             // (k_fused7 with streamed Wmat: backward) loop instead of as a burst behind the "landed" barrier:
+                             // a wave waits ~500 cycles per piece for the CU's address path (phase profile, 3 workgroups per
+                             // CU: 3 000 of 11 600 cycles per tile and wave at C2) -- behind an MFMA that wait is free
+#endif
+#ifndef PGL_LDS1
+#define PGL_LDS1 1           // A-fragment reads of the resident-tile kernels as single ds_read_b64 (volatile: the compiler's
+                             // load/store optimizer otherwise pairs them into ds_read2_b64, which is served in 16-lane groups
+                             // with a 32-bank modulus at half the rate -- and the forward pattern col*RS + grp conflicts 2-way
+                             // there, SQ_LDS_BANK_CONFLICT = 4 cycles per read; ds_read_b64: 32-lane groups, 64 banks, no conflict)
+#endif
+__device__ __forceinline__ double pgl_lds_f64(const double* p)
+{
+#if PGL_LDS1
+    return *(const volatile __attribute__((address_space(3))) double*)p;
+#else
+    return *p;
+#endif
+}
+
+// Per-chunk partials of G: [post tile][k-tile][r][chunk][64 lanes] -- all chunk partials of one 64-element
+// fragment are contiguous (chunk stride 512 B), so the reduction over chunks (k_finalize) is a streaming read;
+// the fused kernels write one 512-byte piece per fragment at the end of their chunk.
+__device__ __forceinline__ double* pgl_gpart(double* G, const int pt, const int KT, const int kt0,
+                                             const int nChunks, const int chunk, const int lane)
+{
+    return G + (((size_t)pt * KT + kt0) * 4) * ((size_t)nChunks * 64) + (size_t)chunk * 64 + lane;
+}
+
 struct FusedParams {
     // problem
     long long nT;
@@ -89,7 +119,44 @@ struct FusedParams {
     int img_tile0;                       // first tile the resident images cover
     const int* __restrict__ pidx;        // post-synaptic neuron of local column j (null: n_lo + j) -- an
                                          // arbitrary subset of neurons per launch (pgl_ll_grad_list_dev)
+    // kernels that keep their Wmat fragments in registers (k_fused6, k_fused7 up to 40 k-steps) gather them
+    // straight from the caller's theta (npost, P) and Weff (Nall, Nall) -- no k_prep_w launch, no Wfrag round
+    // trip; null = read Wfrag / bias
+    const double* __restrict__ theta;
+    const double* __restrict__ Weff;
+    int P;
+    int epi64;                           // 2: all-f64 rate epilogue (PGL_OPT_EPI_F64), 0: default (see pgl_rate4)
 };
+
+// The Wmat B fragments (k-steps ks0 .. ks0 + NS - 1, lane group grp) of local post neuron nloc, as k_prep_w would
+// write them:  Wmat[k][n] = theta_n[1 + Dstim + k] * Weff[k / B][n]  (impulse columns),  theta_n[1 + k - Kimp]
+// (stimulus columns), k = 4 ks + grp.  Branch-free: every load goes to a clamped, always valid address and all
+// 2 NS loads are in flight together (one L2 / HBM latency per workgroup instead of one per k-step).
+template <int NS>
+__device__ __forceinline__ void pgl_wfrag_direct(const FusedParams& p, const int ks0, const int grp, const int nloc,
+                                                 const int nglob, const bool valid_n, double (&w)[NS])
+{
+    const double* row = p.theta + (size_t)(valid_n ? nloc : 0) * p.P;
+    const double* wcol = p.Weff + (valid_n ? nglob : 0);
+    const int imp0 = 1 + p.DsAll + p.np0 * p.B, st0 = 1 + p.ds0 - p.Kimp;
+    const float rB = 1.0f / (float)p.B;      // k / B for k < 2^20, B <= 8: (k + 0.5) / B is >= 1/16 away from an integer
+    double tv[NS], wv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * (ks0 + s) + grp;
+        const int kc = (k < p.Ktot) ? k : 0;
+        const bool imp = kc < p.Kimp;
+        const int npre = p.np0 + (int)(((float)(imp ? kc : 0) + 0.5f) * rB);
+        tv[s] = row[(imp ? imp0 : st0) + kc];
+        wv[s] = wcol[(size_t)npre * p.Nall];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * (ks0 + s) + grp;
+        const double v = (k < p.Kimp) ? tv[s] * wv[s] : tv[s];
+        w[s] = (valid_n && k < p.Ktot) ? v : 0.0;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // f64 elementary functions of the epilogue.  Hand-rolled (instead of the ocml calls)
@@ -188,14 +255,17 @@ __device__ __forceinline__ double pgl_log(const double v, const CP C)
 // standard_glm's bias ~ 20) log1p and 1/(1+e) come from their alternating series (error < e^6).
 template <int NE, typename CP>
 __device__ __forceinline__ void pgl_rate_terms_n(const double (&x)[NE], const double (&s)[NE],
-                                                 const int nlin, const double dt, double (&term)[NE],
+                                                 const int nlin_, const double dt, double (&term)[NE],
                                                  double (&res)[NE], const CP C)
 {
+    // nlin_: PGL_NLIN_* in bit 0; bit 1 set = all-f64 epilogue (PGL_OPT_EPI_F64: no single-precision correction)
+    const int nlin = nlin_ & 1;
+    const bool allf64 = (nlin_ & 2) != 0;
     // NE independent elements per lane are carried through every stage together: the Horner chains
     // are latency bound (dependent f64 FMAs), two of them interleave in the same issue slots
     if (nlin == 1) {
         double e[NE], l1p[NE], inv[NE], lam[NE], sig[NE];
-        bool small = true, spike = false, hi = (PGL_EPI_F32 != 0);
+        bool small = true, spike = false, hi = (PGL_EPI_F32 != 0) && !allf64;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             hi = hi && (x[i] > 12.0);
@@ -288,6 +358,15 @@ __device__ __forceinline__ void pgl_rate_terms_n(const double (&x)[NE], const do
 // per wave, cycles between the phase boundaries of a tile summed over the chunk.
 #ifdef PGL_PROF
 __device__ long long g_pgl_prof[2][4096][8][12];          // [pass-1][workgroup][wave][phase]
+__device__ long long g_pgl_prof_ts[4096][4];              // per workgroup: entry, loop start, loop end, exit (100 MHz ticks)
+#define PGL_PROF_ENTRY const long long prof_entry = __builtin_amdgcn_s_memrealtime();
+#define PGL_PROF_EXIT                                                                              \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                               \
+            g_pgl_prof_ts[blockIdx.x][0] = prof_entry;                                             \
+            g_pgl_prof_ts[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();                       \
+        }                                                                                          \
+    } while (0)
 #define PGL_PROF_DECL long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t = __builtin_amdgcn_s_memtime(); \
     const long long prof_rt0 = __builtin_amdgcn_s_memrealtime(), prof_t0 = prof_t;
 #define PGL_PROF_MARK(i)                                           \
@@ -302,8 +381,14 @@ __device__ long long g_pgl_prof[2][4096][8][12];          // [pass-1][workgroup]
         prof_acc[11] = __builtin_amdgcn_s_memrealtime() - prof_rt0;     /* 100 MHz ticks of the loop */  \
         if (lane == 0 && blockIdx.x < 4096)                                                   \
             for (int i_ = 0; i_ < 12; ++i_) g_pgl_prof[pass - 1][blockIdx.x][wave][i_] = prof_acc[i_]; \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                          \
+            g_pgl_prof_ts[blockIdx.x][1] = prof_rt0;                                          \
+            g_pgl_prof_ts[blockIdx.x][2] = prof_rt0 + prof_acc[11];                           \
+        }                                                                                     \
     } while (0)
 #else
+#define PGL_PROF_ENTRY
+#define PGL_PROF_EXIT
 #define PGL_PROF_DECL
 #define PGL_PROF_MARK(i)
 #define PGL_PROF_STORE(pass)
@@ -321,10 +406,12 @@ typedef double pgl_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) double* pgl_k_cdp;
 #define PGL_ROW __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (&sc)[4], const int nlin,
+__device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (&sc)[4], const int nlin_,
                                           const double dt, const pgl_k_cdp C, double* scratch,
                                           const int lane, double& term, double (&res)[4] PGL_PROF_ARGS)
 {
+    const int nlin = nlin_ & 1;                       // bit 1 of nlin_: all-f64 epilogue (PGL_OPT_EPI_F64)
+    const bool allf64 = (nlin_ & 2) != 0;
     double k[4], r[4], q[4], e[4];
     // every constant of the exp / series stages is requested up front: one scalar-memory wait
     double c[14];
@@ -334,7 +421,7 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
     double lam[4], sig[4];
     bool fastdone = false;
 #if PGL_EPI_F32
-    if (nlin == 1) {
+    if (nlin == 1 && !allf64) {
         // every element of the wave at x > 12 (the operating regime of standard_glm, bias ~ 20): exp(-x) < 6.2e-6
         // only enters lam = x + log1p(e) and sigmoid = 1/(1+e) as a correction that single precision resolves --
         // e = v_exp_f32(-x log2 e) (relative error ~1e-6: the f32 rounding of x in the exponent), so lam and the
@@ -911,7 +998,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 // pointer would turn every constant into a flat load
                 pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                 asm volatile("" : "+v"(Cl));
-                pgl_rate_terms_n<EPW>(xe, sc, p.nlin, p.dt, terme, rese, Cl);
+                pgl_rate_terms_n<EPW>(xe, sc, p.nlin | p.epi64, p.dt, terme, rese, Cl);
             }
 #pragma unroll
             for (int e = 0; e < EPW; ++e) {
@@ -959,11 +1046,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         p.llpart[slot * 64 + lane] = ll_acc;
         p.gbpart[slot * 64 + lane] = gb_acc;
         if (p.want_grad) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + (size_t)ksl * KTW) * 256 + lane;
+            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
             for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
         }
     }
@@ -1227,7 +1315,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
                 } else {
                     pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                     asm volatile("" : "+v"(Cl));
-                    pgl_rate_terms_n<2>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                    pgl_rate_terms_n<2>(xe, se, p.nlin | p.epi64, p.dt, terme, rese, Cl);
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -1271,11 +1359,12 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
         p.gbpart[slot * 64 + lane] = gb_acc;
     }
     if (active && p.want_grad) {
-        double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL) * 256 + lane;
+        double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, 0, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
         for (int kt = 0; kt < KTH; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
         }
     }
     } else {
@@ -1407,11 +1496,12 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
     }
 
     if (active) {
-        double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTH) * 256 + lane;
+        double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, KTH, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
         for (int kt = 0; kt < KTH; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+            for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
         }
     }
     }
@@ -1568,6 +1658,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int IMGL = pgl_img_bytes(KTL), IMGH = pgl_img_bytes(KTH);
     constexpr int KTG = (PASS == 1) ? KTL : KTH; // k-tiles of G this pass accumulates
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PGL_PROF_ENTRY
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1620,7 +1711,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         constexpr int DSTEP = (NS >= 2 * NRT) ? ((DSFULL < DSCAP) ? DSFULL : DSCAP) : 0;   // MFMAs between rounds
         double ar[PD];
 #pragma unroll
-        for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTG)) * RSG + 16 * (s % KTG)];
+        for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KTG)) * RSG + 16 * (s % KTG));
         auto round = [&](const int j) {
             if (j < NR0) {
                 pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
@@ -1638,7 +1729,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         for (int s = 0; s < NS; ++s) {
             if (PGL_PRIO && s == NS / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             const double a = ar[s % PD];
-            if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG)];
+            if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG));
             G[s % KTG] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTG], G[s % KTG], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             if (DSTEP > 0) {
@@ -1704,7 +1795,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 pgl_d2 wr[PW2];
                 double ar[PA];
                 auto afrag = [&](const int s) -> double {
-                    return (s < KSL) ? faL[4 * s] : faH[4 * (s - KSL)];
+                    return (s < KSL) ? pgl_lds_f64(faL + 4 * s) : pgl_lds_f64(faH + 4 * (s - KSL));
                 };
                 // scalar bases of the Wmat fragment stream, one per 4 KB (four pairs of k-steps)
                 pgl_glb_cd2p wr_base[KS_ALL / 8 + 1];
@@ -1758,7 +1849,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
                     const double* cg = PGL_C;
                     asm volatile("" : "+s"(cg));           // keeps the scalar loads inside the tile loop
-                    done = pgl_rate4(xs, scb, p.nlin, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
+                    done = pgl_rate4(xs, scb, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
                     if (done) {
                         ll_acc += term4;                    // lanes of padding neurons are never read back
 #pragma unroll
@@ -1788,7 +1879,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                         } else {
                             pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                             asm volatile("" : "+v"(Cl));
-                            pgl_rate_terms_n<ENE>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                            pgl_rate_terms_n<ENE>(xe, se, p.nlin | p.epi64, p.dt, terme, rese, Cl);
                         }
 #pragma unroll
                         for (int e = 0; e < ENE; ++e) {
@@ -1831,11 +1922,12 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             p.gbpart[slot * 64 + lane] = gb_acc;
         }
         if (active && p.want_grad) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL) * 256 + lane;
+            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, 0, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
             for (int kt = 0; kt < KTL; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
         }
     } else {
@@ -1874,14 +1966,16 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         }
         PGL_PROF_STORE(2);
         if (active) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + KTL) * 256 + lane;
+            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, KTL, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
             for (int kt = 0; kt < KTH; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
         }
     }
+    PGL_PROF_EXIT;
 }
 
 // ---------------------------------------------------------------------------
@@ -1909,6 +2003,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     constexpr int RS = pgl_img_rsh(KT_ALL);
     constexpr int IMG = pgl_img_bytes(KT_ALL);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PGL_PROF_ENTRY
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1923,8 +2018,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 
     unsigned char* bufs = smem;                                          // [2][MT][IMG]
     double* Xp = reinterpret_cast<double*>(smem + (size_t)2 * MT * IMG); // [MT][NW][4][64] partial currents
-    double* Rb = Xp + (size_t)MT * NW * 256;                             // [MT][PTW][4][64] residuals
-    double* Cs = Rb + (size_t)MT * PTW * 256;                            // [32] math constants
+    // residuals [MT][PTW][4][64]: they take the place of the k-slice-0 partials -- element (m, ptl, r, lane) of both
+    // is read (partial) and then written (residual) by the one wave that owns register r in the epilogue, and the
+    // next step's partials are only written behind the "landed" barrier, when every wave has read its residuals
+    double* Rb = Xp;
+    constexpr int RBS = NW;                                              // residual tile stride in 2 KB slots
+    double* Cs = Xp + (size_t)MT * NW * 256;                             // [32] math constants
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
     d4_t G[KTW];
@@ -1937,7 +2036,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     const int nloc = pt * 16 + col;
     const bool valid_n = active && (nloc < p.npost);
     const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
-    const double bias_l = valid_n ? p.bias[nloc] : 0.0;
+    const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : 0.0;
     const double* __restrict__ wrow =
         p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
     const int kcol0 = ksl * KTW * 16;
@@ -1965,7 +2064,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     double wreg[KSW];
 #pragma unroll
     for (int s = 0; s < KSW; ++s) wreg[s] = 0.0;
-    if (active) {
+    if (active && p.theta) {
+        pgl_wfrag_direct<KSW>(p, ksl * KSW, grp, nloc, nglob, valid_n, wreg);
+    } else if (active) {
         const pgl_d2* wr2 = reinterpret_cast<const pgl_d2*>(wrow);
 #pragma unroll
         for (int s2 = 0; s2 < KSW / 2; ++s2) {
@@ -1991,17 +2092,41 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     };
     load_counts(tile_beg);
     int par = 0;
+    PGL_PROF_DECL
     for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
         const unsigned char* cur = bufs + (size_t)par * MT * IMG;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces of the step landed
+        PGL_PROF_MARK(0);
         __syncthreads();                                  // ... everybody's; the other buffer is free
+        PGL_PROF_MARK(1);
         double sc[MT * EPW];
 #pragma unroll
         for (int i = 0; i < MT * EPW; ++i) sc[i] = (double)scn[i];
-        if (tile + MT < tile_end) {
+        // the images of the next step: PWV pieces of 1 KiB per wave, one every DS forward MFMAs (PGL_DMA_IL), the
+        // whole burst up front for waves without MFMA work
+        const bool more = tile + MT < tile_end;
+        unsigned char* const nxt = bufs + (size_t)(par ^ 1) * MT * IMG;
+        constexpr int NCH = IMG / 1024, PPI = (NCH + NW - 1) / NW, PWV = MT * PPI, NMF = MT * KSW;
+        constexpr int DS = (PGL_DMA_IL && NMF >= PWV) ? NMF / PWV : 0;
+        auto piece = [&](const int j) {
+            typedef __attribute__((address_space(1))) void gvoid;
+            typedef __attribute__((address_space(3))) void lvoid;
+            const int m = j / PPI, cc = (j % PPI) * NW + wave;
+            if (cc < NCH && tile + MT + m < tile_end) {
+                const unsigned char* gs = fimg + (size_t)(tile + MT + m) * IMG + (size_t)cc * 1024;
+                asm volatile("" : "+s"(gs));
+                __builtin_amdgcn_global_load_lds((gvoid*)(gs + lane * 16), (lvoid*)(nxt + (size_t)m * IMG + (size_t)cc * 1024),
+                                                 16, 0, 0);
+            }
+        };
+        if (more) {
             load_counts(tile + MT);
-            dma_step(tile + MT, bufs + (size_t)(par ^ 1) * MT * IMG);
+            if (DS == 0 || !active) {
+#pragma unroll
+                for (int j = 0; j < PWV; ++j) piece(j);
+            }
         }
+        PGL_PROF_MARK(2);
         // ---- forward over this wave's K slice, tile by tile ----
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -2012,23 +2137,33 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 constexpr int PA = (KSW < 4) ? KSW : 4;
                 double ar[PA];
 #pragma unroll
-                for (int s = 0; s < PA; ++s) ar[s] = fa[4 * s];
+                for (int s = 0; s < PA; ++s) ar[s] = pgl_lds_f64(fa + 4 * s);
 #pragma unroll
                 for (int s = 0; s < KSW; ++s) {
                     const double a = ar[s % PA];
-                    if (s + PA < KSW) ar[s % PA] = fa[4 * (s + PA)];
+                    if (s + PA < KSW) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
                     if (s & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
                     else
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (DS > 0) {
+                        constexpr int DSS = (DS > 0) ? DS : 1;
+                        const int q1 = m * KSW + s + 1;
+                        if (q1 % DSS == 0 && q1 / DSS <= PWV) {
+                            if (more) piece(q1 / DSS - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
             }
             double* xw = Xp + ((size_t)m * NW + wave) * 256 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) xw[r * 64] = acc0[r] + acc1[r];
         }
+        PGL_PROF_MARK(3);
         __syncthreads();
+        PGL_PROF_MARK(4);
         // ---- epilogue: sum of the KSPLIT partials + bias -> ll terms, residuals; the elements of all MT
         // tiles go through the rate chains together (independent chains interleave) ----
         if (active) {
@@ -2040,9 +2175,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 for (int e = 0; e < EPW; ++e) {
                     const int r = er[e];
                     double x = bias_l;
+                    if (emine) {                       // (the other half-wave's elements may already hold residuals)
 #pragma unroll
-                    for (int k2 = 0; k2 < KSPLIT; ++k2)
-                        x += Xp[((size_t)m * NW + ptl + PTW * k2) * 256 + r * 64 + lane];
+                        for (int k2 = 0; k2 < KSPLIT; ++k2)
+                            x += Xp[((size_t)m * NW + ptl + PTW * k2) * 256 + r * 64 + lane];
+                    }
                     const long long tg = (long long)(tile + m) * TT + grp + 4 * r;
                     vte[m * EPW + e] = valid_n && (tg < p.t_hi) && emine && (tile + m < tile_end);
                     xe[m * EPW + e] = x;
@@ -2050,7 +2187,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
             }
             pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
             asm volatile("" : "+v"(Cl));
-            pgl_rate_terms_n<MT * EPW>(xe, sc, p.nlin, p.dt, terme, rese, Cl);
+            pgl_rate_terms_n<MT * EPW>(xe, sc, p.nlin | p.epi64, p.dt, terme, rese, Cl);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -2058,11 +2195,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                     const double res = vte[m * EPW + e] ? rese[m * EPW + e] : 0.0;
                     ll_acc += vte[m * EPW + e] ? terme[m * EPW + e] : 0.0;
                     gb_acc += res;
-                    if (emine) Rb[((size_t)m * PTW + ptl) * 256 + er[e] * 64 + lane] = res;
+                    if (emine) Rb[((size_t)m * RBS + ptl) * 256 + er[e] * 64 + lane] = res;
                 }
             }
         }
+        PGL_PROF_MARK(5);
         __syncthreads();
+        PGL_PROF_MARK(6);
         // ---- backward on this wave's K slice ----
         if (active && p.want_grad) {
 #pragma unroll
@@ -2070,37 +2209,41 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 if (tile + m >= tile_end) break;
                 double rr[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rr[r] = Rb[((size_t)m * PTW + ptl) * 256 + r * 64 + lane];
+                for (int r = 0; r < 4; ++r) rr[r] = Rb[((size_t)m * RBS + ptl) * 256 + r * 64 + lane];
                 const double* fb = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + grp * RS + kcol0 + col;
                 constexpr int NS = 4 * KTW;
                 constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
                 double ar[PD];
 #pragma unroll
-                for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KTW)) * RS + 16 * (s % KTW)];
+                for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KTW)) * RS + 16 * (s % KTW));
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const double a = ar[s % PD];
-                    if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KTW)) * RS + 16 * ((s + PD) % KTW)];
+                    if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KTW)) * RS + 16 * ((s + PD) % KTW));
                     G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KTW], G[s % KTW], 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        PGL_PROF_MARK(7);
     }
+    PGL_PROF_STORE(1);
 
     if (active) {
         const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
         p.llpart[slot * 64 + lane] = ll_acc;
         p.gbpart[slot * 64 + lane] = gb_acc;
         if (p.want_grad) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT_ALL + (size_t)ksl * KTW) * 256 + lane;
+            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
             for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
         }
     }
+    PGL_PROF_EXIT;
 }
 
 // ---------------------------------------------------------------------------
@@ -2123,10 +2266,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     constexpr int IMG = pgl_img_bytes(KT);
     constexpr bool WREG = (KS <= 40);            // the wave's Wmat fragments stay in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef PGL_PROF
-    long long pgl_prof_dummy_acc[12] = {0};
-    long long pgl_prof_dummy_t = 0;
-#endif
+    PGL_PROF_ENTRY
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -2153,7 +2293,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     const bool valid_n = active && (nloc < p.npost);
     const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
     // padding lanes get a benign current: they must not push their wave out of the epilogue's series regime
-    const double bias_l = valid_n ? p.bias[nloc] : (p.nlin == 1 ? 30.0 : 0.0);
+    const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : (p.nlin == 1 ? 30.0 : 0.0);
     const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS * 64;
 
     const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
@@ -2162,7 +2302,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG;
 
     double wreg[WREG ? KS : 1];
-    if (WREG) {
+    if (WREG && p.theta) {
+        pgl_wfrag_direct<(WREG ? KS : 1)>(p, 0, grp, nloc, nglob, valid_n, wreg);
+    } else if (WREG) {
         const pgl_d2* wr2 = reinterpret_cast<const pgl_d2*>(wrow);
 #pragma unroll
         for (int s2 = 0; s2 < (WREG ? KS / 2 : 0); ++s2) {
@@ -2186,17 +2328,44 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     }
 
     int par = 0;
+    PGL_PROF_DECL
     for (int tile = tile_beg; tile < tile_end; ++tile, par ^= 1) {
         const int t0 = tile * TT;
         const unsigned char* cur = bufs + (size_t)par * IMG;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces landed, counts are here
+        PGL_PROF_MARK(0);
         __syncthreads();                                  // ... every wave's; the other buffer is free
+        PGL_PROF_MARK(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) scb[r] = scn[r];
-        if (tile + 1 < tile_end) {
+        // the image of the next tile: PWV pieces of 1 KiB per wave, issued between the MFMAs (PGL_DMA_IL) of the
+        // forward loop when the Wmat fragments live in registers -- with the streamed Wmat ring a DMA in flight
+        // would sit in front of the ring loads in the in-order vmcnt queue -- else of the backward loop; waves
+        // without that loop send the burst up front
+        const bool more = tile + 1 < tile_end;
+        unsigned char* const nxt = bufs + (size_t)(par ^ 1) * IMG;
+        constexpr int NCH = IMG / 1024, PWV = (NCH + NWV - 1) / NWV;
+        constexpr int DSF = (PGL_DMA_IL && WREG && KS >= PWV) ? KS / PWV : 0;                 // forward-loop spacing
+        constexpr int DSB = (PGL_DMA_IL && !WREG && 4 * KT >= 2 * PWV) ? (2 * KT) / PWV : 0;   // backward: first half
+        auto piece = [&](const int j) {
+            typedef __attribute__((address_space(1))) void gvoid;
+            typedef __attribute__((address_space(3))) void lvoid;
+            const int cc = j * NWV + wave;
+            if (cc < NCH) {
+                const unsigned char* gs = fimg + (size_t)(tile + 1) * IMG + (size_t)cc * 1024;
+                asm volatile("" : "+s"(gs));
+                __builtin_amdgcn_global_load_lds((gvoid*)(gs + lane * 16), (lvoid*)(nxt + (size_t)cc * 1024), 16, 0, 0);
+            }
+        };
+        const bool il_bwd = DSB > 0 && active && p.want_grad;
+        if (more) {
             load_counts(tile + 1, scn);
-            pgl_dma_img<KT, NWV>(fimg + (size_t)(tile + 1) * IMG, bufs + (size_t)(par ^ 1) * IMG, wave, lane);
+            if (!active || (DSF == 0 && !il_bwd)) {
+#pragma unroll
+                for (int j = 0; j < PWV; ++j) piece(j);
+            }
         }
+        PGL_PROF_MARK(2);
         if (!active) continue;
         // ---- forward over all K ----
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -2206,17 +2375,24 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             constexpr int PA = 4;
             double ar[PA];
 #pragma unroll
-            for (int s = 0; s < PA; ++s) ar[s] = fa[4 * s];
+            for (int s = 0; s < PA; ++s) ar[s] = pgl_lds_f64(fa + 4 * s);
             if constexpr (WREG) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const double a = ar[s % PA];
-                    if (s + PA < KS) ar[s % PA] = fa[4 * (s + PA)];
+                    if (s + PA < KS) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
                     if (s & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
                     else
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (DSF > 0) {
+                        constexpr int DSS = (DSF > 0) ? DSF : 1;
+                        if ((s + 1) % DSS == 0 && (s + 1) / DSS <= PWV) {
+                            if (more) piece((s + 1) / DSS - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
             } else {
                 const double* wr_s = wrow;
@@ -2230,7 +2406,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 for (int s = 0; s < KS; ++s) {
                     const double a = ar[s % PA];
                     const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
-                    if (s + PA < KS) ar[s % PA] = fa[4 * (s + PA)];
+                    if (s + PA < KS) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
                     if ((s & 1) && (s / 2 + PW2 < KS / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
                     if (s & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
@@ -2240,6 +2416,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 }
             }
         }
+        PGL_PROF_MARK(3);
         // ---- epilogue on the accumulator registers ----
         double rr[4];
         {
@@ -2250,7 +2427,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
                 const double* cg = PGL_C;
                 asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
-                done = pgl_rate4(xs, scb, p.nlin, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_DUMMY);
+                done = pgl_rate4(xs, scb, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
                 if (done) {
                     ll_acc += valid_n ? term4 : 0.0;
 #pragma unroll
@@ -2275,7 +2452,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                     }
                     pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
                     asm volatile("" : "+v"(Cl));
-                    pgl_rate_terms_n<2>(xe, se, p.nlin, p.dt, terme, rese, Cl);
+                    pgl_rate_terms_n<2>(xe, se, p.nlin | p.epi64, p.dt, terme, rese, Cl);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const double res = vte[e] ? rese[e] : 0.0;
@@ -2286,6 +2463,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 }
             }
         }
+        PGL_PROF_MARK(4);
         // ---- backward over all K ----
         if (p.want_grad) {
             const double* fb = reinterpret_cast<const double*>(cur) + grp * RS + col;
@@ -2293,30 +2471,41 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
             double ar[PD];
 #pragma unroll
-            for (int s = 0; s < PD; ++s) ar[s] = fb[(4 * (s / KT)) * RS + 16 * (s % KT)];
+            for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KT)) * RS + 16 * (s % KT));
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double a = ar[s % PD];
-                if (s + PD < NS) ar[s % PD] = fb[(4 * ((s + PD) / KT)) * RS + 16 * ((s + PD) % KT)];
+                if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KT)) * RS + 16 * ((s + PD) % KT));
                 G[s % KT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KT], G[s % KT], 0, 0, 0);
                 if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if (DSB > 0) {
+                    constexpr int DSS = (DSB > 0) ? DSB : 1;
+                    if ((s + 1) % DSS == 0 && (s + 1) / DSS <= PWV) {
+                        if (more) piece((s + 1) / DSS - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
+        PGL_PROF_MARK(5);
     }
+    PGL_PROF_STORE(1);
 
     if (active) {
         const size_t slot = (size_t)chunk * p.nPT + pt;
         p.llpart[slot * 64 + lane] = ll_acc;
         p.gbpart[slot * 64 + lane] = gb_acc;
         if (p.want_grad) {
-            double* gp = p.Gpart + (((size_t)chunk * p.nPT + pt) * KT) * 256 + lane;
+            double* gp = pgl_gpart(p.Gpart, pt, KT, 0, p.nChunks, chunk, lane);
+            const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * 64] = G[kt][r];
+                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
         }
     }
+    PGL_PROF_EXIT;
 }
 
 // ---------------------------------------------------------------------------
@@ -2359,7 +2548,56 @@ __global__ void k_prep_w(const double* __restrict__ theta, const double* __restr
 // finalize: deterministic reduction of the per-chunk partials, Weff chain rule,
 // scatter into the (npost, P) gradient layout
 // ---------------------------------------------------------------------------
-__global__ void k_finalize(const double* __restrict__ Gpart, const double* __restrict__ llpart,
+// ll_n and d ll_n / d bias of neuron n: all threads of the block stride over the (chunk, k-slice wave, lane group)
+// partials with four independent sums each, fixed-order butterfly + fixed-order combination of the waves --
+// deterministic for a given launch geometry.  (One wave walking the partials alone is a serial chain of
+// nChunks * nsub / 16 dependent global loads: 150 us for the 1 250 chunks of a 4-neuron population.)
+__device__ __forceinline__ void pgl_reduce_ll(const double* __restrict__ llpart, const double* __restrict__ gbpart,
+                                              double* __restrict__ ll_out, double* __restrict__ grad_out,
+                                              const int n, const int P, const int nPT, const int nChunks,
+                                              const int nsub, double (*red)[64])
+{
+    // always the first 256 threads of the block, whatever its size: the ll of an ll-only call (k_finalize_ll) and of
+    // an ll+grad call (trailing blocks of k_finalize) are then the same sums in the same order, bit for bit
+    const int nthr = 256, t = (int)threadIdx.x, lane = t & 63, w = t >> 6, nw = 4;
+    const int pt = n >> 4, col = n & 15;
+    const int per = 4 * nsub;
+    const int total = nChunks * per;
+    double sl[4] = {0.0, 0.0, 0.0, 0.0}, sg[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = t; i0 < total && t < nthr; i0 += 4 * nthr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j * nthr;
+            if (i < total) {
+                const int c = i / per, g = i - c * per;
+                const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
+                sl[j] += llpart[idx];
+                sg[j] += gbpart[idx];
+            }
+        }
+    }
+    double a = (sl[0] + sl[1]) + (sl[2] + sl[3]), b = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0 && w < nw) {
+        red[w][0] = a;
+        red[w][1] = b;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double x = 0.0, y = 0.0;
+        for (int j = 0; j < nw; ++j) {
+            x += red[j][0];
+            y += red[j][1];
+        }
+        ll_out[n] = x;
+        if (grad_out != nullptr) grad_out[(size_t)n * P] = y;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ Gpart, const double* __restrict__ llpart,
                            const double* __restrict__ gbpart, const double* __restrict__ Weff,
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
@@ -2367,39 +2605,24 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
                            int nkt, const int* __restrict__ pidx)
 {
     // reduces the k-tiles [kt0, kt0 + nkt) of every post tile (the two halves of the two-pass
-    // kernels are reduced by separate launches: the first one runs beside pass 2)
+    // kernels are reduced by separate launches: the first one runs beside pass 2).
+    // A block of blockDim.x / 64 waves (1 .. 16) owns one 64-element fragment of G: its chunk partials are one
+    // contiguous run of nChunks x 512 bytes (pgl_gpart), the waves take consecutive pieces of it.
     const int P = 1 + DsAll + Nall * B;
+    const int nwf = (int)(blockDim.x >> 6);
     const long long nfrag = (long long)nPT * nkt * 256;
-    const int gblocks = (int)((nfrag + 63) / 64);          // one block per 64 G elements, its four waves share the chunks
+    const int gblocks = (int)((nfrag + 63) / 64);
+    __shared__ double red[16][64];
     if ((int)blockIdx.x >= gblocks) {
-        // trailing blocks: ll_n and d ll_n / d bias (one wave per neuron), when the caller folded the
+        // trailing blocks: ll_n and d ll_n / d bias (one block per neuron), when the caller folded the
         // ll reduction into this launch (nsub > 0) -- it then runs beside the G reduction
         if (nsub <= 0) return;
-        const int n = ((int)blockIdx.x - gblocks) * 4 + (int)(threadIdx.x >> 6);
+        const int n = (int)blockIdx.x - gblocks;
         if (n >= npost) return;
-        const int lane = threadIdx.x & 63;
-        const int pt = n >> 4, col = n & 15;
-        const int per = 4 * nsub;
-        const int total = nChunks * per;
-        double sl = 0.0, sg = 0.0;
-        for (int i = lane; i < total; i += 64) {
-            const int c = i / per, g = i - c * per;
-            const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
-            sl += llpart[idx];
-            sg += gbpart[idx];
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            sl += __shfl_xor(sl, o, 64);
-            sg += __shfl_xor(sg, o, 64);
-        }
-        if (lane == 0) {
-            ll_out[n] = sl;
-            if (grad_out != nullptr) grad_out[(size_t)n * P] = sg;
-        }
+        pgl_reduce_ll(llpart, gbpart, ll_out, grad_out, n, P, nPT, nChunks, nsub, red);
         return;
     }
     if (grad_out == nullptr) return;
-    __shared__ double red[4][64];
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
     const long long gid = blockIdx.x * 64LL + lane;
     const int r = (int)((gid >> 6) & 3);
@@ -2411,24 +2634,24 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
     double s = 0.0;
     if (live) {
         // wave w sums the chunks [c0, c1) with eight interleaved partial sums (eight loads in flight per
-        // lane); the four waves' sums are combined in a fixed order: deterministic for a given geometry
-        const int per = (nChunks + 3) / 4;
+        // lane); the waves' sums are combined in a fixed order: deterministic for a given geometry
+        const int per = (nChunks + nwf - 1) / nwf;
         const int c0 = w * per, c1 = (c0 + per < nChunks) ? c0 + per : nChunks;
-        const size_t cstride = (size_t)nPT * KT * 256;
-        const double* gp = Gpart + (size_t)pt * KT * 256 + (size_t)(kt * 4 + r) * 64 + lane;
+        const double* gp = Gpart + (((size_t)pt * KT + kt) * 4 + r) * ((size_t)nChunks * 64) + lane;
         double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int c = c0;
         for (; c + 8 <= c1; c += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] += gp[(size_t)(c + j) * cstride];
+            for (int j = 0; j < 8; ++j) a[j] += gp[(size_t)(c + j) * 64];
         }
-        for (int j = 0; c < c1; ++c, ++j) a[j] += gp[(size_t)c * cstride];
+        for (int j = 0; c < c1; ++c, ++j) a[j] += gp[(size_t)c * 64];
         s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     red[w][lane] = s;
     __syncthreads();
     if (w == 0 && live) {
-        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        s = 0.0;
+        for (int j = 0; j < nwf; ++j) s += red[j][lane];
         if (k < Kimp) {
             const int npre = np0 + k / B;
             grad_out[(size_t)n * P + 1 + DsAll + np0 * B + k] = s * Weff[(size_t)npre * Nall + (pidx ? pidx[n] : n_lo + n)];
@@ -2438,34 +2661,17 @@ __global__ void k_finalize(const double* __restrict__ Gpart, const double* __res
     }
 }
 
-// ll_n and d ll_n / d bias: one wave per neuron, lanes stride over the (chunk, lane-group)
-// partials, fixed-order butterfly -> deterministic for a given launch geometry
-__global__ __launch_bounds__(64) void k_finalize_ll(const double* __restrict__ llpart,
-                                                    const double* __restrict__ gbpart,
-                                                    double* __restrict__ ll_out,
-                                                    double* __restrict__ grad_out, int P, int npost,
-                                                    int nPT, int nChunks, int nsub)
+// ll-only evaluations: one block per neuron
+__global__ __launch_bounds__(256) void k_finalize_ll(const double* __restrict__ llpart,
+                                                     const double* __restrict__ gbpart,
+                                                     double* __restrict__ ll_out,
+                                                     double* __restrict__ grad_out, int P, int npost,
+                                                     int nPT, int nChunks, int nsub)
 {
+    __shared__ double red[16][64];
     const int n = blockIdx.x;
     if (n >= npost) return;
-    const int pt = n >> 4, col = n & 15;
-    const int per = 4 * nsub;
-    const int total = nChunks * per;
-    double sl = 0.0, sg = 0.0;
-    for (int i = threadIdx.x; i < total; i += 64) {
-        const int c = i / per, g = i - c * per;
-        const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
-        sl += llpart[idx];
-        sg += gbpart[idx];
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        sl += __shfl_xor(sl, o, 64);
-        sg += __shfl_xor(sg, o, 64);
-    }
-    if (threadIdx.x == 0) {
-        ll_out[n] = sl;
-        if (grad_out != nullptr) grad_out[(size_t)n * P] = sg;
-    }
+    pgl_reduce_ll(llpart, gbpart, ll_out, grad_out, n, P, nPT, nChunks, nsub, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -3676,6 +3882,21 @@ __global__ __launch_bounds__(256) void k_sta_finish(const double* __restrict__ p
 }
 
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
+// Rows m of a batch of square matrices H (M, P, P) with scale[m] != 0 become scale[m] * identity; the other rows are
+// not touched (their blocks exit at once).  Lock-step BFGS: "restart this neuron from steepest descent" / "scale the
+// initial inverse Hessian by s.y / y.y" without a pass over the whole batch and without telling the host which rows
+// (inference/batched_bfgs.py).
+__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ H, const double* __restrict__ scale, int P)
+{
+    const int m = blockIdx.y;
+    const double d = scale[m];
+    if (d == 0.0) return;
+    const long long PP = (long long)P * P;
+    double* Hm = H + (size_t)m * PP;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < PP; i += (long long)gridDim.x * 256)
+        Hm[i] = (i / P == i % P) ? d : 0.0;
+}
+
 __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restrict__ ST,
                                long long nT, int N)
 {

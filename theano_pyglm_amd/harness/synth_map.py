@@ -1,7 +1,10 @@
 """
 MAP fit on synthetic data -- counterpart of test/synth_map.py + test/synth_harness.py.
 
-    python -m theano_pyglm_amd.harness.synth_map -d data.pkl -r out_dir [-m standard_glm] [--batched]
+    python -m theano_pyglm_amd.harness.synth_map -d data.pkl -r out_dir [-m standard_glm] [--sequential]
+
+The sweep over the neurons runs as the GPU lock-step optimizer by default (inference/batched_bfgs.py);
+--sequential (batched=False) is the reference's loop of per-neuron scipy fits.
 """
 import argparse
 import os
@@ -30,7 +33,7 @@ def initialize_test_harness(model_name, data, data_dir=None):
     return popn, popn_true, x_true
 
 
-def run_synth_test(model_name, data, results_dir, data_dir=None, batched=False, rng=None):
+def run_synth_test(model_name, data, results_dir, data_dir=None, batched=None, rng=None):
     """test/synth_map.py:10-32."""
     popn, popn_true, x_true = initialize_test_harness(model_name, data, data_dir)
     x0 = popn.sample(rng)
@@ -51,11 +54,12 @@ def main():
     ap.add_argument('-m', '--model', default='standard_glm')
     ap.add_argument('-d', '--dataFile', required=True)
     ap.add_argument('-r', '--resultsDir', default='.')
-    ap.add_argument('--batched', action='store_true')
+    ap.add_argument('--sequential', action='store_true', help='per-neuron scipy fits (the reference loop)')
     args = ap.parse_args()
     with open(args.dataFile, 'rb') as f:
         data = pickle.load(f)
-    run_synth_test(args.model, data, args.resultsDir, os.path.dirname(args.dataFile), args.batched)
+    run_synth_test(args.model, data, args.resultsDir, os.path.dirname(args.dataFile),
+                   False if args.sequential else None)
 
 
 if __name__ == '__main__':

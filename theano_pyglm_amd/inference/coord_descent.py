@@ -12,8 +12,9 @@ For standard_glm-like models (constant weights, complete graph) the N per-neuron
 are independent, so `fit_glms_batched` advances all of them in lock-step:
 one fused device pass per iteration evaluates ll and gradient of every neuron at its own
 trial point.  `coord_descent(..., batched=True)` uses it (optimizer state in numpy),
-`batched='torch'` keeps the optimizer state on the GPU (inference/batched_bfgs.py); the
-default reproduces the reference's sequential sweep.
+`batched='torch'` keeps the optimizer state on the GPU (inference/batched_bfgs.py) and is what
+the default (batched=None) selects whenever the model's packing is served; batched=False
+reproduces the reference's sequential sweep of scipy fits.
 """
 import copy
 
@@ -208,9 +209,21 @@ def fit_glms_batched(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, v
     return f, it, n_evals
 
 
-def coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=False, verbose=False):
-    """coord_descent.py:206-266."""
+def resolve_batched(population, batched):
+    """batched=None (the default of coord_descent and the harness): the GPU lock-step optimizer whenever the
+    model's packing is served (batched_bfgs.supported), else the reference's sequential per-neuron scipy fits;
+    False / True / 'torch' force the sequential / numpy lock-step / GPU lock-step sweep."""
+    if batched is None:
+        from theano_pyglm_amd.inference.batched_bfgs import supported
+        return 'torch' if supported(population) else False
+    return batched
+
+
+def coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=None, verbose=False):
+    """coord_descent.py:206-266.  `batched`: see resolve_batched (None = automatic; batched=False is the
+    reference's sweep of N sequential scipy BFGS fits, kept for comparison)."""
     N = population.model['N']
+    batched = resolve_batched(population, batched)
     network = population.network
     if not isinstance(network.graph, CompleteGraphModel):
         print(" WARNING: MAP inference via coordinate descent can only be performed "

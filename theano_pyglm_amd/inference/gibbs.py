@@ -376,12 +376,7 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         `cols`: the post-synaptic columns to resample (default all; a rank's shard in multi-GPU runs)."""
         pop = self.population
         N = pop.N
-        if len(pop.data_sequences) != 1:
-            for n in (range(N) if cols is None else cols):
-                self.update(x, n)
-            return x
-        pop.set_data(pop.data_sequences[0])
-        h = pop._handle(pop._current)
+        h = _SequenceSum(pop)
         cols = np.arange(N) if cols is None else np.asarray(cols, dtype=int)
         nc = len(cols)
         A = np.array(x['net']['graph']['A']).reshape(N, N)
@@ -446,10 +441,7 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         The per-pair host work is kept to scalar arithmetic (16 384 pairs per sweep at N = 128)."""
         pop = self.population
         N = pop.N
-        if len(pop.data_sequences) != 1:
-            raise Exception("device-resident column update supports one data sequence")
-        pop.set_data(pop.data_sequences[0])
-        h = pop._handle(pop._current)
+        h = _SequenceSum(pop)
         A = np.asarray(x['net']['graph']['A'])
         W = np.asarray(x['net']['weights']['W'], dtype=float).reshape(N, N)
         xn = x['glms'][n_post]
@@ -503,6 +495,48 @@ class CollapsedGibbsNetworkColumnUpdate(object):
         x['net']['graph']['A'] = A
         x['net']['weights']['W'] = W.ravel()
         return stats
+
+
+class _SequenceSum(object):
+    """The device state of the collapsed column update for ALL data sequences of a population: the inner ll
+    is the sum over `population.data_sequences` (gibbs.py:899-903, 931-935) -- one resident handle per
+    sequence, every prepare / rank-1 update applied to each of them, the (columns x weights) ll blocks added."""
+
+    def __init__(self, population):
+        if not population.data_sequences:
+            raise Exception("No data sequence has been added")
+        self.hs = []
+        for data in population.data_sequences:
+            population.set_data(data)
+            self.hs.append(population._handle(data))
+
+    def gibbs_prepare_all(self, theta, Weff):
+        for h in self.hs:
+            h.gibbs_prepare_all(theta, Weff)
+
+    def gibbs_ll_cols(self, n_post, n_pre, aw_cur, w):
+        out = self.hs[0].gibbs_ll_cols(n_post, n_pre, aw_cur, w)
+        for h in self.hs[1:]:
+            out = out + h.gibbs_ll_cols(n_post, n_pre, aw_cur, w)
+        return out
+
+    def gibbs_update_cols(self, n_post, n_pre, delta):
+        for h in self.hs:
+            h.gibbs_update_cols(n_post, n_pre, delta)
+
+    def gibbs_prepare(self, n_post, theta_n, weff_col):
+        for h in self.hs:
+            h.gibbs_prepare(n_post, theta_n, weff_col)
+
+    def gibbs_ll(self, n_pre, aw_cur, w):
+        out = self.hs[0].gibbs_ll(n_pre, aw_cur, w)
+        for h in self.hs[1:]:
+            out = out + h.gibbs_ll(n_pre, aw_cur, w)
+        return out
+
+    def gibbs_update(self, n_pre, delta):
+        for h in self.hs:
+            h.gibbs_update(n_pre, delta)
 
 
 def initialize_updates(population, rng=None, w_sampler='ars'):

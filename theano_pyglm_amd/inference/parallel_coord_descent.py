@@ -111,15 +111,24 @@ def _time_sharded_sweeps(population, x, maxiter, atol, verbose):
     return x
 
 
-def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched='torch', verbose=False,
-                           shard='neurons'):
+NARROW_SHARD = 64      # neurons per rank below which the time split is the default (a 16-neuron
+                       # shard of a 128-neuron population runs at a third of the 128-wide MFMA rate)
+
+
+def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=None, verbose=False,
+                           shard=None):
     """parallel_coord_descent.py:57-156.  Call on every rank of an initialised process group with the
     same x0 (e.g. drawn from the same seed); without a process group this is coord_descent.
-    shard: 'neurons' (the reference's split) or 'time' (see the module docstring; needs batched='torch')."""
+    shard: 'neurons' (the reference's split), 'time' (see the module docstring; needs the GPU lock-step
+    optimizer) or None = 'time' when a rank's neuron block would be narrower than NARROW_SHARD neurons
+    and the lock-step optimizer serves the model, else 'neurons'."""
     N = population.N
     world, rank = PL.world_rank()
+    batched = cd.resolve_batched(population, batched)
     if world == 1:
         return cd.coord_descent(population, x0=x0, maxiter=maxiter, atol=atol, batched=batched, verbose=verbose)
+    if shard is None:
+        shard = 'time' if (batched == 'torch' and N // world < NARROW_SHARD) else 'neurons'
     if shard == 'time':
         if x0 is None:
             raise ValueError("parallel_coord_descent needs the same x0 on every rank")

@@ -9,7 +9,13 @@ from theano_pyglm_amd import _lib
 rows = []
 
 
+import os
+ONLY = [t for t in os.environ.get('CFG_ONLY', '').split(',') if t]    # e.g. CFG_ONLY="C2 standard_glm,C5 spatio"
+
+
 def run(name, N, T, ibasis, kind, Dstim=0, kernel=0, n_hi=None):
+    if ONLY and not any(name.startswith(t) for t in ONLY):
+        return
     nT = int(round(T / 0.001))
     p = H.Problem(N, nT, ibasis, kind=kind, Dstim=Dstim, seed=1234, w_scale=0.5 if kind == 'explinear' else 0.02)
     dev = p.device()

@@ -20,9 +20,11 @@ data = {'S': S, 'N': N, 'dt': dt, 'T': T, 'stim': None, 'dt_stim': 0.1}
 t0 = time.time(); popn.add_data(data); print("add_data %.2fs" % (time.time() - t0))
 x0 = popn.sample(np.random.RandomState(0))
 lp0 = popn.compute_log_p(x0)
-t0 = time.time()
-x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched={'torch': 'torch', 'numpy': True, 'seq': False}[mode],
-                     verbose=False)
-wall = time.time() - t0
+for rep in range(3):
+    t0 = time.time()
+    x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1,
+                         batched={'torch': 'torch', 'numpy': True, 'seq': False, 'default': None}[mode], verbose=False)
+    wall = time.time() - t0
+    print("MAP sweep %d mode=%s N=%d T=%gs: wall %.3f s  %s" % (rep, mode, N, T, wall, getattr(popn, 'last_fit_stats', None)))
 lp1 = popn.compute_log_p(x)
-print("MAP sweep mode=%s N=%d T=%gs: wall %.2f s, log p %.3f -> %.3f" % (mode, N, T, wall, lp0, lp1))
+print("log p %.3f -> %.3f" % (lp0, lp1))

@@ -43,8 +43,32 @@ def pmc(dbs, out):
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def timeline(db, out, last=40):
+    """Per-dispatch timeline of the last `last` kernel dispatches: start (us, relative), duration, gap to the end of
+    the previous dispatch on the device, queue/stream -- shows what is exposed between the kernels of one evaluation."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    name = 'name' if 'name' in cols else 'kernel_name'
+    extra = [k for k in ('stream_id', 'queue_id', 'stream') if k in cols]
+    q = "select %s, start, end%s from kernels order by start" % (name, ''.join(', ' + k for k in extra))
+    rows = list(c.execute(q))
+    rows = rows[-last:]
+    t0 = rows[0][1]
+    with open(out, 'w') as f:
+        f.write("# last %d kernel dispatches: start_us,dur_us,gap_after_prev_end_us,stream,kernel\n" % len(rows))
+        prev_end = None
+        for r in rows:
+            nm, st, en = r[0], r[1], r[2]
+            gap = (st - prev_end) / 1e3 if prev_end is not None else 0.0
+            f.write("%.1f,%.1f,%.1f,%s,%s\n" % ((st - t0) / 1e3, (en - st) / 1e3, gap,
+                                               '/'.join(str(x) for x in r[3:]), nm[:60]))
+            prev_end = en if prev_end is None else max(prev_end, en)
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'timeline':
+        timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2:-1], sys.argv[-1])

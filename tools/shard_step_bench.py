@@ -7,6 +7,7 @@ sys.path.insert(0, '.')
 from theano_pyglm_amd import _lib, parallel as PL
 import bench
 
+import os
 Gs = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 N, dt = 128, 0.001
 S = bench.make_workload(N, 600.0, dt, seed=1234 + 3)
@@ -19,6 +20,7 @@ theta = np.zeros((N, P)); theta[:, 0] = 20.0 + 0.1 * rng.standard_normal(N)
 theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
 dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt)
 dev.set_spikes(S); dev.set_basis(ib)
+if os.environ.get('FINW'): dev.set_option(97, int(os.environ['FINW']))      # finalize waves per fragment (A/B)
 _st = torch.cuda.Stream(); torch.cuda.set_stream(_st)      # handle 0 (default stream) cannot be named
 dev.set_stream(_st.cuda_stream)
 d_theta = torch.from_numpy(theta).cuda(); d_W = torch.ones((N, N), dtype=torch.float64, device='cuda')
