@@ -125,14 +125,16 @@ def map_wall_clock(S, N, dt):
     x0 = popn.sample(np.random.RandomState(0))
     lp0 = popn.compute_log_p(x0)
     walls = []
-    for rep in range(2):        # the first sweep also pays torch's lazy rocBLAS / kernel loading
+    assert cd.resolve_batched(popn, None) == 'torch'
+    for rep in range(3):        # the first sweep also pays the feature-tile build and torch's lazy rocBLAS / kernel loading
         t0 = time.perf_counter()
-        x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+        x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)      # default path (GPU lock-step optimizer)
         walls.append(time.perf_counter() - t0)
     lp1 = popn.compute_log_p(x)
     popn.release_data()
-    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": walls[1],
-            "first_call_s": walls[0],
+    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": min(walls[1:]),
+            "first_call_s": walls[0], "sweeps_s": walls,
+            "path": "coord_descent default (batched=None -> GPU lock-step optimizer)",
             "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
             "bfgs_iterations": getattr(popn, 'last_fit_stats', {}).get('iterations'),
             "ll_grad_evaluations": getattr(popn, 'last_fit_stats', {}).get('evaluations'),
@@ -141,7 +143,8 @@ def map_wall_clock(S, N, dt):
             "neurons_stalled": getattr(popn, 'last_fit_stats', {}).get('stalled'),
             "neurons_at_maxiter": getattr(popn, 'last_fit_stats', {}).get('maxiter'),
             "optimizer": "lock-step batched BFGS (per-neuron line-search state machines, one launch per pending trial of "
-                         "all active neurons), maxiter 225, gtol 1e-5, GPU-resident state on one stream"}
+                         "the listed neurons, active set read back two launches late: no host sync per launch), initial "
+                         "inverse-Hessian scaling s.y/y.y, maxiter 225, gtol 1e-5, GPU-resident state on one stream"}
 
 
 def mcmc_inner_ll(S, N, dt):
@@ -298,6 +301,12 @@ def main():
 
     import torch
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()         # (does not initialise the GPU)
+    if not args.debug_single_device and (ndev < world or local_rank >= ndev):
+        # fail loudly on every rank BEFORE any rendezvous: a missing GPU must not turn into a hung collective
+        sys.stderr.write("bench.py: rank %d needs GPU %d of %d ranks but only %d device(s) are visible\n"
+                         % (rank, local_rank, world, ndev))
+        sys.exit(3)
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n"
@@ -364,9 +373,14 @@ def main():
     assert torch.cuda.current_stream().cuda_stream == bench_stream.cuda_stream != 0
     dev.set_stream(bench_stream.cuda_stream)
 
+    coll_events = []                      # (start, end) events around the collective of every timed step
+
     def step(record):
         dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr(),
                         n_lo, n_hi)
+        if world > 1 and record and not args.debug_single_device:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(bench_stream)
         if world > 1:
             if args.debug_single_device:         # gloo: collectives on host copies
                 dev.sync()
@@ -383,6 +397,10 @@ def main():
                 dist.all_reduce(d_out)               # population (ll, grad) on every rank
             else:
                 dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB)
+            if record and not args.debug_single_device:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record(bench_stream)
+                coll_events.append((ev0, ev1))
 
     for _ in range(args.warmup):
         step(False)
@@ -397,6 +415,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device='cpu' if args.debug_single_device else 'cuda')
@@ -404,7 +423,16 @@ def main():
         elapsed = float(t.item())
 
     info = dev.info(n_lo, n_hi)
-    n_timed, kern_ms, _ = dev.timing_summary(reset=True)
+    n_timed, kern_ms, call_ms = dev.timing_summary(reset=True)
+    per_rank = None
+    if world > 1:
+        # what every rank paid per step: its own wall clock, its fused kernels, its whole evaluation (prep + fused +
+        # finalize) and the collective (HIP events on the stream; includes waiting for the slowest rank)
+        coll_ms = float(np.mean([a.elapsed_time(b) for a, b in coll_events])) if coll_events else None
+        mine = {"rank": rank, "ms_per_step": 1e3 * local_elapsed / args.steps, "kernel_ms": kern_ms,
+                "evaluation_ms": call_ms, "collective_ms": coll_ms, "bins": int(t_hi - t_lo), "neurons": int(n_hi - n_lo)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     alt = None
     if world == 1 and not args.f32_features and info['kernel_version'] == 5:
         # the same evaluation with the features regenerated from the spike events inside the kernel
@@ -422,6 +450,28 @@ def main():
                "kernel_ms": alt_ms, "achieved": info['flops'] / (alt_ms * 1e-3) / 1e12,
                "frac": info['flops'] / (alt_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
         dev.set_option(_lib.OPT_KERNEL, 0)
+    allf64 = None
+    if world == 1 and not args.f32_features:
+        # the same evaluation with the all-f64 rate epilogue (PGL_OPT_EPI_F64: no single-precision exp(-x)
+        # correction), so that the effect of that term is visible beside every headline number
+        dev.set_option(_lib.OPT_EPI_F64, 1)
+        for _ in range(3):
+            step(False)
+        torch.cuda.synchronize()
+        dev.timing_summary(reset=True)
+        for _ in range(10):
+            step(False)
+        torch.cuda.synchronize()
+        _, f64_ms, _ = dev.timing_summary(reset=True)
+        ll_f64 = d_ll.cpu().numpy().copy()
+        dev.set_option(_lib.OPT_EPI_F64, 0)
+        step(False)
+        torch.cuda.synchronize()
+        dev.timing_summary(reset=True)
+        ll_def = d_ll.cpu().numpy()
+        allf64 = {"kernel_ms": f64_ms, "achieved": info['flops'] / (f64_ms * 1e-3) / 1e12,
+                  "frac": info['flops'] / (f64_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                  "max_rel_ll_diff_vs_default": float(np.max(np.abs(ll_f64 - ll_def) / np.abs(ll_f64)))}
     assert n_timed == min(args.steps, 256), "timing window does not cover the timed steps" 
     achieved = info['flops'] / (kern_ms * 1e-3) / 1e12
     ll_host = d_ll.cpu().numpy()
@@ -489,6 +539,10 @@ def main():
         }
         if alt is not None:
             out["roofline"]["alt_in_kernel_features"] = alt
+        if allf64 is not None:
+            out["roofline"]["all_f64_epilogue"] = allf64
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
             tr = pmc_traffic(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if tr is not None:

@@ -1693,6 +1693,9 @@ int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff)
     ENSURE(h->Weff, (size_t)N * N * 8);
     HIPCHK(hipMemcpyAsync(h->gtheta.p, theta, (size_t)N * P * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->Weff.p, Weff, (size_t)N * N * 8, hipMemcpyHostToDevice, h->stream));
+    // the caller's (pageable) theta / Weff may be temporaries that die when this call returns: the uploads
+    // must have left host memory by then, whatever the runtime does with pageable sources
+    HIPCHK(hipStreamSynchronize(h->stream));
     // forward-only launches of the K-split kernel: GX[t][n] = sum_slices F_s . W_s (stimulus columns
     // included), the same phase 1 as the sliced ll+grad path
     const std::vector<Slice> slices = make_slices(h);
@@ -1808,7 +1811,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     GibbsColsParams gp;
     if (h->nlin == PGL_NLIN_EXPLINEAR && h->opt_gibbs != 1) {
         // regime-split path: rate terms by k_gibbs_rate_cols (single precision for the log1p term where
-        // |x| > 12, compacted f64 elsewhere), spike terms from the event lists
+        // |x| >= 8, compacted f64 elsewhere), spike terms from the event lists
         int max_ev = 0;
         rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8, true, &max_ev);
         if (rc) return rc;
@@ -1831,12 +1834,13 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
                             (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
                            (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gibbs_rate_cols),
+        auto rate_kernel = k_gibbs_rate_cols;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rate_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
         hipLaunchKernelGGL(k_gibbs_cols_setup, dim3((ncols * h->Rk + 255) / 256), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_gibbs_rate_cols, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
+        hipLaunchKernelGGL(rate_kernel, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
@@ -2049,7 +2053,7 @@ extern "C" int pgl_debug_prof(long long* out, int n_ll)
 }
 extern "C" int pgl_debug_prof_ts(long long* out, int n_ll)
 {
-    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 4096 * 4);
+    const size_t bytes = std::min((size_t)n_ll * 8, sizeof(long long) * 4096 * 5);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pgl_prof_ts), bytes, 0, hipMemcpyDeviceToHost));
     return PGL_OK;

@@ -358,13 +358,15 @@ __device__ __forceinline__ void pgl_rate_terms_n(const double (&x)[NE], const do
 // per wave, cycles between the phase boundaries of a tile summed over the chunk.
 #ifdef PGL_PROF
 __device__ long long g_pgl_prof[2][4096][8][12];          // [pass-1][workgroup][wave][phase]
-__device__ long long g_pgl_prof_ts[4096][4];              // per workgroup: entry, loop start, loop end, exit (100 MHz ticks)
+__device__ long long g_pgl_prof_ts[4096][5];              // per workgroup: entry, loop start, loop end, exit (100 MHz ticks), XCC / SE / CU id
 #define PGL_PROF_ENTRY const long long prof_entry = __builtin_amdgcn_s_memrealtime();
 #define PGL_PROF_EXIT                                                                              \
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                               \
             g_pgl_prof_ts[blockIdx.x][0] = prof_entry;                                             \
             g_pgl_prof_ts[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();                       \
+            g_pgl_prof_ts[blockIdx.x][4] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16) | \
+                                           (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11));   \
         }                                                                                          \
     } while (0)
 #define PGL_PROF_DECL long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t = __builtin_amdgcn_s_memtime(); \
@@ -3161,15 +3163,16 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 
 // ---------------------------------------------------------------------------
 // Regime-split form of the batched inner ll (explinear only).  softplus(x) = max(x,0) + log1p(exp(-|x|)):
-//   * |x| > 12 (the operating regime: bias ~ 20, and the deeply inhibited bins behind a presynaptic spike
-//     for the negative quadrature nodes): the log1p term is < 6.2e-6 and only needs single precision --
-//     e = v_exp_f32(-|x| log2 e), log1p(e) = e (1 - e/2) (+O(e^3) < 8e-17); its absolute error
-//     (<= 1e-6 relative to itself: the f32 rounding of |x| <= 700 in the exponent) is <= 6e-12 of a bin
-//     whose rate is >= 12, or of a rate term < 6.2e-6 next to the spike terms.  ~10 instructions per
-//     evaluation instead of ~55 of the f64 exp + log1p.
-//   * |x| < 12 ("band", ~13 % of the evaluations at C4), |x| >= 700 (lam underflows: reference NaN
-//     semantics), inf and NaN: the f64 path, on COMPACTED lanes -- band elements are queued per wave in LDS
-//     with their weight index and evaluated 64 at a time.
+//   * |x| >= 8 (the operating regime: bias ~ 20, and the deeply inhibited bins behind a presynaptic spike
+//     for the negative quadrature nodes; 91 % of the evaluations at C4): the log1p term is < 3.4e-4 and only
+//     needs single precision -- e = v_exp_f32(-|x| log2 e), log1p(e) = e (1 - e/2 + e^2/3) (+O(e^4) < 3.2e-15);
+//     its error (<= 5e-7 relative to itself: the f32 rounding of |x| in the exponent) is <= 1.7e-10 absolute
+//     = 2e-11 of a bin whose rate is >= 8, or of a rate term < 3.4e-4 next to the spike terms
+//     (PGL_GFAST_HI; round 2 switched at |x| = 12: 6e-12, 87 %).  ~10 instructions per evaluation instead of
+//     ~55 of the f64 exp + log1p.
+//   * |x| < 8 ("band", 8.6 % of the evaluations at C4: |x| is uniformly distributed below 12, tools/gibbs_x_hist.py),
+//     |x| >= 700 (lam underflows: reference NaN semantics), inf and NaN: the f64 path, on COMPACTED lanes -- band
+//     elements are queued per wave in LDS with their weight index and evaluated 64 at a time.
 //   * S*log(lam) only exists at the spike bins of n_post (2 % of the bins): k_gibbs_spike_cols walks the
 //     event list of the post-synaptic neuron instead of testing every bin.
 // Lanes of a wave are 64 consecutive bins of one column; a wave keeps x0 / ic of its bins in registers
@@ -3179,6 +3182,13 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 //   part[blk][c][k] = sum_t lam_k(t)   (k_gibbs_reduce_cols2 applies -dt and adds the spike terms)
 // ---------------------------------------------------------------------------
 #define PGL_GRB 256           // bins per sub-block
+#ifndef PGL_GFAST_HI
+#define PGL_GFAST_HI 0x40200000u   // high word of the double 8.0: from |x| >= 8 the log1p(exp(-|x|)) <= 3.4e-4 term of the softplus
+                                   // comes from the single-precision hardware exp: its relative error (<= 5e-7: the f32 rounding of
+                                   // |x| in the exponent, 1 ulp of v_exp_f32) is <= 1.7e-10 absolute in a bin whose rate is >= 8
+                                   // (2e-11 relative; round 2 used |x| >= 12, 6e-12 absolute).  8.6 % of the evaluations at C4 stay on
+                                   // the compacted f64 path instead of 13.3 % (tools/gibbs_x_hist.py: |x| is uniform below 12)
+#endif
 #define PGL_GQ 256            // band-queue entries per wave (the band elements of one weight: <= 4 x 64)
 
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
@@ -3338,17 +3348,17 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                 for (int sg = 0; sg < 4; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
-                    // fast regime: 12 <= |x| < 700, read off the high word of |x| (monotonic for non-negative
+                    // fast regime: PGL_GFAST <= |x| < 700, read off the high word of |x| (monotonic for non-negative
                     // doubles; NaN, inf and |x| >= 700 fall outside and take the f64 path)
                     const unsigned hx = (unsigned)__double2hiint(x[sg]) & 0x7fffffffu;
-                    const bool f = (hx - 0x40280000u) < (0x4085e000u - 0x40280000u);
+                    const bool f = (hx - PGL_GFAST_HI) < (0x4085e000u - PGL_GFAST_HI);
                     fl[sg] = f && vl[sg];
                     bl[sg] = !f && vl[sg];
                 }
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
                     const float e = __builtin_amdgcn_exp2f((float)fabs(x[sg]) * -1.44269504088896340736f);
-                    corr[sg] = e * fmaf(e, -0.5f, 1.0f);
+                    corr[sg] = e * fmaf(e, fmaf(e, 0.33333334f, -0.5f), 1.0f);     // log1p(e), e <= 3.4e-4: e^4/4 < 3.2e-15
                 }
                 double accl = 0.0;
                 float accc = 0.0f;

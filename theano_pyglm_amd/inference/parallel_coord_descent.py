@@ -47,11 +47,42 @@ def parallel_compute_log_p(population, x, shard='neurons'):
     N = population.N
     world, rank = PL.world_rank()
     if shard == 'time' and world > 1:
-        lp_n = np.zeros(N)
-        for data in population.data_sequences:
-            population.set_data(data)
-            lp_n += population.compute_ll_vector(x)
-        lp_n = PL.allreduce_sum(lp_n, _device_of(population))
+        if population._time_shard != (rank, world):
+            raise RuntimeError("parallel_compute_log_p(shard='time') needs Population.set_time_shard(rank, world) to be "
+                               "active: without it every rank evaluates the whole recording and the all-reduce returns "
+                               "world_size times the log likelihood")
+        dev = _device_of(population)
+        if dev is not None:
+            # device path (RCCL): the per-neuron ll of every data sequence stays in HBM, is summed there and
+            # all-reduced there; one small copy to the host at the end
+            import torch
+            with torch.cuda.device(dev):
+                theta = torch.from_numpy(population.theta_matrix(x)).to(dev)
+                Weff = torch.from_numpy(np.ascontiguousarray(population.W_eff(x), dtype=np.float64)).to(dev)
+                tot = torch.zeros(N, dtype=torch.float64, device=dev)
+                ll = torch.empty(N, dtype=torch.float64, device=dev)
+                st = torch.cuda.Stream(dev)
+                st.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(st):
+                    for data in population.data_sequences:
+                        population.set_data(data)
+                        h = population._handle(data)
+                        h.set_stream(st.cuda_stream)
+                        try:
+                            h.ll_grad_dev(theta.data_ptr(), Weff.data_ptr(), ll.data_ptr(), 0)
+                            tot += ll
+                        finally:
+                            h.sync()
+                            h.set_stream(None)
+                    PL.allreduce_sum_t(tot)
+                    st.synchronize()
+                lp_n = tot.cpu().numpy()
+        else:
+            lp_n = np.zeros(N)
+            for data in population.data_sequences:
+                population.set_data(data)
+                lp_n += population.compute_ll_vector(x)
+            lp_n = PL.allreduce_sum(lp_n, None)
         for n in range(N):
             population._check_vars(x, n)
             lp_n[n] += population.glm.log_prior(x['glms'][n])
@@ -80,7 +111,12 @@ def gather_glms(population, x, lo, hi):
     for n in range(lo, hi):
         rows.append(packdict(get_vars(syms, x['glms'][n]))[0])
     rows = np.array(rows).reshape(hi - lo, v0.size)
-    full = PL.gather_glm_params(rows, N, _device_of(population))
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64))
+    dev = _device_of(population)
+    if dev is not None:
+        t = t.to(dev)                           # RCCL all-gather on the rank's own GPU; one copy back below
+    full = PL.allgather_rows_t(t, N).cpu().numpy()
     for n in range(N):
         if not (lo <= n < hi):
             set_vars(syms, x['glms'][n], unpackdict(full[n].copy(), shapes))

@@ -111,6 +111,10 @@ class Population(object):
             h.set_basis(imp.ibasis)
             if self.glm.Dstim > 0:
                 if data.get('fstim', None) is not None:
+                    if getattr(self.glm.bkgd_model, 'separable', False):
+                        raise ValueError("data['fstim'] (dense stimulus features) cannot be used with the separable "
+                                         "stimulus path: theta rows carry [w_t, w_x] there; drop 'fstim' (the features are "
+                                         "built from data['stim'] on the device) or set model['bkgd']['separable'] = False")
                     h.set_stim_features(data['fstim'])      # caller-supplied dense features
                 else:
                     self.glm.bkgd_model.upload(h, data)     # built on the device from data['stim']
@@ -155,11 +159,20 @@ class Population(object):
         return self._handle(data).get_stim_features()
 
     def release_data(self, data=None):
-        """Free the device buffers of one data sequence (or of all of them)."""
+        """Free the device buffers of one data sequence (or of all of them).
+
+        Ownership: the population keeps a strong reference to every data dict it has been conditioned on
+        (`add_data`, `set_data`, and internally every evaluation on a held-out dict) together with its device
+        handle -- spikes, event index and up to three sets of resident feature tiles (3 GB at N=128, T=600 s) --
+        until this method is called; the reference's shared variables are simply overwritten by the next
+        set_data (glm.py:99-110).  Transient data sets (cross-validation splits, initialisation populations)
+        should be released explicitly, as harness/synth_map_with_xv.py and inference/gibbs.py do."""
         keep = []
         for d, h in self._handles:
             if data is None or d is data:
                 h.close()
+                if self._current is d:
+                    self._current = None
             else:
                 keep.append((d, h))
         self._handles = keep

@@ -11,6 +11,7 @@ from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
 src = sys.argv[3] if len(sys.argv) > 3 else 'poisson'
+sigma = float(sys.argv[4]) if len(sys.argv) > 4 else None          # override of the impulse prior sigma (template: 0.001)
 nT = int(round(T / 0.001))
 if src == 'model':
     from theano_pyglm_amd.harness.generate_synth_data import make_dataset
@@ -23,20 +24,24 @@ else:
     rng = np.random.default_rng(1234 + 5)
     S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
     stim = np.random.RandomState(1234 + 5).randn(nT // 100, 3)
-    popn = Population(make_model('spatiotemporal_glm', N=N, dt=0.001))
+    model = make_model('spatiotemporal_glm', N=N, dt=0.001)
+    if sigma is not None:
+        model['impulse']['sigma'] = sigma
+    popn = Population(model)
     popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': T, 'stim': stim, 'dt_stim': 0.1})
 x0 = popn.sample(np.random.RandomState(7))
+res_b = {}
 for scaling in (True, False):
     xb = copy.deepcopy(x0)
     t0 = time.time()
     nlp_b, iters, evals = fit_glms_batched_torch(popn, xb, init_scaling=scaling)
     print("lock-step init_scaling=%s: %.2f s  %s" % (scaling, time.time() - t0, popn.last_fit_stats))
-    if scaling:
-        keep = (nlp_b.copy(), copy.deepcopy(xb))
-nlp_b, xb = keep
+    res_b[scaling] = (nlp_b.copy(), copy.deepcopy(xb))
+print("sum nlp: scaling %.6f  no scaling %.6f" % (res_b[True][0].sum(), res_b[False][0].sum()))
+nlp_b, xb = res_b[False]
 prms = cd.prep_first_order_glm_inference(popn)
 for n in (0, N // 3, 2 * N // 3, N - 1):
-    for mi in (225, 3000):
+    for mi in (225, 1000):
         xs = copy.deepcopy(x0)
         nv = popn.extract_vars(xs, n)
         t0 = time.time()

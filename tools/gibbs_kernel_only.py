@@ -21,6 +21,18 @@ cols = np.arange(N)
 pre = (cols * 37 + 11) % N
 ws = np.tile(np.concatenate((np.sqrt(2) * np.polynomial.hermite.hermgauss(10)[0], [0.0])), (N, 1))
 aw = (A * W)[pre, cols]
-for _ in range(6):
-    ll = dev.gibbs_ll_cols(cols, pre, aw, ws)
-print(np.isfinite(ll).mean())
+import time
+from theano_pyglm_amd import _lib
+res = {}
+for opt in (1, 0, 1, 0):
+    dev.set_option(_lib.OPT_GIBBS_KERNEL, opt)
+    for _ in range(3):
+        ll = dev.gibbs_ll_cols(cols, pre, aw, ws)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ll = dev.gibbs_ll_cols(cols, pre, aw, ws)
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    res[opt] = ll
+    print("PGL_OPT_GIBBS_KERNEL=%d: %.3f ms per launch of %d pairs x %d weights, finite %.3f" % (opt, ms, N, ws.shape[1], np.isfinite(ll).mean()))
+fin = np.isfinite(res[0]) & np.isfinite(res[1])
+print("max rel diff regime-split vs all-f64: %.2e" % np.max(np.abs(res[0][fin] - res[1][fin]) / np.abs(res[1][fin])))

@@ -50,10 +50,11 @@ for i, nm in enumerate(names):
     print("  %-18s mean %8.0f  (%4.1f %%)  min %8.0f max %8.0f" % (nm, d[:, :, i].mean(), 100 * d[:, :, i].mean() / tot.mean(),
                                                                d[:, :, i].min(), d[:, :, i].max()))
 
-ts = np.zeros((4096, 4), dtype=np.int64)
+ts = np.zeros((4096, 5), dtype=np.int64)
 lib.pgl_debug_prof_ts.argtypes = [C.c_void_p, C.c_int]
 if lib.pgl_debug_prof_ts(ts.ctypes.data_as(C.c_void_p), ts.size) == 0:
-    ts = ts[:nblk].astype(float) / 100.0                      # us
+    hw = ts[:nblk, 4].copy()
+    ts = ts[:nblk, :4].astype(float) / 100.0                  # us
     t0 = ts[:, 0].min()
     print("workgroup timeline (us, relative to the first entry): entry mean %.1f max %.1f | entry->loop mean %.1f max %.1f | "
           "loop mean %.1f | loop end->exit mean %.1f max %.1f | last exit %.1f"
@@ -63,3 +64,18 @@ if lib.pgl_debug_prof_ts(ts.ctypes.data_as(C.c_void_p), ts.size) == 0:
     q = [0, nblk // 4, nblk // 2, 3 * nblk // 4, nblk - 1]
     print("entry time quantiles (us):", ["%.1f" % (ts[order[i], 0] - t0) for i in q],
           " exit time quantiles:", ["%.1f" % (np.sort(ts[:, 3])[i] - t0) for i in q])
+    # where did the slow workgroups run?  XCC id (HW_REG_XCC_ID) and SE / CU id (HW_REG_HW_ID bits 15:13 / 11:8)
+    xcc, hwid = hw >> 16, hw & 0xffff
+    se, cu = (hwid >> 13) & 7, (hwid >> 8) & 15
+    dur = ts[:, 3] - ts[:, 0]
+    print("exit-entry per XCC: " + "  ".join("x%d: n=%d mean %.1f max %.1f" % (x, (xcc == x).sum(), dur[xcc == x].mean(), dur[xcc == x].max())
+                                               for x in np.unique(xcc)))
+    key = xcc * 1000 + se * 16 + cu
+    per_cu = {}
+    for k, d_ in zip(key, dur):
+        per_cu.setdefault(int(k), []).append(d_)
+    cnt = np.array([len(v) for v in per_cu.values()])
+    mx = np.array([max(v) for v in per_cu.values()])
+    print("distinct CUs %d; workgroups per CU: %s; mean of the per-CU max duration by count: %s"
+          % (len(per_cu), dict(zip(*np.unique(cnt, return_counts=True))),
+             {int(c): round(float(mx[cnt == c].mean()), 1) for c in np.unique(cnt)}))
