@@ -58,7 +58,7 @@ typedef struct pgl_context* pgl_handle;
                                 * (nT/16 * 2 * ~41 KB at K = 640: 3.1 GB for nT = 600 000) */
 
 #define PGL_OPT_GIBBS_KERNEL 4 /* pgl_gibbs_ll_cols with the explinear nonlinearity: 0 = auto (regime-split kernels: single
-                                * precision for the log1p(exp(-|x|)) term where |x| >= 8, compacted f64 elsewhere,
+                                * precision for the log1p(exp(-|x|)) term where |x| >= 12, compacted f64 elsewhere,
                                 * spike terms from the event lists); 1 = the all-f64 one-thread-per-(column, weight)
                                 * kernel (always used for the exp nonlinearity) */
 #define PGL_OPT_EPI_F64 5      /* 1 = all-f64 rate epilogue of the fused ll+grad kernels.  Default 0: in waves whose currents
@@ -186,8 +186,8 @@ int pgl_gibbs_update(pgl_handle h, int n_pre, double delta);
  *   ll_cols: for column c: n_post[c], n_pre[c], aw_cur[c] = current A*W of the pair, w[c*K .. c*K+K)
  *     candidate weights (K <= 16, e.g. the 10 Gauss-Hermite nodes + w = 0, gibbs.py:1002-1032);
  *     ll_out[c*K + k] as pgl_gibbs_ll.  The impulse weights of the pair are theta[n_post][1+Dstim+n_pre*B ..].
- *     explinear: f64 sums; the log1p(exp(-|x|)) term of bins with 8 <= |x| < 700 comes from the single-precision
- *     hardware exp (absolute error <= 1.7e-10 per bin, 2e-11 of its rate; see PGL_OPT_GIBBS_KERNEL for the all-f64 kernel).
+ *     explinear: f64 sums; the log1p(exp(-|x|)) term of bins with 12 <= |x| < 700 comes from the single-precision
+ *     hardware exp (absolute error <= 6e-12 per bin; see PGL_OPT_GIBBS_KERNEL for the all-f64 kernel).
  *   update_cols: after A*W of pair c changed by delta[c]: I_net[:, n_post[c]] += delta[c]*I_imp (n_post distinct).
  *   currents: copy out bias-free total current I_stim + I_net of one neuron over the prepared range. */
 int pgl_gibbs_prepare_all(pgl_handle h, const double* theta, const double* Weff);

@@ -486,7 +486,15 @@ def test_map_lockstep_matches_sequential_c3_subset():
 def test_map_lockstep_matches_sequential_c5_subset():
     """C5 (spatiotemporal_glm, N=64, T=300 s, D_stim=3): the GPU lock-step optimizer on the packing
     [bias, w_t, w_x, w_ir] (bkgd.py:214-227; chain rule through vec(w_t (x) w_x) in torch) against sequential
-    reference-style scipy fits (fit_glm, coord_descent.py:161-204) for four neurons."""
+    reference-style scipy fits (fit_glm, coord_descent.py:161-204) for four neurons.
+
+    The template's impulse prior N(0, 0.001) (precision 1e6 on 192 of the 199 coordinates, next to curvatures of
+    O(1e3 - 1e4)) makes the problem so badly scaled that NEITHER optimizer converges within the reference's
+    maxiter = 225 (scipy: "Maximum number of iterations", gradient still O(10 - 100)), so the objectives cannot agree
+    to the 1e-6 of the well-conditioned configurations (C2 / C3 tests above); measured: the lock-step value is
+    2e-5 - 6e-5 BELOW scipy's after 225 iterations and 1e-4 - 2e-4 above scipy's precision-loss stop after ~300.
+    Asserted: one-sided 1e-4 / two-sided 1e-3 at equal maxiter, and that a longer lock-step run keeps descending to
+    scipy's best value."""
     from theano_pyglm_amd.inference import coord_descent as cd
     from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch, supported
     N, nT = 64, 300000
@@ -497,23 +505,31 @@ def test_map_lockstep_matches_sequential_c5_subset():
     assert supported(popn) and cd.resolve_batched(popn, None) == 'torch'
     popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': stim, 'dt_stim': 0.1})
     x0 = popn.sample(np.random.RandomState(7))
+    lp0, _ = popn.compute_lp_grad_packed(x0)
     xb = copy.deepcopy(x0)
     nlp_b, iters, evals = fit_glms_batched_torch(popn, xb)
     st = popn.last_fit_stats
     print("C5 lock-step BFGS:", st)
     assert st['converged_gtol'] + st['stalled'] + st['maxiter'] == N
-    assert st['converged_gtol'] >= N - 4
-    prms = cd.prep_first_order_glm_inference(popn)
-    xs = copy.deepcopy(x0)
-    for n in (0, 21, 42, 63):
-        nv = popn.extract_vars(xs, n)
-        res = cd.fit_glm(nv, n, prms)
-        assert abs(res.fun - nlp_b[n]) <= 1e-6 * abs(res.fun), (n, res.fun, nlp_b[n], st)
-        g = popn.compute_grad(xb, n)
-        assert np.max(np.abs(g)) < 1e-3
-    # the state dict carries the optimum in the model's own variables
+    assert np.all(nlp_b < -lp0)                               # every neuron improved on its starting point
+    # the state dict carries the result in the model's own variables, consistent with the device objective
     assert xb['glms'][5]['bkgd']['w_t'].shape == (popn.glm.bkgd_model.Bt,)
     assert np.isclose(-np.sum(nlp_b) + popn.network.log_p(xb['net']), popn.compute_log_p(xb), rtol=1e-10)
+    prms = cd.prep_first_order_glm_inference(popn)
+    xs = copy.deepcopy(x0)
+    best = {}
+    for n in (0, 21, 42, 63):
+        nv = popn.extract_vars(xs, n)
+        res = cd.fit_glm(nv, n, prms)                         # maxiter 225, like the reference
+        assert nlp_b[n] <= res.fun + 1e-4 * abs(res.fun), (n, res.fun, nlp_b[n], st)
+        assert abs(nlp_b[n] - res.fun) <= 1e-3 * abs(res.fun), (n, res.fun, nlp_b[n], st)
+        nv2 = popn.extract_vars(copy.deepcopy(x0), n)
+        best[n] = cd.fit_glm(nv2, n, prms, maxiter=1500).fun   # until scipy stops by itself (~300 iterations)
+    # a longer lock-step run of the same four neurons ends at or below scipy's own best value
+    for n, fbest in best.items():
+        xl = copy.deepcopy(x0)
+        nlp_l, _, _ = fit_glms_batched_torch(popn, xl, maxiter=1500, n_lo=n, n_hi=n + 1)
+        assert nlp_l[0] <= fbest + 1e-6 * abs(fbest), (n, fbest, nlp_l[0], popn.last_fit_stats)
     popn.release_data()
 
 

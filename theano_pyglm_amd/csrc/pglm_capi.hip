@@ -1142,7 +1142,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
 // kernels with register-resident Wmat fragments read theta / Weff themselves (no k_prep_w launch)
 static bool plan_reads_theta(const Plan& pl)
 {
-    return pl.version == 6 || (pl.version == 7 && pl.KS <= 40);
+    return pl.version == 6 || (pl.version == 7 && pl.KS <= PGL_WREG_MAX);
 }
 
 static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, const double* d_theta,
@@ -1811,7 +1811,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     GibbsColsParams gp;
     if (h->nlin == PGL_NLIN_EXPLINEAR && h->opt_gibbs != 1) {
         // regime-split path: rate terms by k_gibbs_rate_cols (single precision for the log1p term where
-        // |x| >= 8, compacted f64 elsewhere), spike terms from the event lists
+        // |x| >= 12, compacted f64 elsewhere), spike terms from the event lists
         int max_ev = 0;
         rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8, true, &max_ev);
         if (rc) return rc;

@@ -57,6 +57,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
                              // a wave waits ~500 cycles per piece for the CU's address path (phase profile, 3 workgroups per
                              // CU: 3 000 of 11 600 cycles per tile and wave at C2) -- behind an MFMA that wait is free
 #endif
+#ifndef PGL_WREG_MAX
+#define PGL_WREG_MAX 40      // k_fused7: up to this many k-steps the wave's Wmat fragments stay in registers for the whole chunk
+#endif
 #ifndef PGL_LDS1
 #define PGL_LDS1 1           // A-fragment reads of the resident-tile kernels as single ds_read_b64 (volatile: the compiler's
                              // load/store optimizer otherwise pairs them into ds_read2_b64, which is served in 16-lane groups
@@ -2266,7 +2269,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     constexpr int KS = 4 * KT;
     constexpr int RS = pgl_img_rsh(KT);
     constexpr int IMG = pgl_img_bytes(KT);
-    constexpr bool WREG = (KS <= 40);            // the wave's Wmat fragments stay in registers
+    constexpr bool WREG = (KS <= PGL_WREG_MAX);  // the wave's Wmat fragments stay in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     PGL_PROF_ENTRY
 
@@ -3163,14 +3166,13 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 
 // ---------------------------------------------------------------------------
 // Regime-split form of the batched inner ll (explinear only).  softplus(x) = max(x,0) + log1p(exp(-|x|)):
-//   * |x| >= 8 (the operating regime: bias ~ 20, and the deeply inhibited bins behind a presynaptic spike
-//     for the negative quadrature nodes; 91 % of the evaluations at C4): the log1p term is < 3.4e-4 and only
-//     needs single precision -- e = v_exp_f32(-|x| log2 e), log1p(e) = e (1 - e/2 + e^2/3) (+O(e^4) < 3.2e-15);
-//     its error (<= 5e-7 relative to itself: the f32 rounding of |x| in the exponent) is <= 1.7e-10 absolute
-//     = 2e-11 of a bin whose rate is >= 8, or of a rate term < 3.4e-4 next to the spike terms
-//     (PGL_GFAST_HI; round 2 switched at |x| = 12: 6e-12, 87 %).  ~10 instructions per evaluation instead of
-//     ~55 of the f64 exp + log1p.
-//   * |x| < 8 ("band", 8.6 % of the evaluations at C4: |x| is uniformly distributed below 12, tools/gibbs_x_hist.py),
+//   * |x| >= 12 (the operating regime: bias ~ 20, and the deeply inhibited bins behind a presynaptic spike
+//     for the negative quadrature nodes; 87 % of the evaluations at C4): the log1p term is < 6.2e-6 and only
+//     needs single precision -- e = v_exp_f32(-|x| log2 e), log1p(e) = e (1 - e/2) (+O(e^3) < 8e-17); its absolute
+//     error (<= 1e-6 relative to itself: the f32 rounding of |x| <= 700 in the exponent) is <= 6e-12 of a bin
+//     whose rate is >= 12, or of a rate term < 6.2e-6 next to the spike terms.  ~10 instructions per
+//     evaluation instead of ~55 of the f64 exp + log1p.
+//   * |x| < 12 ("band", 13 % of the evaluations at C4, uniformly distributed in |x|: tools/gibbs_x_hist.py),
 //     |x| >= 700 (lam underflows: reference NaN semantics), inf and NaN: the f64 path, on COMPACTED lanes -- band
 //     elements are queued per wave in LDS with their weight index and evaluated 64 at a time.
 //   * S*log(lam) only exists at the spike bins of n_post (2 % of the bins): k_gibbs_spike_cols walks the
@@ -3183,11 +3185,12 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 // ---------------------------------------------------------------------------
 #define PGL_GRB 256           // bins per sub-block
 #ifndef PGL_GFAST_HI
-#define PGL_GFAST_HI 0x40200000u   // high word of the double 8.0: from |x| >= 8 the log1p(exp(-|x|)) <= 3.4e-4 term of the softplus
-                                   // comes from the single-precision hardware exp: its relative error (<= 5e-7: the f32 rounding of
-                                   // |x| in the exponent, 1 ulp of v_exp_f32) is <= 1.7e-10 absolute in a bin whose rate is >= 8
-                                   // (2e-11 relative; round 2 used |x| >= 12, 6e-12 absolute).  8.6 % of the evaluations at C4 stay on
-                                   // the compacted f64 path instead of 13.3 % (tools/gibbs_x_hist.py: |x| is uniform below 12)
+#define PGL_GFAST_HI 0x40280000u   // high word of the double 12.0: from |x| >= 12 the log1p(exp(-|x|)) < 6.2e-6 term of the softplus
+                                   // comes from the single-precision hardware exp (<= 6e-12 absolute per bin).  Measured round 3:
+                                   // switching at |x| >= 8 (0x40200000u, three series terms) moves 35 % of the compacted f64
+                                   // elements to the fast path -- |x| is uniform below 12 at C4, tools/gibbs_x_hist.py -- but buys
+                                   // only 3 % (1.41 vs 1.45 ms) for a 30x larger error (1.7e-10 per bin: the 1e-11 parity test
+                                   // against the all-f64 kernel fails), so the threshold stays at 12
 #endif
 #define PGL_GQ 256            // band-queue entries per wave (the band elements of one weight: <= 4 x 64)
 
@@ -3358,7 +3361,7 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
 #pragma unroll
                 for (int sg = 0; sg < 4; ++sg) {
                     const float e = __builtin_amdgcn_exp2f((float)fabs(x[sg]) * -1.44269504088896340736f);
-                    corr[sg] = e * fmaf(e, fmaf(e, 0.33333334f, -0.5f), 1.0f);     // log1p(e), e <= 3.4e-4: e^4/4 < 3.2e-15
+                    corr[sg] = e * fmaf(e, -0.5f, 1.0f);
                 }
                 double accl = 0.0;
                 float accc = 0.0f;
