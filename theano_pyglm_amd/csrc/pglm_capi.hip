@@ -289,7 +289,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             const int kt6 = ktw6 * (nw6 / ptw6);
             int mt6 = 0;
             for (int mt = (nw6 == 4 ? 1 : 2); mt >= 1 && mt6 == 0; --mt) {
-                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt6) + (size_t)mt * nw6 * 2048 + 256;
+                const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt6) + (size_t)mt * nw6 * 2048 + 256 + (size_t)nw6 * 384;
                 const size_t cap = (nw6 == 4) ? 80 * 1024 : 160 * 1024;      // two 4-wave workgroups per CU
                 if (lds6 <= cap && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
             }
@@ -297,7 +297,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
                 nw6 = 8; ptw6 = pl.PTW; ktw6 = pl.KTW;
                 const int kt8 = ktw6 * (8 / ptw6);
                 for (int mt = 2; mt >= 1 && mt6 == 0; --mt) {
-                    const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt8) + (size_t)mt * 8 * 2048 + 256;
+                    const size_t lds6 = (size_t)2 * mt * pgl_img_bytes(kt8) + (size_t)mt * 8 * 2048 + 256 + (size_t)8 * 384;
                     if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
                 }
             }
@@ -350,7 +350,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     int wgPerCU = (pl.version == 7) ? pl.wg7 : 1;
     if (pl.version == 6) {
         // as many workgroups per CU as registers and LDS allow (4-wave form at C2: three)
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256;
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
         wgPerCU = fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
@@ -377,7 +377,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         return PGL_OK;
     }
     if (pl.version == 6) {
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256;
+        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -513,7 +513,7 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
 template <int KTW, int PTW, int MT, int NW>
 static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ)
 {
-    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256;
+    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256 + (size_t)NW * 384;
     if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
         auto kern = k_fused6<KTW, PTW, MT, NW>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -670,7 +670,14 @@ int pgl_create(int N, int64_t nT, int B, int R, int nlin, double dt, int device,
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(PGL_ERR_HIP, hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    {
+        // the side stream reduces the first G half beside pass 2 of the two-pass kernel: highest priority, so that its
+        // blocks take every wave slot pass 2 leaves free and the reduction is over before pass 2 is (at default
+        // priority it finished ~15 us after a 1/8-recording pass 2 and delayed the second reduction)
+        int prio_lo = 0, prio_hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_hi = 0;
+        e = hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { pgl_destroy(h); return fail(PGL_ERR_HIP, hipGetErrorString(e)); }

@@ -411,19 +411,20 @@ typedef double pgl_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) double* pgl_k_cdp;
 #define PGL_ROW __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (&sc)[4], const int nlin_,
-                                          const double dt, const pgl_k_cdp C, double* scratch,
-                                          const int lane, double& term, double (&res)[4] PGL_PROF_ARGS)
+template <int NE, int CAP>
+__device__ __forceinline__ bool pgl_rate_fx(const double (&x)[NE], const unsigned (&sc)[NE], const int nlin_,
+                                            const double dt, const pgl_k_cdp C, double* scratch,
+                                            const int lane, double& term, double (&res)[NE] PGL_PROF_ARGS)
 {
     const int nlin = nlin_ & 1;                       // bit 1 of nlin_: all-f64 epilogue (PGL_OPT_EPI_F64)
     const bool allf64 = (nlin_ & 2) != 0;
-    double k[4], r[4], q[4], e[4];
+    double k[NE], r[NE], q[NE], e[NE];
     // every constant of the exp / series stages is requested up front: one scalar-memory wait
     double c[14];
 #pragma unroll
     for (int j = 0; j < 14; ++j) c[j] = C[j];
     const double c13 = C[22], cthr = C[23];
-    double lam[4], sig[4];
+    double lam[NE], sig[NE];
     bool fastdone = false;
 #if PGL_EPI_F32
     if (nlin == 1 && !allf64) {
@@ -434,10 +435,10 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
         // 9 instructions per element instead of 36: every VALU instruction here is an MFMA issue slot lost.
         bool hi = true;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hi = hi && (x[i] > 12.0);
+        for (int i = 0; i < NE; ++i) hi = hi && (x[i] > 12.0);
         if (__all(hi)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NE; ++i) {
                 const double ef = (double)__builtin_amdgcn_exp2f((float)x[i] * -1.44269504088896340736f);
                 lam[i] = fma(ef, fma(ef, -0.5, 1.0), x[i]);                  // x + e (1 - e/2), e^3/3 < 8e-17
                 sig[i] = fma(-ef, fma(-ef, fma(-ef, 1.0, 1.0), 1.0), 1.0);   // 1 - e + e^2 - e^3
@@ -449,44 +450,44 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
     if (!fastdone) {
     // ---- e = exp(y), y = -|x| (explinear) or x (exp) ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] = rint((nlin == 1 ? -fabs(x[i]) : x[i]) * c[0]);
+    for (int i = 0; i < NE; ++i) k[i] = rint((nlin == 1 ? -fabs(x[i]) : x[i]) * c[0]);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], c[1], (nlin == 1 ? -fabs(x[i]) : x[i]));
+    for (int i = 0; i < NE; ++i) r[i] = fma(-k[i], c[1], (nlin == 1 ? -fabs(x[i]) : x[i]));
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], c[2], r[i]);
+    for (int i = 0; i < NE; ++i) r[i] = fma(-k[i], c[2], r[i]);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(c[3], r[i], c[4]);
+    for (int i = 0; i < NE; ++i) q[i] = fma(c[3], r[i], c[4]);
     PGL_ROW;
 #pragma unroll
     for (int j = 5; j <= 13; ++j) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], c[j]);
+        for (int i = 0; i < NE; ++i) q[i] = fma(q[i], r[i], c[j]);
         PGL_ROW;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 0.5);
+    for (int i = 0; i < NE; ++i) q[i] = fma(q[i], r[i], 0.5);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 1.0);
+    for (int i = 0; i < NE; ++i) q[i] = fma(q[i], r[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = fma(q[i], r[i], 1.0);
+    for (int i = 0; i < NE; ++i) q[i] = fma(q[i], r[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] = fmin(fmax(k[i], -2200.0), 2200.0);
+    for (int i = 0; i < NE; ++i) k[i] = fmin(fmax(k[i], -2200.0), 2200.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = ldexp(q[i], (int)k[i]);
+    for (int i = 0; i < NE; ++i) e[i] = ldexp(q[i], (int)k[i]);
     PGL_ROW;
     PGL_PROF_MARK(7);
     if (nlin != 1) {
         // exp nonlinearity: lam = e, term = x s - dt lam, r = s - dt lam
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const double sd = (double)sc[i];
             res[i] = fma(-dt, e[i], sd);
             t += fma(x[i], sd, -dt * e[i]);
@@ -496,84 +497,87 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
     }
     bool small = true;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) small = small && (e[i] < cthr);
+    for (int i = 0; i < NE; ++i) small = small && (e[i] < cthr);
     if (!__all(small)) return false;
     // ---- series regime: log1p(e) and 1/(1+e) from their alternating series (error < e^6) ----
-    double l1p[4], inv[4];
+    double l1p[NE], inv[NE];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], 0.2, 0.25);
+    for (int i = 0; i < NE; ++i) l1p[i] = fma(-e[i], 0.2, 0.25);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], 1.0, 1.0);
+    for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], 1.0, 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], c13);
+    for (int i = 0; i < NE; ++i) l1p[i] = fma(-e[i], l1p[i], c13);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], 0.5);
+    for (int i = 0; i < NE; ++i) l1p[i] = fma(-e[i], l1p[i], 0.5);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) l1p[i] = fma(-e[i], l1p[i], 1.0);
+    for (int i = 0; i < NE; ++i) l1p[i] = fma(-e[i], l1p[i], 1.0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) l1p[i] = e[i] * l1p[i];
+    for (int i = 0; i < NE; ++i) l1p[i] = e[i] * l1p[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
+    for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
     PGL_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lam[i] = fmax(x[i], 0.0) + l1p[i];
+    for (int i = 0; i < NE; ++i) lam[i] = fmax(x[i], 0.0) + l1p[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sig[i] = (x[i] >= 0.0) ? inv[i] : e[i] * inv[i];
+    for (int i = 0; i < NE; ++i) sig[i] = (x[i] >= 0.0) ? inv[i] : e[i] * inv[i];
     PGL_ROW;
     }
     // reference semantics at lam == 0 / NaN are the general path's business
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ok = ok && (lam[i] > 0.0);
+    for (int i = 0; i < NE; ++i) ok = ok && (lam[i] > 0.0);
     if (!__all(ok)) return false;
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t = fma(-dt, lam[i], t);
+    for (int i = 0; i < NE; ++i) t = fma(-dt, lam[i], t);
     PGL_PROF_MARK(8);
     // ---- spike terms, compacted: slot = rank of the (register, lane) pair among the tile's spikes ----
-    unsigned long long m[4];
+    // (scratch: CAP rates + CAP (log, 1/x) pairs = 3 CAP doubles per wave; CAP = 64 or, where LDS is short, 32)
+    unsigned long long m[NE];
+    int base[NE], total = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = __ballot(sc[i] != 0u);
-    const int n0 = __popcll(m[0]), n1 = __popcll(m[1]), n2 = __popcll(m[2]), n3 = __popcll(m[3]);
-    const int total = n0 + n1 + n2 + n3;
+    for (int i = 0; i < NE; ++i) {
+        m[i] = __ballot(sc[i] != 0u);
+        base[i] = total;
+        total += __popcll(m[i]);
+    }
     if (total == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) res[i] = -dt * sig[i];
-    } else if (total < 64) {
-        const int base[4] = {0, n0, n0 + n1, n0 + n1 + n2};
-        int slot[4];
+        for (int i = 0; i < NE; ++i) res[i] = -dt * sig[i];
+    } else if (total < CAP) {
+        int slot[NE];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NE; ++i) {
             slot[i] = base[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[i] >> 32),
                                          __builtin_amdgcn_mbcnt_lo((unsigned)m[i], 0u));
             if (sc[i] != 0u) scratch[slot[i]] = lam[i];
-            slot[i] = (sc[i] != 0u) ? slot[i] : 63;       // lanes without a spike read the unused slot 63, weight 0
+            slot[i] = (sc[i] != 0u) ? slot[i] : CAP - 1;   // lanes without a spike read the unused last slot, weight 0
         }
         __builtin_amdgcn_wave_barrier();               // one wave: its LDS operations execute in order
         const double lc = (lane < total) ? scratch[lane] : 1.0;
         pgl_d2 LI;
         LI.x = pgl_log(lc, C);
         LI.y = pgl_rcp(lc);
-        pgl_d2* const so = reinterpret_cast<pgl_d2*>(scratch + 64);
-        so[lane] = LI;
+        pgl_d2* const so = reinterpret_cast<pgl_d2*>(scratch + CAP);
+        if (CAP == 64 || lane < CAP) so[lane] = LI;
         __builtin_amdgcn_wave_barrier();
-        pgl_d2 g[4];
+        pgl_d2 g[NE];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = so[slot[i]];
+        for (int i = 0; i < NE; ++i) g[i] = so[slot[i]];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // elements without a spike read slot 63 with weight 0: that slot is never a real spike here
-            // (total < 64) and holds (log 1, 1/1) -- slot 0 would be ANOTHER neuron's spike, and 0 * (1/lam)
+        for (int i = 0; i < NE; ++i) {
+            // elements without a spike read the last slot with weight 0: that slot is never a real spike here
+            // (total < CAP) and holds (log 1, 1/1) -- slot 0 would be ANOTHER neuron's spike, and 0 * (1/lam)
             // of a denormal or infinite rate is NaN
             const double sd = (double)sc[i];
             t = fma(g[i].x, sd, t);
@@ -581,7 +585,7 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NE; ++i) {
             res[i] = -dt * sig[i];
             if (m[i] != 0ull) {
                 const double sd = (double)sc[i];
@@ -595,6 +599,13 @@ __device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (
     PGL_PROF_MARK(9);
     term = t;
     return true;
+}
+
+__device__ __forceinline__ bool pgl_rate4(const double (&x)[4], const unsigned (&sc)[4], const int nlin,
+                                          const double dt, const pgl_k_cdp C, double* scratch,
+                                          const int lane, double& term, double (&res)[4] PGL_PROF_ARGS)
+{
+    return pgl_rate_fx<4, 64>(x, sc, nlin, dt, C, scratch, lane, term, res PGL_PROF_PASS);
 }
 
 template <typename CP>
@@ -2029,6 +2040,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     double* Rb = Xp;
     constexpr int RBS = NW;                                              // residual tile stride in 2 KB slots
     double* Cs = Xp + (size_t)MT * NW * 256;                             // [32] math constants
+    double* const wscratch = Cs + 32 + wave * 48;                         // per wave: spike compaction of the epilogue (CAP = 16:
+                                                                          // 3 x 16 doubles; LDS is what limits the workgroups per CU)
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
     d4_t G[KTW];
@@ -2041,7 +2054,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     const int nloc = pt * 16 + col;
     const bool valid_n = active && (nloc < p.npost);
     const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
-    const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : 0.0;
+    // padding lanes (neurons >= npost) get a benign current: they must not push their wave out of the epilogue's
+    // fast regime; nothing they produce is ever read
+    const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : (p.nlin == 1 ? 30.0 : 0.0);
     const double* __restrict__ wrow =
         p.Wfrag + ((size_t)(active ? pt : 0) * KS_ALL + (size_t)ksl * KSW) * 64;
     const int kcol0 = ksl * KTW * 16;
@@ -2083,17 +2098,25 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 
     // post-synaptic counts of the elements this wave owns in the epilogue, requested one step ahead (a
     // short step -- two tiles of a 160-column row are 1 500 MFMA cycles -- is over before an HBM miss returns)
+    // (S is zero-padded to whole tiles, upload_spikes: one pointer per owned accumulator register, advanced by a step
+    //  per request -- no 64-bit multiplies in the tile loop; a last partial step reads at most MT - 1 tiles past the
+    //  chunk, inside the padded array as long as the tile exists, hence the clamp on the tile index only)
     unsigned scn[MT * EPW];
+    const uint8_t* cptr[EPW];
+    const int last_tile = p.nT16 - 1;
+#pragma unroll
+    for (int e = 0; e < EPW; ++e)
+        cptr[e] = p.S + ((size_t)(tile_beg < last_tile ? tile_beg : last_tile) * TT + grp + 4 * er[e]) * p.Nall + nglob;
+    const size_t ctile = (size_t)TT * p.Nall;
     auto load_counts = [&](const int tile0s) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            const size_t moff = (tile0s + m <= last_tile) ? (size_t)m * ctile : 0;
 #pragma unroll
-            for (int e = 0; e < EPW; ++e) {
-                const long long tg = (long long)(tile0s + m) * TT + grp + 4 * er[e];
-                const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
-                scn[m * EPW + e] = p.S[tc * p.Nall + nglob];
-            }
+            for (int e = 0; e < EPW; ++e) scn[m * EPW + e] = cptr[e][moff];
         }
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) cptr[e] += (size_t)MT * ctile;
     };
     load_counts(tile_beg);
     int par = 0;
@@ -2105,8 +2128,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         __syncthreads();                                  // ... everybody's; the other buffer is free
         PGL_PROF_MARK(1);
         double sc[MT * EPW];
+        unsigned scu[MT * EPW];
 #pragma unroll
-        for (int i = 0; i < MT * EPW; ++i) sc[i] = (double)scn[i];
+        for (int i = 0; i < MT * EPW; ++i) {
+            scu[i] = scn[i];
+            sc[i] = (double)scn[i];
+        }
         // the images of the next step: PWV pieces of 1 KiB per wave, one every DS forward MFMAs (PGL_DMA_IL), the
         // whole burst up front for waves without MFMA work
         const bool more = tile + MT < tile_end;
@@ -2190,17 +2217,45 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                     xe[m * EPW + e] = x;
                 }
             }
-            pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
-            asm volatile("" : "+v"(Cl));
-            pgl_rate_terms_n<MT * EPW>(xe, sc, p.nlin | p.epi64, p.dt, terme, rese, Cl);
+            // whole step inside the evaluated range and every lane owns its elements: the fixed-order epilogue with
+            // the spike terms compacted (log lam and 1/lam once per step for the ~2 % of elements with a spike instead
+            // of for every element of every wave that holds one: ~90 f64 instructions per tile and wave at C2)
+            bool done = false;
+            if (KSPLIT <= 4 && tile + MT <= tile_end && (long long)(tile + MT) * TT <= p.t_hi && !(p.dbg & 4)) {
+                const double* cg = PGL_C;
+                asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
+                double termx = 0.0;
+#ifdef PGL_PROF
+                long long pgl_prof_dummy_acc[12] = {0};
+                long long pgl_prof_dummy_t = 0;
+#endif
+                done = pgl_rate_fx<MT * EPW, 16>(xe, scu, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, termx,
+                                                 rese PGL_PROF_DUMMY);
+                if (done) {
+                    ll_acc += termx;                       // lanes of padding neurons are never read back
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+                    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                for (int e = 0; e < EPW; ++e) {
-                    const double res = vte[m * EPW + e] ? rese[m * EPW + e] : 0.0;
-                    ll_acc += vte[m * EPW + e] ? terme[m * EPW + e] : 0.0;
-                    gb_acc += res;
-                    if (emine) Rb[((size_t)m * RBS + ptl) * 256 + er[e] * 64 + lane] = res;
+                        for (int e = 0; e < EPW; ++e) {
+                            gb_acc += rese[m * EPW + e];
+                            Rb[((size_t)m * RBS + ptl) * 256 + er[e] * 64 + lane] = rese[m * EPW + e];
+                        }
+                    }
+                }
+            }
+            if (!done) {
+                pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                asm volatile("" : "+v"(Cl));
+                pgl_rate_terms_n<MT * EPW>(xe, sc, p.nlin | p.epi64, p.dt, terme, rese, Cl);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int e = 0; e < EPW; ++e) {
+                        const double res = vte[m * EPW + e] ? rese[m * EPW + e] : 0.0;
+                        ll_acc += vte[m * EPW + e] ? terme[m * EPW + e] : 0.0;
+                        gb_acc += res;
+                        if (emine) Rb[((size_t)m * RBS + ptl) * 256 + er[e] * 64 + lane] = res;
+                    }
                 }
             }
         }
