@@ -1548,6 +1548,17 @@ __device__ __forceinline__ double conv_one(const int2* __restrict__ spk, int lo,
 }
 
 __host__ __device__ constexpr int pgl_img_rsh(int kt) { return kt * 16 + 2; }
+// Row order of an image: time row i = 4q + r of the tile is stored at physical row 2q + 8 (r & 1) + (r >> 1).
+// With the row stride = 2 (mod 32) doubles both A-fragment patterns of ds_read_b64 (32-lane groups, 64 banks) are
+// then conflict-free: forward -- lanes (time i = 0..15) x (two consecutive columns) -- sees the 16 rows 2 double-banks
+// apart whatever their order; backward -- lanes (two time rows 4q + {0,1} or 4q + {2,3}) x (16 consecutive columns) --
+// needs the two rows 16 double-banks apart, i.e. 8 physical rows.  (Stored in time order the backward reads of lanes
+// with r = 0 and r = 1 overlap in 14 of 16 banks: SQ_LDS_BANK_CONFLICT = one cycle per backward read.)
+__host__ __device__ constexpr int pgl_img_row(int i) { return 2 * (i >> 2) + ((i & 1) << 3) + ((i >> 1) & 1); }
+// backward: lane group grp reads time row 4q + grp at k-step q = physical row pgl_img_brow(grp) + 2q
+__host__ __device__ constexpr int pgl_img_brow(int grp) { return ((grp & 1) << 3) + (grp >> 1); }
+// time row stored at physical row p
+__host__ __device__ constexpr int pgl_img_row_inv(int p) { return 4 * ((p & 7) >> 1) + ((p >> 3) & 1) + 2 * (p & 1); }
 __host__ __device__ constexpr int pgl_img_bytes(int kt) { return ((16 * pgl_img_rsh(kt) * 8 + 1023) / 1024) * 1024; }
 
 // grid = (nT16, 2); block = 256.  One block builds one image: part 0 = the first ktl k-tiles of
@@ -1571,9 +1582,10 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
     double* dst = reinterpret_cast<double*>(Fimg + (size_t)blockIdx.x * (imgl + imgh) + (part ? imgl : 0));
     const int nel = (int)((part ? imgh : imgl) / 8);
     for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-        const int t = i / rsh, c = i - t * rsh;
+        const int tp = i / rsh, c = i - tp * rsh;        // physical row tp of the image holds time row t (pgl_img_row)
+        const int t = pgl_img_row_inv(tp & 15);
         double v = 0.0;
-        if (t < 16 && c < cw) {
+        if (tp < 16 && c < cw) {
             const int col = cbeg + c;
             const long long tg = (long long)tile * 16 + t;
             if (col < Kimp) {
@@ -1718,7 +1730,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int RSG = (PASS == 1) ? RSL : RSH;
     auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
                         unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
-        const double* fb = reinterpret_cast<const double*>(Fb) + grp * RSG + col;
+        const double* fb = reinterpret_cast<const double*>(Fb) + pgl_img_brow(grp) * RSG + col;
         constexpr int NS = 4 * KTG;
         constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
         constexpr int NRT = NR0 + NR1;
@@ -1727,7 +1739,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         constexpr int DSTEP = (NS >= 2 * NRT) ? ((DSFULL < DSCAP) ? DSFULL : DSCAP) : 0;   // MFMAs between rounds
         double ar[PD];
 #pragma unroll
-        for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KTG)) * RSG + 16 * (s % KTG));
+        for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / KTG)) * RSG + 16 * (s % KTG));
         auto round = [&](const int j) {
             if (j < NR0) {
                 pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
@@ -1745,7 +1757,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         for (int s = 0; s < NS; ++s) {
             if (PGL_PRIO && s == NS / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             const double a = ar[s % PD];
-            if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG));
+            if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (2 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG));
             G[s % KTG] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTG], G[s % KTG], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             if (DSTEP > 0) {
@@ -1802,8 +1814,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
             constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
             if (active && !(p.dbg & 8)) {
-                const double* faL = reinterpret_cast<const double*>(Lb) + col * RSL + grp;
-                const double* faH = reinterpret_cast<const double*>(buf1) + col * RSH + grp;
+                const double* faL = reinterpret_cast<const double*>(Lb) + pgl_img_row(col) * RSL + grp;
+                const double* faH = reinterpret_cast<const double*>(buf1) + pgl_img_row(col) * RSH + grp;
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
                 constexpr int PA = 4;
@@ -2165,7 +2177,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
             if (active && tile + m < tile_end) {
-                const double* fa = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + col * RS + kcol0 + grp;
+                const double* fa = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + pgl_img_row(col) * RS + kcol0 + grp;
                 constexpr int PA = (KSW < 4) ? KSW : 4;
                 double ar[PA];
 #pragma unroll
@@ -2270,16 +2282,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 double rr[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rr[r] = Rb[((size_t)m * RBS + ptl) * 256 + r * 64 + lane];
-                const double* fb = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + grp * RS + kcol0 + col;
+                const double* fb = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + pgl_img_brow(grp) * RS + kcol0 + col;
                 constexpr int NS = 4 * KTW;
                 constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
                 double ar[PD];
 #pragma unroll
-                for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KTW)) * RS + 16 * (s % KTW));
+                for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / KTW)) * RS + 16 * (s % KTW));
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const double a = ar[s % PD];
-                    if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KTW)) * RS + 16 * ((s + PD) % KTW));
+                    if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (2 * ((s + PD) / KTW)) * RS + 16 * ((s + PD) % KTW));
                     G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KTW], G[s % KTW], 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -2431,7 +2443,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
         d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
         {
-            const double* fa = reinterpret_cast<const double*>(cur) + col * RS + grp;
+            const double* fa = reinterpret_cast<const double*>(cur) + pgl_img_row(col) * RS + grp;
             constexpr int PA = 4;
             double ar[PA];
 #pragma unroll
@@ -2526,16 +2538,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         PGL_PROF_MARK(4);
         // ---- backward over all K ----
         if (p.want_grad) {
-            const double* fb = reinterpret_cast<const double*>(cur) + grp * RS + col;
+            const double* fb = reinterpret_cast<const double*>(cur) + pgl_img_brow(grp) * RS + col;
             constexpr int NS = 4 * KT;
             constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
             double ar[PD];
 #pragma unroll
-            for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (4 * (s / KT)) * RS + 16 * (s % KT));
+            for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / KT)) * RS + 16 * (s % KT));
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double a = ar[s % PD];
-                if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (4 * ((s + PD) / KT)) * RS + 16 * ((s + PD) % KT));
+                if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (2 * ((s + PD) / KT)) * RS + 16 * ((s + PD) % KT));
                 G[s % KT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KT], G[s % KT], 0, 0, 0);
                 if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 if (DSB > 0) {
