@@ -142,6 +142,29 @@ int pgl_sync(pgl_handle h);
  * touched. */
 int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int M, int P);
 
+/* Bookkeeping of the lock-step optimiser (inference/batched_bfgs.py) as row kernels on the handle's stream -- the
+ * reference has no counterpart, it calls scipy.optimize.minimize(method="bfgs") neuron by neuron
+ * (coord_descent.py:161-204).  All optimiser state of a shard of M neurons with P parameters lives in ONE device block
+ * of pgl_bfgs_state_doubles(M, P) doubles (flags and counters stored as doubles), in this order:
+ *   (M,P) each: X, g, p, H g, s, y, t = H g_new;  (M,P,3) each: U, V (H += U V^T);
+ *   (M) each: f, alpha, slope, rho, scale, iters, restarts, nhalf, active, frozen, acc, upd.
+ *   trial:     Xt[j] = X[r] + alpha[r] p[r], r = d_rows[j] (NULL: j), j < L
+ *   objective: rows of d_Xt are theta rows [bias, w_stim, w_ir]; in place ll -> f = -(ll + log prior),
+ *              grad -> g = -(grad + prior gradient) with fit_glm's NaN rules (coord_descent.py:170-182);
+ *              priors: bias.py:33, bkgd.py:76 (stim_sigma), priors.py:139 (kind 0) / 202 (kind 1: group lasso)
+ *   accept:    Armijo test of the listed trials; accepted rows take the step, failed ones halve alpha
+ *   update:    expects t = H g (caller: batched GEMV); writes U, V, H_new g, the next direction / step, the restart
+ *              and convergence flags; scale[r] != 0 asks for H[r] = I after the caller's H += U V^T
+ *              (pgl_identity_rows_dev). */
+long long pgl_bfgs_state_doubles(int M, int P);
+int pgl_bfgs_trial_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_Xt);
+int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, double* d_ll_f, double* d_grad_g,
+                           int prior_kind, double mu_b, double sg_b, double stim_sigma, double mu, double sigma,
+                           double lam);
+int pgl_bfgs_accept_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
+                        const double* d_f, const double* d_g);
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter);
+
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
  * fS_out (nT,N,B) row-major, float64. */
 int pgl_features(pgl_handle h, double* fS_out);

@@ -30,7 +30,8 @@ SYMBOLS = [
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
-    'pgl_identity_rows_dev',
+    'pgl_identity_rows_dev', 'pgl_bfgs_state_doubles', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
+    'pgl_bfgs_accept_dev', 'pgl_bfgs_update_dev',
 ]
 
 
@@ -103,6 +104,12 @@ def load():
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_list_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
+    if hasattr(lib, 'pgl_bfgs_update_dev'):
+        lib.pgl_bfgs_state_doubles.argtypes = [C.c_int, C.c_int]
+        lib.pgl_bfgs_trial_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+        lib.pgl_bfgs_objective_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int] + [C.c_double] * 6
+        lib.pgl_bfgs_accept_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
+        lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int]
     if hasattr(lib, 'pgl_identity_rows_dev'):                 # (older dev A/B builds named by PYGLM_HIP_LIB lack it)
         lib.pgl_identity_rows_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.pgl_features.argtypes = [vp, vp]
@@ -124,7 +131,9 @@ def load():
         if 'PYGLM_HIP_LIB' in os.environ and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
-        if name not in ('pgl_last_error',):
+        if name == 'pgl_bfgs_state_doubles':
+            fn.restype = C.c_longlong
+        elif name not in ('pgl_last_error',):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -303,6 +312,27 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_ll_grad_list_dev(self.h, C.c_void_p(d_idx), int(count), C.c_void_p(d_theta),
                                            C.c_void_p(d_Weff), C.c_void_p(d_ll),
                                            C.c_void_p(d_grad) if d_grad else None))
+
+    # -- lock-step optimiser bookkeeping (device pointers as integers; asynchronous on the handle's stream) --
+    def bfgs_state_doubles(self, M, P):
+        return int(self.lib.pgl_bfgs_state_doubles(int(M), int(P)))
+
+    def bfgs_trial_dev(self, d_state, M, P, d_rows, L, d_Xt):
+        _chk(self.lib.pgl_bfgs_trial_dev(self.h, C.c_void_p(d_state), int(M), int(P),
+                                         C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_Xt)))
+
+    def bfgs_objective_dev(self, L, P, d_Xt, d_ll_f, d_grad_g, prior_kind, mu_b, sg_b, stim_sigma, mu, sigma, lam):
+        _chk(self.lib.pgl_bfgs_objective_dev(self.h, int(L), int(P), C.c_void_p(d_Xt), C.c_void_p(d_ll_f),
+                                             C.c_void_p(d_grad_g), int(prior_kind), float(mu_b), float(sg_b),
+                                             float(stim_sigma), float(mu), float(sigma), float(lam)))
+
+    def bfgs_accept_dev(self, d_state, M, P, d_rows, L, d_Xt, d_f, d_g):
+        _chk(self.lib.pgl_bfgs_accept_dev(self.h, C.c_void_p(d_state), int(M), int(P),
+                                          C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_Xt),
+                                          C.c_void_p(d_f), C.c_void_p(d_g)))
+
+    def bfgs_update_dev(self, d_state, M, P, gtol, maxiter):
+        _chk(self.lib.pgl_bfgs_update_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol), int(maxiter)))
 
     def reset_identity_dev(self, d_H, d_scale, M, P):
         """Rows m of the device batch d_H (M, P, P) with d_scale[m] != 0 (device float64) become d_scale[m] * I

@@ -1428,6 +1428,55 @@ int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int 
     return PGL_OK;
 }
 
+// ---- lock-step BFGS bookkeeping kernels (inference/batched_bfgs.py) ----------------------------------------------
+long long pgl_bfgs_state_doubles(int M, int P) { return (long long)pgl_bfgs_doubles(M, P); }
+
+int pgl_bfgs_trial_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_Xt)
+{
+    if (!h || !d_state || !d_Xt || M <= 0 || P <= 0 || L <= 0 || L > M) return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_bfgs_trial, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows, d_Xt);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, double* d_ll_f, double* d_grad_g,
+                           int prior_kind, double mu_b, double sg_b, double stim_sigma, double mu, double sigma,
+                           double lam)
+{
+    if (!h || !d_Xt || !d_ll_f || !d_grad_g || L <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if (P != 1 + h->Dstim + h->Kimp || h->sep) return fail(PGL_ERR_ARG, "rows must be theta rows [bias, w_stim, w_ir]");
+    if (prior_kind != 0 && prior_kind != 1) return fail(PGL_ERR_ARG, "prior kind: 0 Gaussian, 1 group lasso");
+    HIPCHK(hipSetDevice(h->device));
+    BfgsPrior q;
+    q.N = h->N; q.B = h->B; q.Dstim = h->Dstim; q.kind = prior_kind;
+    q.mu_b = mu_b; q.sg_b = sg_b; q.stim_sigma = stim_sigma; q.mu = mu; q.sigma = sigma; q.lam = lam;
+    hipLaunchKernelGGL(k_bfgs_objective, dim3(L), dim3(256), 0, h->stream, P, d_Xt, d_ll_f, d_grad_g, q);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_accept_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
+                        const double* d_f, const double* d_g)
+{
+    if (!h || !d_state || !d_Xt || !d_f || !d_g || M <= 0 || P <= 0 || L <= 0 || L > M)
+        return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_bfgs_accept, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows, d_Xt, d_f,
+                       d_g);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter)
+{
+    if (!h || !d_state || M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_bfgs_update, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol, maxiter);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
 int pgl_sync(pgl_handle h)
 {
     if (!h) return fail(PGL_ERR_ARG, "null handle");

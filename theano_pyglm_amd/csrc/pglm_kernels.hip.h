@@ -3997,3 +3997,254 @@ __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restric
         if (t < nT && n < N) ST[(size_t)n * nT + t] = tile[tt][nn];
     }
 }
+
+// ---------------------------------------------------------------------------
+// Lock-step BFGS bookkeeping (inference/batched_bfgs.py): the per-neuron line-search / update state machines of
+// all M neurons of a shard as a handful of row kernels -- one workgroup per neuron row -- instead of ~110 tiny
+// framework kernels per evaluation (4 us of work and a launch gap each: a fifth of a MAP sweep at C3).  The
+// reference has no counterpart: it calls scipy.optimize.minimize(method="bfgs") per neuron (coord_descent.py:194).
+// All state lives in ONE device block of doubles (flags and counters included), laid out by pgl_bfgs_view.
+// ---------------------------------------------------------------------------
+struct BfgsView {
+    int M, P;
+    double *X, *g, *p, *Hg, *s, *y, *t;              // (M, P)
+    double *U, *V;                                   // (M, P, 3): H += U V^T is the BFGS update
+    double *f, *alpha, *slope, *rho, *scale, *iters, *restarts, *nhalf, *active, *frozen, *acc, *upd;   // (M)
+};
+#define PGL_BFGS_NVEC 7
+#define PGL_BFGS_NSCAL 12
+__host__ __device__ inline size_t pgl_bfgs_doubles(int M, int P)
+{
+    return (size_t)M * P * (PGL_BFGS_NVEC + 6) + (size_t)M * PGL_BFGS_NSCAL;
+}
+__host__ __device__ inline BfgsView pgl_bfgs_view(double* st, int M, int P)
+{
+    BfgsView v;
+    const size_t MP = (size_t)M * P;
+    v.M = M; v.P = P;
+    v.X = st; v.g = st + MP; v.p = st + 2 * MP; v.Hg = st + 3 * MP; v.s = st + 4 * MP; v.y = st + 5 * MP;
+    v.t = st + 6 * MP; v.U = st + 7 * MP; v.V = st + 10 * MP;
+    double* q = st + 13 * MP;
+    v.f = q; v.alpha = q + M; v.slope = q + 2 * M; v.rho = q + 3 * M; v.scale = q + 4 * M; v.iters = q + 5 * M;
+    v.restarts = q + 6 * M; v.nhalf = q + 7 * M; v.active = q + 8 * M; v.frozen = q + 9 * M; v.acc = q + 10 * M;
+    v.upd = q + 11 * M;
+    return v;
+}
+
+// sum / max over the 256 threads of a block, result in every thread (fixed order)
+__device__ __forceinline__ double pgl_blk_sum(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double pgl_blk_max(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// trial points of the listed rows: Xt[j] = X[r] + alpha[r] p[r], r = rows[j] (null: r = j)
+__global__ __launch_bounds__(256) void k_bfgs_trial(const BfgsView v, const int* __restrict__ rows,
+                                                    double* __restrict__ Xt)
+{
+    const int j = blockIdx.x, r = rows ? rows[j] : j;
+    const double a = v.alpha[r];
+    for (int c = threadIdx.x; c < v.P; c += 256)
+        Xt[(size_t)j * v.P + c] = fma(a, v.p[(size_t)r * v.P + c], v.X[(size_t)r * v.P + c]);
+}
+
+struct BfgsPrior {
+    int N, B, Dstim, kind;                // kind: 0 Gaussian, 1 group lasso on the impulse weights (priors.py:139 / 202)
+    double mu_b, sg_b, stim_sigma, mu, sigma, lam;
+};
+
+// f = -(ll + log prior), g = -(grad ll + grad log prior) of the listed trial rows [bias, w_stim, w_ir] (the packing
+// that IS the device's theta row); fit_glm's NaN rules: f NaN -> 1e16, any NaN in a gradient row -> zero row
+// (coord_descent.py:170-182).  In place: ll -> f, grad -> g.
+__global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const double* __restrict__ Xt,
+                                                        double* __restrict__ ll, double* __restrict__ grad,
+                                                        const BfgsPrior q)
+{
+    __shared__ double red[4];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const double* x = Xt + (size_t)j * P;
+    double* g = grad + (size_t)j * P;
+    double lp = 0.0;
+    bool bad = false;
+    if (tid == 0) {                                                            // bias.py:33
+        const double d = x[0] - q.mu_b;
+        lp += -0.5 / (q.sg_b * q.sg_b) * d * d;
+        const double gv = -(g[0] - d / (q.sg_b * q.sg_b));
+        bad = bad || (gv != gv);
+        g[0] = gv;
+    }
+    for (int c = 1 + tid; c < 1 + q.Dstim; c += 256) {                         // bkgd.py:76
+        const double w = x[c], is2 = 1.0 / (q.stim_sigma * q.stim_sigma);
+        lp += -0.5 * is2 * w * w;
+        const double gv = -(g[c] - w * is2);
+        bad = bad || (gv != gv);
+        g[c] = gv;
+    }
+    const int o = 1 + q.Dstim;
+    for (int n = tid; n < q.N; n += 256) {                                     // one presynaptic group per thread
+        const double* w = x + o + n * q.B;
+        double* gw = g + o + n * q.B;
+        if (q.kind == 1) {                                                     // priors.py:202
+            double z[PGL_MAXB], ss = 0.0;
+            for (int b = 0; b < q.B; ++b) {
+                z[b] = (w[b] - q.mu) / q.sigma;
+                ss += z[b] * z[b];
+            }
+            const double nrm = sqrt(ss);
+            lp -= q.lam * nrm;
+            for (int b = 0; b < q.B; ++b) {
+                const double gv = -(gw[b] - q.lam * z[b] / nrm / q.sigma);     // 0/0 -> NaN like the host prior
+                bad = bad || (gv != gv);
+                gw[b] = gv;
+            }
+        } else {                                                               // priors.py:139
+            const double is2 = 1.0 / (q.sigma * q.sigma);
+            for (int b = 0; b < q.B; ++b) {
+                const double d = w[b] - q.mu;
+                lp += -0.5 * is2 * d * d;
+                const double gv = -(gw[b] - d * is2);
+                bad = bad || (gv != gv);
+                gw[b] = gv;
+            }
+        }
+    }
+    const double lpt = pgl_blk_sum(lp, red);
+    const bool anybad = pgl_blk_max(bad ? 1.0 : 0.0, red) > 0.0;
+    if (tid == 0) {
+        const double fv = -(ll[j] + lpt);
+        ll[j] = (fv != fv) ? 1e16 : fv;
+    }
+    if (anybad)
+        for (int c = tid; c < P; c += 256) g[c] = 0.0;
+}
+
+// Armijo test of the listed trials; accepted rows take the step (X, f, g) and leave s, y, s.y behind
+__global__ __launch_bounds__(256) void k_bfgs_accept(const BfgsView v, const int* __restrict__ rows,
+                                                     const double* __restrict__ Xt, const double* __restrict__ ft,
+                                                     const double* __restrict__ gt)
+{
+    __shared__ double red[4];
+    const int j = blockIdx.x, r = rows ? rows[j] : j, tid = threadIdx.x, P = v.P;
+    const bool act = v.active[r] != 0.0;
+    const bool ok = act && (ft[j] <= v.f[r] + 1e-4 * v.alpha[r] * v.slope[r]);
+    if (!ok) {
+        if (act && tid == 0) {                        // failed trial: halve the step
+            v.alpha[r] *= 0.5;
+            v.nhalf[r] += 1.0;
+        }
+        return;
+    }
+    double sy = 0.0;
+    for (int c = tid; c < P; c += 256) {
+        const size_t i = (size_t)r * P + c, it = (size_t)j * P + c;
+        const double xn = Xt[it], gn = gt[it];
+        const double s = xn - v.X[i], y = gn - v.g[i];
+        v.s[i] = s;
+        v.y[i] = y;
+        v.X[i] = xn;
+        v.g[i] = gn;
+        sy = fma(s, y, sy);
+    }
+    sy = pgl_blk_sum(sy, red);
+    if (tid == 0) {
+        v.f[r] = ft[j];
+        v.acc[r] = 1.0;
+        const bool u = sy > 1e-12;
+        v.upd[r] = u ? 1.0 : 0.0;
+        v.rho[r] = u ? 1.0 / sy : 0.0;
+    }
+}
+
+// after t = H g_new: the rank-3 factors of the inverse-Hessian update, H_new g_new, and the state machine of every row
+// (new direction / restart / freeze / convergence).  scale[r] != 0 asks for H[r] = I afterwards (k_identity_rows).
+__global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const double gtol, const int maxiter)
+{
+    __shared__ double red[4];
+    const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
+    const size_t o = (size_t)r * P;
+    const bool act = v.active[r] != 0.0, a = v.acc[r] != 0.0, u = v.upd[r] != 0.0;
+    double* U = v.U + o * 3;
+    double* V = v.V + o * 3;
+    if (u) {
+        const double rho = v.rho[r];
+        double yHy = 0.0, vg0 = 0.0, vg2 = 0.0;
+        for (int c = tid; c < P; c += 256) {
+            const double Hy = v.t[o + c] - v.Hg[o + c];
+            yHy = fma(v.y[o + c], Hy, yHy);
+            vg0 = fma(v.s[o + c], v.g[o + c], vg0);
+            vg2 = fma(Hy, v.g[o + c], vg2);
+        }
+        yHy = pgl_blk_sum(yHy, red);
+        vg0 = pgl_blk_sum(vg0, red);
+        vg2 = pgl_blk_sum(vg2, red);
+        const double c0 = (1.0 + rho * yHy) * rho;
+        for (int c = tid; c < P; c += 256) {
+            const double s = v.s[o + c], Hy = v.t[o + c] - v.Hg[o + c];
+            const double u0 = c0 * s, u1 = -rho * Hy, u2 = -rho * s;
+            U[3 * c] = u0; U[3 * c + 1] = u1; U[3 * c + 2] = u2;
+            V[3 * c] = s; V[3 * c + 1] = s; V[3 * c + 2] = Hy;
+            v.Hg[o + c] = v.t[o + c] + (u0 * vg0 + u1 * vg0 + u2 * vg2);      // H_new g_new
+        }
+    } else {
+        for (int c = tid; c < P; c += 256) {
+            U[3 * c] = 0.0; U[3 * c + 1] = 0.0; U[3 * c + 2] = 0.0;
+            V[3 * c] = 0.0; V[3 * c + 1] = 0.0; V[3 * c + 2] = 0.0;
+            v.Hg[o + c] = v.t[o + c];
+        }
+    }
+    __syncthreads();
+    // ---- state machine ----
+    double sl = 0.0, gg = 0.0, gmax = 0.0;
+    for (int c = tid; c < P; c += 256) {
+        const double gc = v.g[o + c];
+        sl = fma(-v.Hg[o + c], gc, sl);
+        gg = fma(gc, gc, gg);
+        gmax = fmax(gmax, fabs(gc));
+    }
+    sl = pgl_blk_sum(sl, red);
+    gg = pgl_blk_sum(gg, red);
+    gmax = pgl_blk_max(gmax, red);
+    const double iters = v.iters[r] + (a ? 1.0 : 0.0);
+    double restarts = a ? 0.0 : v.restarts[r];
+    const bool fail = act && !a;
+    const bool stalled = fail && v.nhalf[r] >= 30.0;
+    const bool again = stalled && restarts == 0.0;
+    const bool frozen = (v.frozen[r] != 0.0) || (stalled && !again);
+    if (again) restarts += 1.0;
+    const bool newls = a || again;
+    const bool reset = (newls && sl >= 0.0) || again;       // not a descent direction / restart: H = I
+    if (newls) {
+        for (int c = tid; c < P; c += 256) {
+            const double gc = v.g[o + c];
+            if (reset) v.Hg[o + c] = gc;
+            v.p[o + c] = reset ? -gc : -v.Hg[o + c];
+        }
+    } else if (reset) {
+        for (int c = tid; c < P; c += 256) v.Hg[o + c] = v.g[o + c];
+    }
+    if (tid == 0) {
+        v.iters[r] = iters;
+        v.restarts[r] = restarts;
+        v.frozen[r] = frozen ? 1.0 : 0.0;
+        v.scale[r] = reset ? 1.0 : 0.0;
+        if (newls) {
+            v.slope[r] = reset ? -gg : sl;
+            v.alpha[r] = again ? fmin(1.0 / fmax(sqrt(gg), 1e-300), 1.0) : 1.0;
+            v.nhalf[r] = 0.0;
+        }
+        v.active[r] = (act && !frozen && gmax > gtol && iters < (double)maxiter) ? 1.0 : 0.0;
+        v.acc[r] = 0.0;                                      // cleared for the next launch
+        v.upd[r] = 0.0;
+    }
+}

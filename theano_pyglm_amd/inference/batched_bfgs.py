@@ -58,6 +58,18 @@ class _Packing(object):
         self.dirichlet = isinstance(glm.imp_model, DirichletImpulses)
         self.Pp = 1 + self.nbk + self.N * self.B
         self.list_launch = self.bk != 'st_sep'       # pgl_ll_grad_list_dev: not with the separable stimulus
+        # the row IS the device's theta row and its prior is one of the forms the row kernels know
+        # (pgl_bfgs_objective_dev): the whole state machine then runs as HIP row kernels
+        self.identity = self.bk in ('none', 'basis') and not self.dirichlet and \
+            isinstance(glm.imp_model.prior, (Gaussian, GroupLasso))
+
+    def prior_params(self):
+        """(kind, mu_b, sg_b, stim_sigma, mu, sigma, lam) for pgl_bfgs_objective_dev."""
+        glm = self.glm
+        pr = glm.imp_model.prior
+        kind = 1 if isinstance(pr, GroupLasso) else 0
+        return (kind, float(glm.bias_model.mu_bias), float(glm.bias_model.sig_bias), 0.01, float(pr.mu),
+                float(pr.sigma), float(getattr(pr, 'lam', 0.0)))
 
     # -- state dict <-> rows -------------------------------------------------------------------
     def pack(self, x, n_lo, n_hi):
@@ -177,20 +189,24 @@ class _Packing(object):
 
 
 def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False,
-                           reduce=None, lag=2, init_scaling=False):
+                           reduce=None, lag=None, init_scaling=False, row_kernels=True):
     """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations).
 
     Everything runs on one dedicated torch stream that the device handles are switched to
     (pgl_set_stream): prior terms, the fused ll+grad launches, the line-search bookkeeping and the
     inverse-Hessian updates are ordered by the stream, and the host never waits for the launch it has
     just queued.  What steers the loop -- which neurons are still active -- reaches the host `lag`
-    launches late through pinned memory: the active set only ever shrinks, so a launch over the stale
+    launches late (default: 1 with the HIP row kernels, 2 with framework tensor ops) through pinned memory: the active set only ever shrinks, so a launch over the stale
     (larger) list evaluates a few rows whose results are masked out on the device, and the host keeps
     queueing torch ops while the GPU is busy with the previous evaluations.  Neurons that have converged
     drop out of the launch list (pgl_ll_grad_list_dev evaluates an arbitrary list of neurons), so late,
     poorly conditioned neurons do not pay for the whole population.  A neuron whose backtracking fails
     restarts once from steepest descent before it is frozen (scipy's BFGS stops there with "precision
     loss", coord_descent.py:194-199).
+
+    `row_kernels`: for rows that are the device's own theta rows (standard_glm-like models) the line-search and
+    update bookkeeping runs as HIP row kernels (_lockstep_bfgs_rows); False keeps it in framework tensor ops
+    (same iterates; the path every other packing takes).
 
     `init_scaling`: scale the identity of a (re)started inverse Hessian by s.y / y.y before the first update
     (Nocedal & Wright 6.20).  Off by default, like scipy's BFGS: measured on the named configurations it cuts the
@@ -219,7 +235,8 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     try:
         with torch.cuda.stream(stream):
             out = _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M,
-                                 verbose, reduce, max(0, int(lag)), init_scaling)
+                                 verbose, reduce, max(0, int(lag)) if lag is not None else None, init_scaling,
+                                 row_kernels)
             stream.synchronize()
     finally:
         for h in handles:
@@ -227,9 +244,119 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     return out
 
 
+def _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce,
+                        lag, pk):
+    """The same state machines as _lockstep_bfgs with all row-wise bookkeeping in HIP row kernels
+    (pgl_bfgs_trial / objective / accept / update_dev, one workgroup per neuron row): per launch of trial points
+    ~10 kernels -- trial, fused ll+grad, objective, accept, batched GEMV, update, batched rank-3 update, identity
+    rows, the copy of the active flags -- instead of ~110 framework kernels of 4 us each.  For rows that are the
+    device's own theta rows [bias, w_stim, w_ir] (standard_glm-like models)."""
+    h0 = handles[0]
+    P = pk.Pp
+    nst = h0.bfgs_state_doubles(M, P)
+    st = torch.zeros(nst, dtype=torch.float64, device=dev)
+    MP = M * P
+
+    def vec(i):
+        return st[i * MP:(i + 1) * MP].view(M, P)
+    X, g, p, Hg, t_ = vec(0), vec(1), vec(2), vec(3), vec(6)
+    U, V = st[7 * MP:10 * MP].view(M, P, 3), st[10 * MP:13 * MP].view(M, P, 3)
+    sc = st[13 * MP:].view(12, M)
+    f, alpha, slope, scale, iters, active, frozen = sc[0], sc[1], sc[2], sc[4], sc[5], sc[8], sc[9]
+    X.copy_(torch.tensor(pk.pack(x, n_lo, n_hi), dtype=torch.float64, device=dev))
+    Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
+    prm = pk.prior_params()
+    n_evals, neuron_evals = [0], [0]
+
+    def evaluate(Xt, idx32, L):
+        """f and g (fit_glm's NaN rules applied) of the L rows Xt for the neurons idx32 (None: the whole shard);
+        returned as views of one block [f | g]."""
+        tot = None
+        for h in handles:
+            buf = torch.empty(L * (1 + P), dtype=torch.float64, device=dev)      # [ll | grad]: one all-reduce
+            if idx32 is None:
+                h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), buf.data_ptr(), buf[L:].data_ptr(), n_lo, n_hi)
+            else:
+                h.ll_grad_list_dev(idx32.data_ptr(), L, Xt.data_ptr(), Weff.data_ptr(), buf.data_ptr(),
+                                   buf[L:].data_ptr())
+            if reduce is not None:
+                reduce(buf)
+            tot = buf if tot is None else tot.add_(buf)
+        h0.bfgs_objective_dev(L, P, Xt.data_ptr(), tot.data_ptr(), tot[L:].data_ptr(), *prm)
+        n_evals[0] += 1
+        neuron_evals[0] += L
+        return tot[:L], tot[L:].view(L, P)
+
+    f0, g0 = evaluate(X, None, M)
+    f.copy_(f0)
+    g.copy_(g0)
+    Hg.copy_(g0)
+    p.copy_(-g0)
+    slope.copy_(-(g0 * g0).sum(1))
+    alpha.copy_(torch.clamp(1.0 / g0.norm(dim=1).clamp_min(1e-300), max=1.0))
+    active.copy_((g0.abs().amax(1) > gtol).to(torch.float64))
+    H = torch.eye(P, dtype=torch.float64, device=dev).repeat(M, 1, 1)
+    max_launches = maxiter * 31 + 2
+    ring = [torch.empty(M, dtype=torch.float64).pin_memory() for _ in range(lag + 1)]
+    pending = []
+
+    def publish(k):
+        hb = ring[k % (lag + 1)]
+        hb.copy_(active, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        pending.append((hb, ev))
+
+    publish(0)
+    rows32, idx32, L = None, None, M
+    launches = 0
+    while launches < max_launches:
+        if len(pending) > lag:
+            hb, ev = pending.pop(0)
+            ev.synchronize()                                    # a launch `lag` back: normally long done
+            act_h = hb.numpy() != 0.0
+            n_act = int(act_h.sum())
+            if n_act == 0:
+                break
+            if n_act < L:
+                idx_h = np.nonzero(act_h)[0].astype(np.int32)
+                L = n_act
+                rows32 = torch.from_numpy(idx_h).to(dev, non_blocking=True)
+                idx32 = rows32 + n_lo
+            if verbose:
+                print("batched BFGS launch %d: %d neurons active %d launches ago, list of %d"
+                      % (launches, n_act, lag, L))
+        launches += 1
+        Xt = torch.empty((L, P), dtype=torch.float64, device=dev)
+        rp = rows32.data_ptr() if rows32 is not None else 0
+        h0.bfgs_trial_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr())
+        ft, gt = evaluate(Xt, idx32, L)
+        h0.bfgs_accept_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr(), ft.data_ptr(), gt.data_ptr())
+        torch.bmm(H, g.unsqueeze(2), out=t_.unsqueeze(2))       # t = H g_new: the one full read of H per launch
+        h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter)
+        H.baddbmm_(U, V.transpose(1, 2))                        # H += U V^T (zero factors for rows without an update)
+        h0.reset_identity_dev(H.data_ptr(), scale.data_ptr(), M, P)
+        publish(launches)
+    it = int(iters.max())
+    gmax = g.abs().amax(1)
+    n_conv = int((gmax <= gtol).sum())
+    n_frozen = int(((frozen != 0) & (gmax > gtol)).sum())
+    pk.unpack(x, X.cpu().numpy(), n_lo, n_hi)
+    population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
+                                 'neuron_evaluations': neuron_evals[0],
+                                 'converged_gtol': n_conv, 'stalled': n_frozen,
+                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'hip row kernels'}
+    return f.cpu().numpy(), it, n_evals[0]
+
+
 def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose,
-                   reduce=None, lag=2, init_scaling=False):
+                   reduce=None, lag=2, init_scaling=False, row_kernels=True):
     pk = _Packing(population, torch)
+    if row_kernels and pk.identity and not init_scaling:
+        # (queueing a launch takes ~10 library calls here: one launch of run-ahead keeps the GPU fed)
+        return _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose,
+                                   reduce, 1 if lag is None else lag, pk)
+    lag = 2 if lag is None else lag
     X = torch.tensor(pk.pack(x, n_lo, n_hi), dtype=torch.float64, device=dev)
     Pp = X.shape[1]
     P = population.glm.P
