@@ -1290,21 +1290,16 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         }
         HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if (pl.version == 5 && d_grad) {
-            // pass 1 | fork: the side stream reduces the first G half and ll while pass 2 runs (it is
-            // MFMA bound and leaves HBM and wave slots free) | pass 2 | join | second half
+            // pass 1 | pass 2 | one reduction of all per-chunk partials.  (Until round 3 the first G half was reduced on a
+            // side stream "beside" pass 2: the dispatch timeline shows that reduction finishing ~14 us AFTER pass 2 --
+            // whatever the stream priority -- and holding up the second one, 42 us in all against 30 us for a single
+            // streaming pass over both halves; at full size the difference is below the noise.)
             hipError_t e = launch_fused5(pl, fp, h->stream, 1);
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 1 launch: ") + hipGetErrorString(e));
-            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true, 0, pl.ktl,
-                                      h->aux_stream);
-            if (rc) return rc;
-            HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
             e = launch_fused5(pl, fp, h->stream, 2);
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 2 launch: ") + hipGetErrorString(e));
             HIPCHK(hipEventRecord(h->ev[2], h->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, false, pl.ktl, pl.kth);
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
             if (rc) return rc;
             HIPCHK(hipEventRecord(h->ev[3], h->stream));
             h->timing_valid = true;
