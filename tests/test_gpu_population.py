@@ -465,3 +465,81 @@ def test_two_data_sequences_log_p_and_lockstep_map():
     st = popn.last_fit_stats
     assert st['converged_gtol'] + st['stalled'] + st['maxiter'] == 4
     popn.release_data()
+
+
+def test_lockstep_row_kernels_equal_tensor_op_bookkeeping(std4):
+    """The lock-step optimizer's bookkeeping as HIP row kernels (pgl_bfgs_trial / objective / accept / update_dev,
+    the default for theta-row packings) against the same state machine in framework tensor ops: identical
+    iterates -- same number of iterations and evaluations, objectives equal to rounding -- for the group-lasso
+    prior (standard_glm), a Gaussian impulse prior, a BasisStimulus model (stimulus block of the prior kernel) and a
+    neuron sub-range; a NaN gradient (zero impulse group under the group lasso, priors.py:202) takes the same path."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    model, popn, data = std4
+    cases = [(popn, data, 0, 4), (popn, data, 1, 3)]
+    mg = make_model('standard_glm', N=4, dt=0.001)
+    mg['impulse']['prior'] = {'type': 'gaussian', 'mu': 0.0, 'sigma': 2.0}
+    pg = Population(mg)
+    pg.add_data(dict((k, v) for k, v in data.items() if not k.startswith('_') and k not in ('fstim', 'preprocessed')))
+    cases.append((pg, data, 0, 4))
+    mb = make_model('standard_glm', N=4, dt=0.001)
+    mb['bkgd'] = {'type': 'basis', 'D_stim': 2, 'dt_max': 0.3, 'basis': mb['bkgd']['basis']}
+    pb = Population(mb)
+    dstim = dict((k, v) for k, v in data.items() if not k.startswith('_') and k not in ('fstim', 'preprocessed'))
+    dstim['stim'] = np.random.RandomState(8).randn(int(round(data['T'] / 0.1)), 2)
+    dstim['dt_stim'] = 0.1
+    pb.add_data(dstim)
+    cases.append((pb, dstim, 0, 4))
+    for k, (pp, dd, lo, hi) in enumerate(cases):
+        x0 = pp.sample(np.random.RandomState(40 + k))
+        if k == 0:
+            x0['glms'][2]['imp']['w_ir'][5:10] = 0.0          # zero group: NaN prior gradient at the start
+        xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+        fa, ita, eva = fit_glms_batched_torch(pp, xa, n_lo=lo, n_hi=hi, row_kernels=True)
+        sa = dict(pp.last_fit_stats)
+        fb, itb, evb = fit_glms_batched_torch(pp, xb, n_lo=lo, n_hi=hi, row_kernels=False, lag=1)
+        sb = dict(pp.last_fit_stats)
+        assert sa.pop('bookkeeping') == 'hip row kernels' and 'bookkeeping' not in sb
+        assert (ita, eva) == (itb, evb) and sa == sb, (k, sa, sb)
+        assert np.allclose(fa, fb, rtol=1e-12, atol=0), (k, fa, fb)
+        for n in range(lo, hi):
+            assert np.allclose(pp.glm.theta_row(xa['glms'][n]), pp.glm.theta_row(xb['glms'][n]), rtol=1e-9, atol=1e-12)
+    pg.release_data()
+    pb.release_data()
+
+
+def test_all_f64_epilogue_option_and_identity_rows():
+    """PGL_OPT_EPI_F64 (run-time switch of the single-precision exp(-x) correction): same ll and gradient to 1e-12 in
+    the regime where the correction is used (currents > 12), bit-identical outside it; pgl_identity_rows_dev touches
+    exactly the flagged rows."""
+    import torch
+    from tests import helpers as Hh
+    from theano_pyglm_amd import _lib
+    for bias_mu, N, nT in ((20.0, 40, 3000), (2.0, 40, 3000), (20.0, 130, 1500)):
+        p = Hh.Problem(N, nT, Hh.std_ibasis(), seed=7, bias_mu=bias_mu, w_scale=0.3)
+        d = p.device()
+        ll0, g0 = d.ll_grad(p.theta, p.Weff)
+        d.set_option(_lib.OPT_EPI_F64, 1)
+        ll1, g1 = d.ll_grad(p.theta, p.Weff)
+        d.set_option(_lib.OPT_EPI_F64, 0)
+        ll2, g2 = d.ll_grad(p.theta, p.Weff)
+        assert np.array_equal(ll0, ll2) and np.array_equal(g0, g2)
+        assert np.allclose(ll0, ll1, rtol=1e-12, atol=0) and Hh.rel_err(g0, g1) < 1e-12
+        if bias_mu < 12:
+            assert np.array_equal(ll0, ll1) and np.array_equal(g0, g1)
+        ll_or, g_or = p.oracle_ll_grad(0, 3)
+        assert np.allclose(ll1[:3], ll_or, rtol=1e-10) and Hh.rel_err(g1[:3], g_or) < 1e-9
+        d.close()
+    p = Hh.Problem(3, 200, Hh.std_ibasis(), seed=1)
+    d = p.device()
+    M, P = 5, 37
+    Hm = torch.randn(M, P, P, dtype=torch.float64, device='cuda')
+    ref = Hm.clone()
+    scale = torch.tensor([0.0, 1.0, 0.0, 2.5, 0.0], dtype=torch.float64, device='cuda')
+    d.reset_identity_dev(Hm.data_ptr(), scale.data_ptr(), M, P)
+    d.sync()
+    torch.cuda.synchronize()
+    eye = torch.eye(P, dtype=torch.float64, device='cuda')
+    for m in range(M):
+        want = ref[m] if scale[m] == 0 else float(scale[m]) * eye
+        assert torch.equal(Hm[m], want)
+    d.close()
