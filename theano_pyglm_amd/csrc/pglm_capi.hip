@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -407,12 +408,28 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     return PGL_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs several microseconds of host time: it is issued once per
+// kernel instantiation and device (and again only for a larger size), not on every launch -- the small configurations
+// are bound by the host's submission rate (tools/step_bench.py)
+template <typename K>
+static hipError_t ensure_dyn_lds(K kern, size_t bytes)
+{
+    static std::map<std::pair<const void*, int>, size_t> have;      // (kernel, device) -> size already granted
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& h = have[std::make_pair(reinterpret_cast<const void*>(kern), dev)];
+    if (bytes <= h) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e == hipSuccess) h = bytes;
+    return e;
+}
+
 template <int KTW, int PTW, int NW, int CAP, typename FT>
 static hipError_t launch_fused2_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
     auto kern = k_fused2<KTW, PTW, NW, CAP, FT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    hipError_t e = ensure_dyn_lds(kern, pl.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NW * 64), pl.lds, s, fp);
     return hipGetLastError();
@@ -439,11 +456,8 @@ static hipError_t launch_fused3_t(const Plan& pl, const FusedParams& fp, hipStre
 {
     auto k1 = k_fused3<KTH, PGL_CAP, 1>;
     auto k2 = k_fused3<KTH, PGL_CAP, 2>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    hipError_t e = ensure_dyn_lds(k1, pl.lds);
+    if (e == hipSuccess) e = ensure_dyn_lds(k2, pl.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
     e = hipGetLastError();
@@ -475,11 +489,8 @@ static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStre
     auto k1 = k_fused5<KTL, KTH, 1>;
     auto k2 = k_fused5<KTL, KTH, 2>;
     const size_t lds2 = (size_t)2 * pgl_img_bytes(KTH) + 256;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipError_t e = ensure_dyn_lds(k1, pl.lds);
+    if (e == hipSuccess) e = ensure_dyn_lds(k2, lds2);
     if (e != hipSuccess) return e;
     if (pass != 2) {
         hipLaunchKernelGGL(k1, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
@@ -516,8 +527,7 @@ static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStre
     constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256 + (size_t)NW * 384;
     if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
         auto kern = k_fused6<KTW, PTW, MT, NW>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+        hipError_t e = ensure_dyn_lds(kern, pl.lds);
         if (e != hipSuccess) return e;
         if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, NW * 64, pl.lds);
         hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NW * 64), pl.lds, s, fp);
@@ -579,8 +589,7 @@ template <int KT, int NWV>
 static hipError_t launch_fused7_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
     auto kern = k_fused7<KT, NWV>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    hipError_t e = ensure_dyn_lds(kern, pl.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NWV * 64), pl.lds, s, fp);
     return hipGetLastError();
@@ -1175,6 +1184,9 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
     if (!stream) stream = h->stream;
     const long long nfrag = (long long)pl.nPT * nkt * 256;
     // one block per 64-element fragment, its waves share the chunks (>= 32 chunks = 16 KB per wave, at most 8 waves)
+    // (measured round 3, tools/step_bench.py + rocprofv3 timeline: the reduction of a SMALL population -- 20 blocks at
+    //  C1 -- takes 20 us whatever the number of waves per fragment or loads in flight per lane (8 -> 16 of either):
+    //  it is not the latency chain of its loads; 1024-thread blocks cost the 1/8-recording shard of C3 +25 us)
     int nwf = h->opt_finw > 0 ? h->opt_finw : std::max(4, std::min(8, pl.nChunks / 32));
     if (with_ll) nwf = std::max(nwf, 4);                  // the ll blocks reduce with 256 threads (pgl_reduce_ll)
     int blocks = (int)((nfrag + 63) / 64);
