@@ -39,12 +39,12 @@ for ps, names in ((0, names1), (1, names2)):
         print("  %-12s mean %8.0f   waves0-3 %8.0f  waves4-7 %8.0f   min %8.0f max %8.0f"
               % (nm, d[:, :, i].mean(), d[:, :4, i].mean(), d[:, 4:, i].mean(), d[:, :, i].min(), d[:, :, i].max()))
 
-ts = np.zeros((4096, 4), dtype=np.int64)
+ts = np.zeros((4096, 5), dtype=np.int64)
 if hasattr(lib, 'pgl_debug_prof_ts'):
     lib.pgl_debug_prof_ts.argtypes = [C.c_void_p, C.c_int]
     if lib.pgl_debug_prof_ts(ts.ctypes.data_as(C.c_void_p), ts.size) == 0:
         # (the table holds the LAST launch that wrote it: pass 2 when the gradient was requested)
-        ts = ts[:min(nblk, 4096)].astype(float) / 100.0
+        ts = ts[:min(nblk, 4096), :4].astype(float) / 100.0
         t0 = ts[:, 0].min()
         print("last launch, workgroup timeline (us): entry mean %.1f max %.1f | entry->loop mean %.1f max %.1f | loop mean %.1f | "
               "loop end->exit mean %.1f max %.1f | last exit %.1f"

@@ -8,7 +8,9 @@ cd "$GRAFT_REPO_ROOT"
 python3 -c 'import __graft_entry__ as g; g.build_hip()'
 OUT=gpurun_out/prof_cfg_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
-rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 tools/config_table.py profiles/${TAG}_config_table.json > $OUT/table.log 2>&1
+# the table itself from an unprofiled run (the tracer adds ~25 us to a 20 us kernel), the per-kernel durations from a traced one
+python3 tools/config_table.py profiles/${TAG}_config_table.json > $OUT/table.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 tools/config_table.py > $OUT/table_traced.log 2>&1
 T=$(find $OUT/trace -name '*results.db' | head -1)
 python3 tools/rocprof_summary.py stats "$T" profiles/${TAG}_configs_kernel_stats.csv
 grep '^|' $OUT/table.log > profiles/${TAG}_config_table.md
