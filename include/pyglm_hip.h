@@ -65,6 +65,11 @@ typedef struct pgl_context* pgl_handle;
                                 * are all > 12 the exp(-x) < 6.2e-6 inside softplus / sigmoid comes from the single-precision
                                 * hardware exp (rate and residual within 5e-13 relative of the all-f64 form) */
 
+#define PGL_OPT_TIMING 6       /* HIP events around every n-th evaluation (pgl_last_timing / pgl_timing_summary): 1 = every call
+                                * (default), n > 1 = a sample, 0 = none.  An event between two kernels of a stream costs ~6 us of
+                                * GPU idle time; loops that queue evaluations back to back (optimisers, bench.py) sample or
+                                * switch the events off */
+
 const char* pgl_last_error(void);
 int pgl_version(void);
 /* number of visible HIP devices (0 when there is none; never fails) */

@@ -20,6 +20,7 @@ OPT_NCHUNKS = 2
 OPT_KERNEL = 3
 OPT_GIBBS_KERNEL = 4
 OPT_EPI_F64 = 5
+OPT_TIMING = 6
 
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [

@@ -80,7 +80,8 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_epi64 = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_epi64 = 0, opt_timing = 1;
+    long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
 };
@@ -745,6 +746,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
     case PGL_OPT_EPI_F64: h->opt_epi64 = value ? 1 : 0; return PGL_OK;
+    case PGL_OPT_TIMING: if (value < 0) return fail(PGL_ERR_ARG, "timing interval < 0"); h->opt_timing = value; h->call_no = 0; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -1272,8 +1274,14 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     if (d_grad) ENSURE(h->Gpart, maxG);
     const int P = 1 + h->Dstim + h->Kimp;
 
-    h->ev = h->evr[h->ev_launches % pgl_context::NEV];
-    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    // HIP events of this evaluation (pgl_last_timing / pgl_timing_summary): every PGL_OPT_TIMING-th call only -- an
+    // event between two kernels of a stream costs ~6 us of GPU idle time (the next dispatch waits for the marker:
+    // rocprofv3 timeline, pass 1 -> pass 2 without an event between them start back to back)
+    const bool rec = h->opt_timing > 0 && (h->call_no++ % h->opt_timing) == 0;
+    if (rec) {
+        h->ev = h->evr[h->ev_launches % pgl_context::NEV];
+        HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    }
     if (!sliced) {
         const Plan& pl = plans[0];
         const bool direct = plan_reads_theta(pl);
@@ -1300,7 +1308,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             fp.theta = d_theta;
             fp.Weff = d_Weff;
         }
-        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         if (pl.version == 5 && d_grad) {
             // pass 1 | pass 2 | one reduction of all per-chunk partials.  (Until round 3 the first G half was reduced on a
             // side stream "beside" pass 2: the dispatch timeline shows that reduction finishing ~14 us AFTER pass 2 --
@@ -1310,17 +1318,17 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 1 launch: ") + hipGetErrorString(e));
             e = launch_fused5(pl, fp, h->stream, 2);
             if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pass 2 launch: ") + hipGetErrorString(e));
-            HIPCHK(hipEventRecord(h->ev[2], h->stream));
+            if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
             rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
             if (rc) return rc;
-            HIPCHK(hipEventRecord(h->ev[3], h->stream));
-            h->timing_valid = true;
-            ++h->ev_launches;
+            if (rec) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+            h->timing_valid = rec;
+            if (rec) ++h->ev_launches;
             return PGL_OK;
         }
         hipError_t e = launch_any(pl, fp, h->stream);
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
-        HIPCHK(hipEventRecord(h->ev[2], h->stream));
+        if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
         if (d_grad) {                       // one launch: G reduction + (trailing blocks) ll reduction
             rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
             if (rc) return rc;
@@ -1337,7 +1345,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         const long long row1 = std::min<long long>(h->nT, (long long)(p0.tile0 + p0.nTiles) * 16);
         ENSURE(h->Xbuf, (size_t)h->nT * xs * 8);
         HIPCHK(hipMemsetAsync((double*)h->Xbuf.p + row0 * xs, 0, (size_t)(row1 - row0) * xs * 8, h->stream));
-        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepParams sp;
         if (h->sep) {                                          // phase 0: X = I_stim (separable stimulus)
             if (h->cur_pidx) return fail(PGL_ERR_UNSUPPORTED, "neuron lists with a separable stimulus");
@@ -1390,11 +1398,11 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
                 if (rc) return rc;
             }
         }
-        HIPCHK(hipEventRecord(h->ev[2], h->stream));
+        if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     }
-    HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    h->timing_valid = true;
-    ++h->ev_launches;
+    if (rec) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    h->timing_valid = rec;
+    if (rec) ++h->ev_launches;
     return PGL_OK;
 }
 
@@ -1521,7 +1529,7 @@ int pgl_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* theta, const dou
 int pgl_last_timing(pgl_handle h, double* fused_ms, double* total_ms)
 {
     if (!h) return fail(PGL_ERR_ARG, "null handle");
-    if (!h->timing_valid) return fail(PGL_ERR_STATE, "no pgl_ll_grad call to time yet");
+    if (!h->timing_valid) return fail(PGL_ERR_STATE, "the last pgl_ll_grad call recorded no events (none yet, or PGL_OPT_TIMING skipped it)");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventSynchronize(h->ev[3]));
     float a = 0, b = 0;

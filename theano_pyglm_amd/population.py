@@ -109,6 +109,9 @@ class Population(object):
                                self.glm.dt, device=self.device)
             h.set_spikes(S)
             h.set_basis(imp.ibasis)
+            # no per-evaluation HIP events on the product path: an event between two kernels of a stream idles the GPU
+            # for ~6 us (pgl_last_timing is for the measurement tools, which drive DeviceGlm directly)
+            h.set_option(_lib.OPT_TIMING, 0)
             if self.glm.Dstim > 0:
                 if data.get('fstim', None) is not None:
                     if getattr(self.glm.bkgd_model, 'separable', False):

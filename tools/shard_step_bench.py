@@ -20,6 +20,8 @@ theta = np.zeros((N, P)); theta[:, 0] = 20.0 + 0.1 * rng.standard_normal(N)
 theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
 dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt)
 dev.set_spikes(S); dev.set_basis(ib)
+TIMING = int(os.environ.get('TIMING', '1'))
+dev.set_option(_lib.OPT_TIMING, TIMING)
 if os.environ.get('FINW'): dev.set_option(97, int(os.environ['FINW']))      # finalize waves per fragment (A/B)
 _st = torch.cuda.Stream(); torch.cuda.set_stream(_st)      # handle 0 (default stream) cannot be named
 dev.set_stream(_st.cuda_stream)
@@ -31,13 +33,14 @@ for G in Gs:
     dev.set_time_range(t_lo, t_hi)
     for _ in range(8):
         dev.ll_grad_dev(d_theta.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
-    torch.cuda.synchronize(); dev.timing_summary(reset=True)
+    torch.cuda.synchronize()
+    if TIMING: dev.timing_summary(reset=True)
     K = 100
     t0 = time.perf_counter()
     for _ in range(K):
         dev.ll_grad_dev(d_theta.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / K * 1e3
-    n, fused, total = dev.timing_summary(reset=True)
+    n, fused, total = dev.timing_summary(reset=True) if TIMING else (0, float('nan'), float('nan'))
     print("G=%d bins %d: step %.3f ms (fused kernels %.3f ms, prep+fused+finalize %.3f ms) -> ideal speed-up "
           "without all-reduce %.2fx" % (G, t_hi - t_lo, wall, fused, total, 0))
