@@ -282,6 +282,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
     ap.add_argument('--no-mcmc', action='store_true', help='skip the secondary MCMC inner-ll measurement')
+    ap.add_argument('--no-ab', action='store_true',
+                    help='skip the A/B loops after the timed region (in-kernel features, all-f64 epilogue): profiler '
+                         'passes use it so that per-kernel averages and counters describe the headline kernel only')
     ap.add_argument('--shard', choices=['time', 'neurons'], default='time')
     # dev-only: exercise the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo collectives)
     ap.add_argument('--debug-single-device', action='store_true')
@@ -440,7 +443,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     alt = None
-    if world == 1 and not args.f32_features and info['kernel_version'] == 5:
+    if world == 1 and not args.f32_features and info['kernel_version'] == 5 and not args.no_ab:
         # the same evaluation with the features regenerated from the spike events inside the kernel
         # (the north star's fused filter kernel, PGL_OPT_KERNEL=3) -- reported beside the headline
         dev.set_option(_lib.OPT_KERNEL, 3)
@@ -457,7 +460,7 @@ def main():
                "frac": info['flops'] / (alt_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
         dev.set_option(_lib.OPT_KERNEL, 0)
     allf64 = None
-    if world == 1 and not args.f32_features:
+    if world == 1 and not args.f32_features and not args.no_ab:
         # the same evaluation with the all-f64 rate epilogue (PGL_OPT_EPI_F64: no single-precision exp(-x)
         # correction), so that the effect of that term is visible beside every headline number
         dev.set_option(_lib.OPT_EPI_F64, 1)

@@ -9,9 +9,9 @@ bash tools/profile_bench.sh r03 > $R/profile_bench.log 2>&1; cp profiles/r03_* $
 echo "== config table"
 bash tools/profile_configs.sh r03 > $R/profile_configs.log 2>&1; cp profiles/r03_config* $R/ 2>/dev/null; cat profiles/r03_config_table.md
 echo "== steady-state cost per evaluation"
-for c in C1 C2 C5 C3; do python3 tools/step_bench.py $c 2>&1 | tail -1; done | tee $R/r03_step_bench.txt
+for t in 1 0; do for c in C1 C2 C5 C3; do TIMING=$t python3 tools/step_bench.py $c 2>&1 | tail -1; done; done | tee $R/r03_step_bench.txt
 echo "== time shards"
-python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G=" | tee $R/r03_shard_steps.txt
+(echo "# HIP events around every evaluation"; python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G="; echo "# no events (the product path)"; TIMING=0 python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G=") | tee $R/r03_shard_steps.txt
 rocprofv3 --kernel-trace --stats -d $R/trace -- python3 tools/shard_step_bench.py 8 > $R/shard_trace.log 2>&1
 T=$(find $R/trace -name '*results.db' | head -1)
 python3 tools/rocprof_summary.py stats "$T" $R/r03_shard8_kernel_stats.csv
