@@ -11,7 +11,7 @@ nbad = 0
 ncmp = {}
 nnf = 0
 for trial in range(40):
-    N = int(rng.choice([17, 33, 48, 64, 80, 128, 130]))
+    N = int(rng.choice([3, 9, 17, 30, 33, 48, 64, 80, 128, 130]))
     kind = str(rng.choice(['explinear', 'exp']))
     nT = int(rng.choice([700, 2500, 6000]))
     Dstim = int(rng.choice([0, 0, 3]))
@@ -19,7 +19,7 @@ for trial in range(40):
                   weighted=bool(rng.rand() < 0.5), Dstim=Dstim, rate_hz=float(rng.choice([5.0, 20.0, 60.0])))
     th = p.theta.copy()
     # a few wild neurons
-    for n in rng.choice(N, size=int(rng.randint(0, 5)), replace=False):
+    for n in rng.choice(N, size=min(N, int(rng.randint(0, 5))), replace=False):
         mode = rng.randint(4)
         if mode == 0: th[n, 0] = rng.uniform(-800, 800)
         elif mode == 1: th[n, 1:] *= rng.choice([20.0, 200.0, 2000.0])
