@@ -1887,11 +1887,29 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         rc = stage_cols(h, ncols, n_post, n_pre, aw_cur, w, K, gp, (size_t)ncols * K * 8, true, &max_ev);
         if (rc) return rc;
         gp.CP = std::min(ncols, 8);
-        gp.nsplit = (gp.CP >= 3) ? 1 : (gp.CP == 2) ? 2 : 4;
+        gp.nsplit = (gp.CP >= 3) ? 1 : (gp.CP == 2) ? 2 : ((PGL_GRB / 64) % 4 == 0 ? 4 : 3);   // (PGL_GRB / 64) % nsplit == 0
         const int ygroups = (ncols + gp.CP - 1) / gp.CP;
         const long long nrows = h->t_hi - h->t_lo;
         const long long nsub = (nrows + PGL_GRB - 1) / PGL_GRB;
-        gp.nloop = (int)std::max<long long>(1, std::min<long long>(PGL_GNL, nsub * ygroups / (8LL * h->numCU)));
+        // sub-blocks per workgroup: three workgroups fit a CU (LDS); the grid should fill a whole number of rounds of
+        // those slots -- e.g. 3 136 workgroups on 768 slots run 5 rounds for 4.08 rounds of work.  Among the loop
+        // lengths that still amortise the per-workgroup staging (>= PGL_GNL / 4) take the best-filled one.
+        {
+            const long long slots = 3LL * h->numCU;
+            int best = 1;
+            double best_fill = 0.0;
+            for (int nl = (nsub * ygroups <= slots) ? 1 : PGL_GNL; nl >= 1; --nl) {     // (fewer units than slots: one each)
+                const long long wgs = ((nsub + nl - 1) / nl) * ygroups;
+                const long long rounds = (wgs + slots - 1) / slots;
+                const double fill = (double)(nsub * ygroups) / (double)(rounds * slots * nl);
+                if (fill > best_fill + 0.02 || (nl >= PGL_GNL / 4 && fill > best_fill)) {
+                    best_fill = fill;
+                    best = nl;
+                }
+                if (nl <= PGL_GNL / 4 && best_fill > 0.0 && wgs >= slots) break;
+            }
+            gp.nloop = best;
+        }
         if ((h->opt_dbg >> 8) & 0xf) gp.nloop = std::min(PGL_GNL, (h->opt_dbg >> 8) & 0xf);      // tests: force the sub-block loop
         const int nblk = (int)((nsub + gp.nloop - 1) / gp.nloop);
         const int sblk = std::max(1, (max_ev + 255) / 256);
@@ -1903,7 +1921,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.hs = (double*)h->ghs.p;
         gp.dbg = h->opt_dbg & 0xff;
         const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
-                            (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX) * 8 +
+                            (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX + (size_t)gp.CP) * 8 +
                            (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
         auto rate_kernel = k_gibbs_rate_cols;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rate_kernel),

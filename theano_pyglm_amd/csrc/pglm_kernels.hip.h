@@ -408,6 +408,7 @@ __device__ long long g_pgl_prof_ts[4096][5];              // per workgroup: entr
 #define PGL_PROF_DUMMY
 #endif
 typedef double pgl_d2 __attribute__((ext_vector_type(2)));
+typedef double pgl_d16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) double* pgl_k_cdp;
 #define PGL_ROW __builtin_amdgcn_sched_barrier(0)
 
@@ -2681,6 +2682,10 @@ __global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ Gp
     // A block of blockDim.x / 64 waves (1 .. 16) owns one 64-element fragment of G: its chunk partials are one
     // contiguous run of nChunks x 512 bytes (pgl_gpart), the waves take consecutive pieces of it.
     const int P = 1 + DsAll + Nall * B;
+    // (Measured round 3 and dropped: splitting the chunks of a fragment over Q blocks whose last arriver -- agent-scope
+    //  fence + counter -- combines the partials, to put a 16-fragment reduction on all CUs: the release / acquire fences
+    //  (__threadfence in every wave of 800 blocks) write back and invalidate the XCD's L2: +27 us at C1, +140 us at C2.  The same holds for any reduction
+    //  "in the tail" of the fused kernels: a kernel boundary is the cheapest cross-XCD synchronisation there is.)
     const int nwf = (int)(blockDim.x >> 6);
     const long long nfrag = (long long)nPT * nkt * 256;
     const int gblocks = (int)((nfrag + 63) / 64);
@@ -3096,7 +3101,8 @@ struct GibbsColsParams {
     double* __restrict__ partS;          // spike-term partials
     int nloop;                           // sub-blocks of PGL_GRB bins per workgroup
     double* __restrict__ hs;             // [ncols][R] impulse response of every listed pair (k_gibbs_cols_setup)
-    int dbg;                             // dev: 1 no event loop, 2 no phase B, 4 no event staging, 8 no GX loads
+    int dbg;                             // dev: 1 no event loop, 2 no phase B, 4 no event staging, 8 no GX loads, 16 no band passes,
+                                         // 32 no exp, 64 no merge tree (results invalid when != 0)
 };
 
 #define PGL_GECAP 24          // staged presynaptic events per column and block (k_gibbs_ll_cols)
@@ -3250,16 +3256,23 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 // scans (fixed order, no atomics).  ~41 KB of LDS per workgroup: three workgroups per CU.
 //   part[blk][c][k] = sum_t lam_k(t)   (k_gibbs_reduce_cols2 applies -dt and adds the spike terms)
 // ---------------------------------------------------------------------------
-#define PGL_GRB 256           // bins per sub-block
-#ifndef PGL_GFAST_HI
-#define PGL_GFAST_HI 0x40280000u   // high word of the double 12.0: from |x| >= 12 the log1p(exp(-|x|)) < 6.2e-6 term of the softplus
+#ifndef PGL_GRB
+#define PGL_GRB 256
+#endif
+//                               bins per sub-block: six segments of 64 per wave and weight -- at C4 13 % of the evaluations are band
+                              // elements, ~50 per (item, weight): one f64 pass at ~80 % lane utilisation (four segments: 33 = 52 %)
+#ifndef PGL_GFAST
+#define PGL_GFAST 12.0f             // (the test reads the single-precision |x|) from |x| >= 12 the log1p(exp(-|x|)) < 6.2e-6 term of the softplus
                                    // comes from the single-precision hardware exp (<= 6e-12 absolute per bin).  Measured round 3:
-                                   // switching at |x| >= 8 (0x40200000u, three series terms) moves 35 % of the compacted f64
+                                   // switching at |x| >= 8 (three series terms) moves 35 % of the compacted f64
                                    // elements to the fast path -- |x| is uniform below 12 at C4, tools/gibbs_x_hist.py -- but buys
                                    // only 3 % (1.41 vs 1.45 ms) for a 30x larger error (1.7e-10 per bin: the 1e-11 parity test
                                    // against the all-f64 kernel fails), so the threshold stays at 12
 #endif
-#define PGL_GQ 256            // band-queue entries per wave (the band elements of one weight: <= 4 x 64)
+#ifndef PGL_GQ
+#define PGL_GQ PGL_GRB
+#endif
+//                               band-queue entries per wave (the band elements of one weight: <= PGL_GRB)
 
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
 __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
@@ -3273,7 +3286,35 @@ __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams 
     p.hs[i] = hh;
 }
 
-#define PGL_GNL 8             // at most this many sub-blocks per workgroup
+#define PGL_GNL 16            // at most this many sub-blocks per workgroup
+
+// Pairwise merges of lane-partial vectors (the reduction tree of k_gibbs_rate_cols).  merge32(a, b): lanes 0..31
+// = a[l] + a[l + 32], lanes 32..63 = b[l - 32] + b[l] (v_permlane32_swap: the upper half of the first register
+// changes places with the lower half of the second); merge16 the same with rows of 16 lanes (odd rows of the first
+// <-> even rows of the second: v_permlane16_swap); merge_dpp<row_mirror, 8> / <row_half_mirror, 4> keep the own
+// half / quad of p (lower) resp. q (upper) and add the other one mirrored.
+typedef unsigned pgl_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double pgl_merge32(const double a, const double b)
+{
+    const pgl_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const pgl_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double pgl_merge16(const double a, const double b)
+{
+    const pgl_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const pgl_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL, int BIT>
+__device__ __forceinline__ double pgl_merge_dpp(const double p, const double q, const int lane)
+{
+    const bool up = (lane & BIT) != 0;
+    const double keep = up ? q : p, send = up ? p : q;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), CTRL, 0xf, 0xf, true);
+    return keep + __hiloint2double(hi, lo);
+}
 
 // sum of v over the 64 lanes of a wave, valid in lane 63: row scans by DPP shifts (zero fill), then the row
 // totals travel with row_bcast15 / row_bcast31 -- fixed order, no LDS
@@ -3298,14 +3339,15 @@ __device__ __forceinline__ double pgl_wave_sum_to_last(double v)
 __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RB = PGL_GRB, XS = RB + 2, NJ = 8;
+    constexpr int RB = PGL_GRB, XS = RB + 2, NJ = RB / 32, NSEG = RB / 64;
     const int K = p.K, CP = p.CP, NSPLIT = p.nsplit, RPB = 256 / CP, R = p.R;
     double* HS = reinterpret_cast<double*>(smem);                   // [CP][R] impulse response of the pair
     double* X0 = HS + CP * R;                                       // [CP][XS] bias + I_stim + I_net of the sub-block
     double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
     double* Qx = Wl + CP * PGL_KMAX;                                // [4][PGL_GQ]
     double* PS = Qx + 4 * PGL_GQ;                                   // [CP * NSPLIT][PGL_KMAX]
-    int2* evS = reinterpret_cast<int2*>(PS + CP * NSPLIT * PGL_KMAX);   // [CP][PGL_GECAP]
+    double* WM = PS + CP * NSPLIT * PGL_KMAX;                       // [CP] largest |candidate weight| of the column
+    int2* evS = reinterpret_cast<int2*>(WM + CP);                   // [CP][PGL_GECAP]
     int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP); // [CP][PGL_GNL] first event of the sub-block's window
     int* WH = WL + CP * PGL_GNL;                                    // [CP][PGL_GNL] one past its last event
     const int tid = threadIdx.x;
@@ -3345,8 +3387,142 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
     // evaluation role: a wave owns whole columns; its lanes are consecutive bins
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double* const Qxw = Qx + wave * PGL_GQ;
-    const int nseg = RB / NSPLIT / 64;                              // 4, 2 or 1 segments of 64 bins per item
+    const int nseg = NSEG / NSPLIT;                                 // 6, 3 or 2 segments of 64 bins per item
     __syncthreads();
+
+    for (int i = tid; i < CP; i += 256) {                           // largest |w_k| of every column (regime pre-check)
+        double m = 0.0;
+        for (int k = 0; k < K; ++k) m = fmax(m, fabs(Wl[i * PGL_KMAX + k]));
+        WM[i] = m;
+    }
+    __syncthreads();
+
+    // The K lane-partial vectors of an (item, sub-block) -- 64 partial sums each -- are merged pairwise as they
+    // appear (pgl_merge32 / 16 / 8 / 4: after four levels ONE vector holds all 16 weights, four lanes each, weight k
+    // in the quad bitrev4(k)), added per lane over the workgroup's sub-blocks, and reduced across the quad once per
+    // workgroup: 15 merges (57 instructions) per item and sub-block instead of one 24-instruction DPP reduction per
+    // weight.  Fixed order, no atomics, no LDS.
+    double accV[2] = {0.0, 0.0};
+    auto eval_item = [&](const int item, const int sb, const long long tb0, const int nb, double& accv) {
+        const int c = item / NSPLIT, sp = item % NSPLIT;
+        const int cc = blockIdx.y * CP + c;
+        if (cc >= p.ncols || (p.dbg & 2)) return;
+        const int tseg = sp * nseg * 64 + lane;                     // bin of segment 0 inside the sub-block
+        // pair current of the lane's bins: every event of the column's window adds count * h[t - s - 1]
+        double icr[NSEG];
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) icr[sg] = 0.0;
+        {
+            const int lo = WL[c * PGL_GNL + sb], cnt = WH[c * PGL_GNL + sb] - lo;
+            const bool staged = cnt <= PGL_GECAP;
+            const double* hs = HS + c * R;
+            const int tr = (int)tb0 + tseg - 1;                     // d = tr + 64*sg - e.x
+            if (!(p.dbg & 1)) {
+                for (int q = 0; q < cnt; ++q) {
+                    const int2 e = staged ? evS[c * PGL_GECAP + q] : p.spk[lo + q];
+                    const double ecnt = (double)e.y;
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        const int d = tr + 64 * sg - e.x;
+                        if ((unsigned)d < (unsigned)R) icr[sg] = fma(ecnt, hs[d], icr[sg]);
+                    }
+                }
+            }
+        }
+        const double awc = p.aw[cc];
+        const double wmax = WM[c];
+        double x0r[NSEG];
+        bool bad = false;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const int tt = tseg + 64 * sg;
+            const bool vl = (sg < nseg) && (tt < nb);
+            // lanes without a bin: x = -600 for every weight -- fast regime, exp2f underflows to 0, max(x, 0) = 0:
+            // they add exact zeros and need no mask in the weight loop
+            x0r[sg] = vl ? X0[c * XS + tt] - awc * icr[sg] : -600.0;
+            icr[sg] = vl ? icr[sg] : 0.0;
+            // |x_k| <= |x0| + max|w| |ic| for every weight: below 699 no weight reaches the region where lam
+            // underflows (reference NaN semantics) or x is inf / NaN
+            bad = bad || !(fma(wmax, fabs(icr[sg]), fabs(x0r[sg])) < 699.0);
+        }
+        // a wave with such a lane sends every element of the item through the f64 path
+        const bool careful = __ballot(bad) != 0ull;
+        double pend1 = 0.0, pend2 = 0.0, pend3 = 0.0, pend4 = 0.0;
+        auto push = [&](const double tot, const int k) {            // k is wave-uniform: scalar branches
+            if (!(k & 1)) { pend1 = tot; return; }
+            double v = pgl_merge32(pend1, tot);
+            if (!(k & 2)) { pend2 = v; return; }
+            v = pgl_merge16(pend2, v);
+            if (!(k & 4)) { pend3 = v; return; }
+            v = pgl_merge_dpp<0x140, 8>(pend3, v, lane);             // row_mirror
+            if (!(k & 8)) { pend4 = v; return; }
+            accv += pgl_merge_dpp<0x141, 4>(pend4, v, lane);         // row_half_mirror
+        };
+        double w_next = Wl[c * PGL_KMAX];
+        for (int k = 0; k < K; ++k) {
+            const double wk = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(w_next)),
+                                               __builtin_amdgcn_readfirstlane(__double2loint(w_next)));
+            w_next = Wl[c * PGL_KMAX + ((k + 1 < K) ? k + 1 : k)];  // in flight during this iteration
+            // softplus(x) = max(x, 0) + log1p(exp(-|x|)): the first term in f64 for every element (one max, one add),
+            // the second in single precision where |x| >= PGL_GFAST and through the f64 queue elsewhere.
+            // All segments side by side: independent chains.
+            double x[NSEG];
+            bool bl[NSEG];
+            float e[NSEG];
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                // fast regime read off the single-precision |x| (|x| < 699 is known: no upper bound to test)
+                const float af = fabsf((float)x[sg]);
+                const bool f = (af >= PGL_GFAST) && !careful;
+                bl[sg] = !f;
+                const float ee = (p.dbg & 32) ? af : __builtin_amdgcn_exp2f(af * -1.44269504088896340736f);
+                e[sg] = f ? ee : 0.0f;
+            }
+            double accl = 0.0;
+            float acc1 = 0.0f, acc2 = 0.0f;                         // log1p(e) = e - e^2/2 (+O(e^3) < 8e-17)
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                acc1 += e[sg];
+                acc2 = fmaf(e[sg], e[sg], acc2);
+                accl += __builtin_fmax(x[sg], 0.0);
+            }
+            // band elements of this weight: queued per wave, evaluated in f64 on full waves; they contribute
+            // lam - max(x, 0) (the max term is already in accl)
+            bool anyb = false;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) anyb = anyb || bl[sg];
+            if (__ballot(anyb) != 0ull && !(p.dbg & 16)) {
+                int qn = 0;
+                double accq = 0.0;
+#pragma unroll
+                for (int sg = 0; sg < NSEG; ++sg) {
+                    const unsigned long long m = __ballot(bl[sg]);
+                    if (m != 0ull) {
+                        const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (bl[sg]) Qxw[idx] = x[sg];
+                        qn += __popcll(m);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int base = 0; base < qn; base += 64) {         // one call site: the f64 code exists once
+                    const bool v = base + lane < qn;
+                    const double xq = v ? Qxw[base + lane] : 20.0;
+                    const double lam = pgl_lambda_only(xq, 1, PGL_C);
+                    // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700
+                    // (incl. +inf): lam = x, nothing beyond the max term
+                    const double d = (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
+                    accq += v ? d : 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                accl += accq;
+            }
+            if (p.dbg & 64) accv += accl + (double)fmaf(acc2, -0.5f, acc1); else push(accl + (double)fmaf(acc2, -0.5f, acc1), k);
+        }
+        for (int k = K; k < PGL_KMAX; ++k) push(0.0, k);            // flush the pending levels
+    };
 
     for (int sb = 0; sb < p.nloop; ++sb) {
         const long long tb0 = tw0 + (long long)sb * RB;
@@ -3356,6 +3532,8 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
         const int nb = (int)(tb1 - tb0);
         // ---- staging: the presynaptic events that can reach the sub-block (per column) and
         //      X0 = bias + I_stim + I_net of its bins, [column][bin] ----
+        // (requesting the next sub-block's currents into registers before the evaluation and storing them behind it
+        //  was measured at 1.63 ms against 1.40: the other two workgroups of the CU already cover this latency)
         for (int i = tid; i < CP * PGL_GECAP; i += 256) {
             const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
             const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
@@ -3370,107 +3548,36 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
             }
         }
         __syncthreads();
-        // ---- evaluation ----
-        for (int item = wave; item < CP * NSPLIT; item += 4) {
-            const int c = item / NSPLIT, sp = item % NSPLIT;
-            const int cc = blockIdx.y * CP + c;
-            if (cc >= p.ncols || (p.dbg & 2)) continue;
-            const int tseg = sp * nseg * 64 + lane;                 // bin of segment 0 inside the sub-block
-            // pair current of the lane's bins: every event of the column's window adds count * h[t - s - 1]
-            double icr[4] = {0.0, 0.0, 0.0, 0.0};
-            {
-                const int lo = WL[c * PGL_GNL + sb], cnt = WH[c * PGL_GNL + sb] - lo;
-                const bool staged = cnt <= PGL_GECAP;
-                const double* hs = HS + c * R;
-                const int tr = (int)tb0 + tseg - 1;                 // d = tr + 64*sg - e.x
-                if (!(p.dbg & 1)) {
-                    for (int q = 0; q < cnt; ++q) {
-                        const int2 e = staged ? evS[c * PGL_GECAP + q] : p.spk[lo + q];
-                        const double ecnt = (double)e.y;
-#pragma unroll
-                        for (int sg = 0; sg < 4; ++sg) {
-                            const int d = tr + 64 * sg - e.x;
-                            if ((unsigned)d < (unsigned)R) icr[sg] = fma(ecnt, hs[d], icr[sg]);
-                        }
-                    }
-                }
-            }
-            const double awc = p.aw[cc];
-            double x0r[4];
-            bool vl[4];
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                const int tt = tseg + 64 * sg;
-                vl[sg] = (sg < nseg) && (tt < nb);
-                x0r[sg] = X0[c * XS + (vl[sg] ? tt : 0)] - awc * icr[sg];
-            }
-            double colsum = 0.0;                                    // lane k: sum over the bins of lam_k
-            double w_next = Wl[c * PGL_KMAX];
-            for (int k = 0; k < K; ++k) {
-                const double wk = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(w_next)),
-                                                   __builtin_amdgcn_readfirstlane(__double2loint(w_next)));
-                w_next = Wl[c * PGL_KMAX + ((k + 1 < K) ? k + 1 : k)];  // in flight during this iteration
-                // all four segments side by side: four independent chains
-                double x[4];
-                bool fl[4], bl[4];
-                float corr[4];
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
-                    // fast regime: PGL_GFAST <= |x| < 700, read off the high word of |x| (monotonic for non-negative
-                    // doubles; NaN, inf and |x| >= 700 fall outside and take the f64 path)
-                    const unsigned hx = (unsigned)__double2hiint(x[sg]) & 0x7fffffffu;
-                    const bool f = (hx - PGL_GFAST_HI) < (0x4085e000u - PGL_GFAST_HI);
-                    fl[sg] = f && vl[sg];
-                    bl[sg] = !f && vl[sg];
-                }
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
-                    const float e = __builtin_amdgcn_exp2f((float)fabs(x[sg]) * -1.44269504088896340736f);
-                    corr[sg] = e * fmaf(e, -0.5f, 1.0f);
-                }
-                double accl = 0.0;
-                float accc = 0.0f;
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
-                    accc += fl[sg] ? corr[sg] : 0.0f;
-                    accl += (fl[sg] && __double2hiint(x[sg]) > 0) ? x[sg] : 0.0;      // max(x, 0) of a fast element
-                }
-                // band elements of this weight: queued per wave, evaluated in f64 on full waves
-                if (__ballot(bl[0] || bl[1] || bl[2] || bl[3]) != 0ull) {
-                    int qn = 0;
-                    double accq = 0.0;
-#pragma unroll
-                    for (int sg = 0; sg < 4; ++sg) {
-                        const unsigned long long m = __ballot(bl[sg]);
-                        if (m != 0ull) {
-                            const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                            if (bl[sg]) Qxw[idx] = x[sg];
-                            qn += __popcll(m);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    for (int base = 0; base < qn; base += 64) {     // one call site: the f64 code exists once
-                        const bool v = base + lane < qn;
-                        const double xq = v ? Qxw[base + lane] : 20.0;
-                        const double lam = pgl_lambda_only(xq, 1, PGL_C);
-                        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52)
-                        accq += v ? ((lam == 0.0) ? __builtin_nan("") : lam) : 0.0;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    accl += accq;
-                }
-                const double tot = pgl_wave_sum_to_last(accl + (double)accc);
-                const double totb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 63),
-                                                     __builtin_amdgcn_readlane(__double2loint(tot), 63));
-                colsum = (lane == k) ? totb : colsum;
-            }
-            if (lane < K) PS[(c * NSPLIT + sp) * PGL_KMAX + lane] += colsum;   // slots owned by this wave
+        // ---- evaluation: a wave owns at most two items (column x time split) of the workgroup ----
+        for (int half = 0; half < 2; ++half) {                      // rolled: the evaluation code exists once
+            const int item = wave + 4 * half;
+            if (item >= CP * NSPLIT) break;
+            double av = half ? accV[1] : accV[0];
+            eval_item(item, sb, tb0, nb, av);
+            if (half) accV[1] = av; else accV[0] = av;
         }
         __syncthreads();                                            // X0 / events are rewritten by the next sub-block
     }
+    // ---- once per workgroup: the four lanes of every weight's quad (quad_perm butterflies), quad q = bitrev4(k) ----
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int item = wave + 4 * half;
+        if (item < CP * NSPLIT) {
+            double r = accV[half];
+            {
+                int lo = __builtin_amdgcn_update_dpp(0, __double2loint(r), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r), 0xB1, 0xf, 0xf, true);
+                r += __hiloint2double(hi, lo);
+                lo = __builtin_amdgcn_update_dpp(0, __double2loint(r), 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+                hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r), 0x4E, 0xf, 0xf, true);
+                r += __hiloint2double(hi, lo);
+            }
+            const int q = lane >> 2;
+            const int k = ((q >> 3) & 1) | (((q >> 2) & 1) << 1) | (((q >> 1) & 1) << 2) | ((q & 1) << 3);
+            if ((lane & 3) == 0 && k < K) PS[item * PGL_KMAX + k] = r;   // slots owned by this wave
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < CP * PGL_KMAX; i += 256) {
         const int c = i / PGL_KMAX, k = i % PGL_KMAX;
         const int cc = blockIdx.y * CP + c;

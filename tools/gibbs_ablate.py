@@ -22,9 +22,9 @@ print('R', popn.glm.imp_model.ibasis.shape)
 cols = np.arange(N); pre = (cols * 37 + 11) % N
 ws11 = np.tile(np.concatenate((np.sqrt(2) * np.polynomial.hermite.hermgauss(10)[0], [0.0])), (N, 1))
 aw = (A * W)[pre, cols]
-for dbg in (0, 1, 2, 4, 8, 12, 15):
+for dbg in (0, 1, 2, 4, 8, 12, 15, 16, 32, 64, 16 + 32 + 64, 1 + 16 + 32 + 64):
     dev.set_option(99, dbg)
-    for K in (1, 11):
+    for K in (11,):
         ws = ws11[:, :K].copy()
         for _ in range(3): dev.gibbs_ll_cols(cols, pre, aw, ws)
         t0 = time.perf_counter()
