@@ -556,6 +556,64 @@ def test_batched_gibbs_regime_split_kernels_match_f64_kernel_and_oracle():
 
 
 @pytest.mark.gpu
+def test_batched_gibbs_shared_presynaptic_neuron_path():
+    """A sweep step of the collapsed sampler lists the pair (j -> n) for every n: all columns share the presynaptic
+    neuron, and k_gibbs_rate_cols then takes the pair currents from the filtered spike train of that one neuron
+    (k_gibbs_pre_features, B multiply-adds per bin) instead of walking the events of the window per column.  Same
+    numbers as the event-loop form (debug option bit 0x1000 forces it), the all-f64 kernel and the oracle; wide,
+    narrow (time-split) and ragged launches, several sub-blocks per workgroup, a time sub-range."""
+    from theano_pyglm_amd import _lib
+    N = 13
+    p = H.Problem(N, 256 * 6 + 41, H.std_ibasis(), kind='explinear', seed=77, weighted=True, w_scale=0.8,
+                  rate_hz=30.0, bias_mu=9.0)
+    p.theta[:3, 0] = [20.0, -2.0, 13.0]
+    d = p.device()
+    A = (p.Weff != 0).astype(float)
+
+    def oracle(cols, pre, ws, t_lo=0, t_hi=None):
+        out = np.zeros((len(cols), ws.shape[1]))
+        for i, c in enumerate(cols):
+            w = p.theta[c, 1:].reshape(N, p.B)
+            I_imp = O.impulse_currents(p.fS, w)
+            I_other = O.other_current(I_imp, A, p.Weff, pre[i], c)
+            sl = slice(t_lo, t_hi)
+            out[i] = O.mcmc_inner_ll(ws[i], p.theta[c, 0], 0.0, I_other[sl], I_imp[sl, pre[i]],
+                                     p.S[sl, c].astype(float), p.dt, p.kind)
+        return out
+
+    d.gibbs_prepare_all(p.theta, p.Weff)
+    for t_rng in (None, (304, 1500)):
+        if t_rng:
+            d.set_time_range(*t_rng)
+            d.gibbs_prepare_all(p.theta, p.Weff)
+        for n_pre in (0, 5, 12):
+            for cols in (np.arange(N), np.array([4, 9]), np.arange(N)[::-1][:7]):
+                pre = np.full(len(cols), n_pre)
+                ws = np.linspace(-3.0, 3.0, 11)[None, :] * (1.0 + 0.1 * cols[:, None])
+                for nloop in (0, 3):
+                    d.set_option(99, nloop << 8)
+                    shared = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+                    assert np.array_equal(shared, d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws), equal_nan=True)
+                    d.set_option(99, (nloop << 8) | 0x1000)
+                    events = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+                    d.set_option(99, 0)
+                    assert np.array_equal(np.isfinite(shared), np.isfinite(events))
+                    fin = np.isfinite(shared)
+                    assert np.allclose(shared[fin], events[fin], rtol=1e-12, atol=0)
+                d.set_option(_lib.OPT_GIBBS_KERNEL, 1)
+                f64 = d.gibbs_ll_cols(cols, pre, p.Weff[pre, cols], ws)
+                d.set_option(_lib.OPT_GIBBS_KERNEL, 0)
+                both = np.isfinite(f64) & fin
+                assert np.allclose(shared[both], f64[both], rtol=1e-11, atol=0)
+                with np.errstate(all='ignore'):
+                    ref = oracle(cols, pre, ws, *(t_rng or (0, None)))
+                rfin = np.isfinite(ref)
+                assert np.array_equal(fin, rfin)
+                assert np.allclose(shared[rfin], ref[rfin], rtol=1e-10, atol=0)
+    d.close()
+
+
+@pytest.mark.gpu
 def test_batched_gibbs_sub_block_loop_and_event_bursts():
     """k_gibbs_rate_cols: several 256-bin sub-blocks per workgroup (forced through the debug option, as the
     full-size launches have them) with a ragged tail, and presynaptic bursts that overflow the LDS event

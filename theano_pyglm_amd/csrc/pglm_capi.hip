@@ -75,7 +75,7 @@ struct pgl_context {
     int gibbs_npost = -1;
     double gibbs_bias = 0;
     // batched column Gibbs (pgl_gibbs_prepare_all / _ll_cols / _update_cols)
-    DevBuf GX, gtheta, gargs, gpart, gout, ghs;
+    DevBuf GX, gtheta, gargs, gpart, gout, ghs, gfs;
     int gx_xs = 0;                       // row stride of GX (16 * post tiles); 0 = not prepared
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
@@ -709,7 +709,7 @@ int pgl_destroy(pgl_handle h)
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
-                      &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
+                      &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
                       &h->spart};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
@@ -1868,6 +1868,7 @@ static int stage_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     gp.partS = nullptr;
     gp.nloop = 1;
     gp.hs = nullptr;
+    gp.fs = nullptr; gp.fs_stride = 0; gp.hs_region = 0;
     gp.dbg = 0;
     return PGL_OK;
 }
@@ -1920,7 +1921,17 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.partS = gp.part + (size_t)nblk * ncols * PGL_KMAX;
         gp.hs = (double*)h->ghs.p;
         gp.dbg = h->opt_dbg & 0xff;
-        const size_t lds = ((size_t)gp.CP * h->Rk + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
+        // every column with the same presynaptic neuron (a sweep step): its filtered spike train once per launch
+        bool same_pre = ncols >= 2 && !(h->opt_dbg & 0x1000);
+        for (int c = 1; c < ncols && same_pre; ++c) same_pre = n_pre[c] == n_pre[0];
+        gp.hs_region = gp.CP * h->Rk;
+        if (same_pre) {
+            gp.fs_stride = (nrows + 63) / 64 * 64;
+            ENSURE(h->gfs, (size_t)h->B * gp.fs_stride * 8);
+            gp.fs = (const double*)h->gfs.p;
+            gp.hs_region = std::max(gp.hs_region, h->B * (PGL_GRB + 2) + gp.CP * 8);
+        }
+        const size_t lds = ((size_t)gp.hs_region + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
                             (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX + (size_t)gp.CP) * 8 +
                            (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
         auto rate_kernel = k_gibbs_rate_cols;
@@ -1929,6 +1940,11 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
         hipLaunchKernelGGL(k_gibbs_cols_setup, dim3((ncols * h->Rk + 255) / 256), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
+        if (same_pre) {
+            hipLaunchKernelGGL(k_gibbs_pre_features, dim3((unsigned)((nrows + 255) / 256)), dim3(256), (size_t)h->B * h->Rk * 8,
+                               h->stream, gp, n_pre[0], (double*)h->gfs.p);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(rate_kernel, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), 0, h->stream, gp);

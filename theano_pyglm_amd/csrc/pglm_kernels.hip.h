@@ -3101,6 +3101,13 @@ struct GibbsColsParams {
     double* __restrict__ partS;          // spike-term partials
     int nloop;                           // sub-blocks of PGL_GRB bins per workgroup
     double* __restrict__ hs;             // [ncols][R] impulse response of every listed pair (k_gibbs_cols_setup)
+    // launches whose columns all share ONE presynaptic neuron (a sweep step of the collapsed sampler: pair j -> n for
+    // every n): its basis-filtered spike train fs[b][t - t_lo] = sum_events count * phi_b[t - s - 1] is built once per
+    // launch (k_gibbs_pre_features) and the pair current of a column is B multiply-adds per bin, ic = sum_b fs_b beta_b,
+    // instead of a loop over the events of the window per (column, sub-block); null = event loop
+    const double* __restrict__ fs;
+    long long fs_stride;
+    int hs_region;                       // doubles of the first LDS region: max(CP * R, B * (PGL_GRB + 2) + CP * 8)
     int dbg;                             // dev: 1 no event loop, 2 no phase B, 4 no event staging, 8 no GX loads, 16 no band passes,
                                          // 32 no exp, 64 no merge tree (results invalid when != 0)
 };
@@ -3336,13 +3343,46 @@ __device__ __forceinline__ double pgl_wave_sum_to_last(double v)
     return v;
 }
 
+// fs[b][t - t_lo] = sum over the events (s, count) of neuron n_pre of count * phi_b[t - s - 1]  (impulse.py:58: the
+// basis-filtered spike train of ONE presynaptic neuron, from its event list); one bin per thread
+__global__ __launch_bounds__(256) void k_gibbs_pre_features(const GibbsColsParams p, const int n_pre, double* __restrict__ fs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* phiS = reinterpret_cast<double*>(smem);                 // [B][R]
+    for (int i = threadIdx.x; i < p.B * p.R; i += 256) phiS[i] = p.phi[i];
+    __syncthreads();
+    const long long t = p.t_lo + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.t_hi) return;
+    const long long tile = t >> 4;
+    const int lo = p.wlo[(size_t)tile * p.N + n_pre], hi = p.whi[(size_t)tile * p.N + n_pre];
+    double acc[PGL_MAXB];
+#pragma unroll
+    for (int b = 0; b < PGL_MAXB; ++b) acc[b] = 0.0;
+    for (int q = lo; q < hi; ++q) {
+        const int2 ev = p.spk[q];
+        const int d = (int)t - ev.x - 1;
+        if ((unsigned)d < (unsigned)p.R) {
+            const double cnt = (double)ev.y;
+#pragma unroll
+            for (int b = 0; b < PGL_MAXB; ++b)
+                if (b < p.B) acc[b] = fma(cnt, phiS[b * p.R + d], acc[b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < PGL_MAXB; ++b)
+        if (b < p.B) fs[(size_t)b * p.fs_stride + (t - p.t_lo)] = acc[b];
+}
+
 __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = PGL_GRB, XS = RB + 2, NJ = RB / 32, NSEG = RB / 64;
     const int K = p.K, CP = p.CP, NSPLIT = p.nsplit, RPB = 256 / CP, R = p.R;
     double* HS = reinterpret_cast<double*>(smem);                   // [CP][R] impulse response of the pair
-    double* X0 = HS + CP * R;                                       // [CP][XS] bias + I_stim + I_net of the sub-block
+    const bool FSM = p.fs != nullptr;                               // one presynaptic neuron for all columns
+    double* FS = HS;                                                // FSM: [B][XS] filtered spike train of the sub-block ...
+    double* BT = HS + p.B * XS;                                     // ... and [CP][8] basis weights of the pairs
+    double* X0 = HS + p.hs_region;                                  // [CP][XS] bias + I_stim + I_net of the sub-block
     double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
     double* Qx = Wl + CP * PGL_KMAX;                                // [4][PGL_GQ]
     double* PS = Qx + 4 * PGL_GQ;                                   // [CP * NSPLIT][PGL_KMAX]
@@ -3353,10 +3393,18 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
     const int tid = threadIdx.x;
     const long long tw0 = p.t_lo + (long long)blockIdx.x * RB * p.nloop;
     // ---- once per workgroup: impulse responses, candidate weights, event windows of every sub-block ----
-    for (int i = tid; i < CP * R; i += 256) {
-        const int ci = i / R;
-        const int cc = blockIdx.y * CP + ci;
-        HS[i] = (cc < p.ncols) ? p.hs[(size_t)cc * R + (i - ci * R)] : 0.0;
+    if (FSM) {
+        for (int i = tid; i < CP * 8; i += 256) {
+            const int ci = i >> 3, b = i & 7;
+            const int cc = blockIdx.y * CP + ci;
+            BT[i] = (cc < p.ncols && b < p.B) ? p.theta[(size_t)p.cols[cc] * p.P + p.woff + p.pre[cc] * p.B + b] : 0.0;
+        }
+    } else {
+        for (int i = tid; i < CP * R; i += 256) {
+            const int ci = i / R;
+            const int cc = blockIdx.y * CP + ci;
+            HS[i] = (cc < p.ncols) ? p.hs[(size_t)cc * R + (i - ci * R)] : 0.0;
+        }
     }
     for (int i = tid; i < CP * PGL_KMAX; i += 256) {
         const int cc = blockIdx.y * CP + i / PGL_KMAX, k = i % PGL_KMAX;
@@ -3368,7 +3416,7 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
         const int cc = blockIdx.y * CP + ci;
         const long long tb0 = tw0 + (long long)sb * RB;
         int lo = 0, hi = 0;
-        if (cc < p.ncols && sb < p.nloop && tb0 < p.t_hi) {
+        if (cc < p.ncols && sb < p.nloop && tb0 < p.t_hi && !FSM) {
             long long tb1 = tb0 + RB;
             if (tb1 > p.t_hi) tb1 = p.t_hi;
             const int npc = p.pre[cc];
@@ -3412,7 +3460,18 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
         double icr[NSEG];
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) icr[sg] = 0.0;
-        {
+        if (FSM) {
+            if (!(p.dbg & 1)) {
+                for (int b = 0; b < p.B; ++b) {
+                    const double bt = BT[c * 8 + b];                // wave-uniform
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        const int tt = tseg + 64 * sg;              // (segments beyond the item's share are zeroed below)
+                        icr[sg] = fma(FS[b * XS + (tt < RB ? tt : 0)], bt, icr[sg]);
+                    }
+                }
+            }
+        } else {
             const int lo = WL[c * PGL_GNL + sb], cnt = WH[c * PGL_GNL + sb] - lo;
             const bool staged = cnt <= PGL_GECAP;
             const double* hs = HS + c * R;
@@ -3534,10 +3593,17 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
         //      X0 = bias + I_stim + I_net of its bins, [column][bin] ----
         // (requesting the next sub-block's currents into registers before the evaluation and storing them behind it
         //  was measured at 1.63 ms against 1.40: the other two workgroups of the CU already cover this latency)
-        for (int i = tid; i < CP * PGL_GECAP; i += 256) {
-            const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
-            const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
-            if (cnt <= PGL_GECAP && j < cnt && !(p.dbg & 4)) evS[i] = p.spk[lo + j];
+        if (FSM) {
+            for (int i = tid; i < p.B * RB; i += 256) {
+                const int b = i / RB, tt = i - b * RB;
+                FS[b * XS + tt] = (tt < nb && !(p.dbg & 4)) ? p.fs[(size_t)b * p.fs_stride + (tb0 - p.t_lo) + tt] : 0.0;
+            }
+        } else {
+            for (int i = tid; i < CP * PGL_GECAP; i += 256) {
+                const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
+                const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
+                if (cnt <= PGL_GECAP && j < cnt && !(p.dbg & 4)) evS[i] = p.spk[lo + j];
+            }
         }
         if (ra < RPB) {
 #pragma unroll

@@ -34,5 +34,21 @@ for opt in (1, 0, 1, 0):
     ms = (time.perf_counter() - t0) / 20 * 1e3
     res[opt] = ll
     print("PGL_OPT_GIBBS_KERNEL=%d: %.3f ms per launch of %d pairs x %d weights, finite %.3f" % (opt, ms, N, ws.shape[1], np.isfinite(ll).mean()))
+pre1 = np.full(N, 11)
+aw1 = (A * W)[pre1, cols]
+for _ in range(3):
+    ll = dev.gibbs_ll_cols(cols, pre1, aw1, ws)
+t0 = time.perf_counter()
+for _ in range(20):
+    ll = dev.gibbs_ll_cols(cols, pre1, aw1, ws)
+print("one presynaptic neuron for all columns (a sweep step): %.3f ms per launch" % ((time.perf_counter() - t0) / 20 * 1e3))
+dev.set_option(99, 0x1000)
+for _ in range(3):
+    ll2 = dev.gibbs_ll_cols(cols, pre1, aw1, ws)
+t0 = time.perf_counter()
+for _ in range(20):
+    ll2 = dev.gibbs_ll_cols(cols, pre1, aw1, ws)
+print("   the same launch through the event loop: %.3f ms; max rel diff %.2e" % ((time.perf_counter() - t0) / 20 * 1e3, np.nanmax(np.abs(ll - ll2) / np.abs(ll2))))
+dev.set_option(99, 0)
 fin = np.isfinite(res[0]) & np.isfinite(res[1])
 print("max rel diff regime-split vs all-f64: %.2e" % np.max(np.abs(res[0][fin] - res[1][fin]) / np.abs(res[1][fin])))
