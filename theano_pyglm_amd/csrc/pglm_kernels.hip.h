@@ -2369,6 +2369,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : (p.nlin == 1 ? 30.0 : 0.0);
     const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS * 64;
 
+    // forward k-steps that hold feature columns: the row is padded to whole 16-column tiles (the backward MFMA's M), the
+    // forward k-step is 4 columns wide -- up to three all-zero steps at the end of the row are skipped (195 columns at C5:
+    // 49 of 52)
+    const int ksf = (p.Ktot + 3) >> 2;
     const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
     if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
@@ -2454,10 +2458,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 for (int s = 0; s < KS; ++s) {
                     const double a = ar[s % PA];
                     if (s + PA < KS) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
-                    if (s & 1)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
-                    else
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
+                    if (s < KS - 3 || s < ksf) {
+                        if (s & 1)
+                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
+                        else
+                            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc0, 0, 0, 0);
+                    }
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                     if (DSF > 0) {
                         constexpr int DSS = (DSF > 0) ? DSF : 1;
@@ -2481,10 +2487,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                     const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
                     if (s + PA < KS) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
                     if ((s & 1) && (s / 2 + PW2 < KS / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
-                    if (s & 1)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
-                    else
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    if (s < KS - 3 || s < ksf) {
+                        if (s & 1)
+                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                        else
+                            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    }
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
