@@ -22,6 +22,25 @@ def _free_port():
     return p
 
 
+def _collect(procs, q, n, timeout=600):
+    """n results from the workers' queue; fails as soon as a worker has died without delivering (a plain
+    q.get(timeout) would sit out the whole timeout on the GPU box)."""
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < n:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [pr.exitcode for pr in procs if pr.exitcode not in (None, 0)]
+            assert not dead, "worker exited with %s before delivering its result" % dead
+            assert time.time() - t0 < timeout, "workers timed out"
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    return res
+
+
 def _pack_state(popn, x):
     from theano_pyglm_amd.utils.packvec import packdict, get_vars
     syms = popn.glm_syms()
@@ -83,10 +102,7 @@ def test_world2_sharded_map_and_gibbs_on_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, clean if r == 0 else None, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for pr in procs:
-        pr.join(timeout=120)
-        assert pr.exitcode == 0
+    res = _collect(procs, q, len(procs))
     res.sort(key=lambda r: r[0])
     # single-process reference on the same data and the same x0
     x0 = popn.sample(np.random.RandomState(11))
@@ -111,3 +127,72 @@ def test_world2_sharded_map_and_gibbs_on_one_gpu():
         assert np.array_equal(a, b)
     A = res[0][5][1]
     assert set(np.unique(A)) <= {0.0, 1.0}
+
+
+def _worker_rccl(port, data0, out):
+    """One rank, backend nccl (= RCCL), collectives forced on the one-rank group: every device-tensor collective
+    of the product path executes on the GPU box."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['PYGLM_COLLECTIVES_AT_WORLD1'] = '1'
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from theano_pyglm_amd import parallel as PL
+    from theano_pyglm_amd.inference.coord_descent import coord_descent
+    from theano_pyglm_amd.inference.parallel_coord_descent import parallel_coord_descent, parallel_compute_log_p
+    from theano_pyglm_amd.inference.parallel_gibbs import parallel_gibbs_sample
+    from theano_pyglm_amd.models.model_factory import make_model, stabilize_sparsity
+    from theano_pyglm_amd.population import Population
+    assert not PL.alone() and dist.get_backend() == 'nccl'
+    # raw collectives on device tensors (float64 payloads, the padded all-gather, the uint8 spike broadcast)
+    t = torch.arange(12, dtype=torch.float64, device='cuda:0').reshape(4, 3)
+    assert torch.equal(PL.allgather_rows_t(t.clone(), 4), t)
+    assert torch.equal(PL.allreduce_sum_t(t.clone()), t)
+    assert np.array_equal(PL.allgather_cols(np.arange(9.0).reshape(3, 3), 3, 'cuda:0'), np.arange(9.0).reshape(3, 3))
+    data = PL.broadcast_data(data0, src=0, device='cuda:0')
+    assert np.array_equal(data['S'], np.asarray(data0['S']).astype(np.uint8)) and data['N'] == data0['N']
+    N = data['N']
+    popn = Population(make_model('standard_glm', N=N, dt=0.001), device=0)
+    popn.add_data(data)
+    x0 = popn.sample(np.random.RandomState(11))
+    lp_n, _ = parallel_compute_log_p(popn, x0)                                   # all-gather of the per-neuron terms
+    xn = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch', shard='neurons')
+    xt = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch', shard='time')  # all-reduce per evaluation
+    m2 = make_model('sparse_weighted_model', N=N, dt=0.001)
+    stabilize_sparsity(m2)
+    pop2 = Population(m2, device=0)
+    pop2.add_data(data)
+    y0 = pop2.sample(np.random.RandomState(12))
+    y0['net']['weights']['W'] = 0.2 * np.asarray(y0['net']['weights']['W'])
+    y = parallel_gibbs_sample(pop2, N_samples=1, x0=copy.deepcopy(y0), seed=5, verbose=False)[-1]
+    lpy = pop2.compute_log_p(y)
+    # the same work without collectives
+    os.environ['PYGLM_COLLECTIVES_AT_WORLD1'] = '0'
+    assert PL.alone()
+    lp_ref = popn.compute_log_p(x0)
+    x_ref = coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch')
+    out.put((lp_n, lp_ref, _pack_state(popn, xn)[0], _pack_state(popn, xt)[0], _pack_state(popn, x_ref)[0],
+             popn.compute_log_p(xt), popn.compute_log_p(x_ref), lpy))
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_on_a_one_rank_group():
+    """The nccl (= RCCL) branches of theano_pyglm_amd.parallel and of the sharded MAP / Gibbs drivers -- device
+    all_reduce, all_gather_into_tensor, broadcast -- run on the GPU box, on a one-rank group (the box has one GPU),
+    and leave the single-process numbers unchanged."""
+    import torch.multiprocessing as mp
+    from theano_pyglm_amd.harness.generate_synth_data import make_dataset
+    N = 6
+    model, popn, data = make_dataset('standard_glm', N, 8.0, seed=21)
+    clean = dict((k, v) for k, v in data.items() if not k.startswith('_') and k not in ('fstim', 'preprocessed'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_worker_rccl, args=(_free_port(), clean, q))
+    pr.start()
+    lp_n, lp_ref, rows_n, rows_t, rows_ref, lpt, lpr, lpy = _collect([pr], q, 1)[0]
+    assert np.isclose(lp_n, lp_ref, rtol=1e-12)
+    assert np.allclose(rows_n, rows_ref, rtol=1e-9, atol=1e-12)
+    assert np.allclose(rows_t, rows_ref, rtol=1e-9, atol=1e-12)
+    assert np.isclose(lpt, lpr, rtol=1e-10) and np.isfinite(lpy)

@@ -33,8 +33,7 @@ from theano_pyglm_amd.utils.packvec import packdict, unpackdict, get_vars, set_v
 
 
 def _device_of(population):
-    world, _ = PL.world_rank()
-    if world == 1:
+    if PL.alone():
         return None
     import torch.distributed as dist
     return None if dist.get_backend() == 'gloo' else 'cuda:%d' % population.device
@@ -46,8 +45,8 @@ def parallel_compute_log_p(population, x, shard='neurons'):
     shard='time' every rank evaluates all neurons on its bins and the ll vector is all-reduced."""
     N = population.N
     world, rank = PL.world_rank()
-    if shard == 'time' and world > 1:
-        if population._time_shard != (rank, world):
+    if shard == 'time' and not PL.alone():
+        if world > 1 and population._time_shard != (rank, world):
             raise RuntimeError("parallel_compute_log_p(shard='time') needs Population.set_time_shard(rank, world) to be "
                                "active: without it every rank evaluates the whole recording and the all-reduce returns "
                                "world_size times the log likelihood")
@@ -161,7 +160,7 @@ def parallel_coord_descent(population, x0=None, maxiter=50, atol=1e-5, batched=N
     N = population.N
     world, rank = PL.world_rank()
     batched = cd.resolve_batched(population, batched)
-    if world == 1:
+    if PL.alone():
         return cd.coord_descent(population, x0=x0, maxiter=maxiter, atol=atol, batched=batched, verbose=verbose)
     if shard is None:
         shard = 'time' if (batched == 'torch' and N // world < NARROW_SHARD) else 'neurons'

@@ -40,6 +40,17 @@ def world_rank():
     return 1, 0
 
 
+def alone():
+    """True when there is nothing to exchange: one rank (or no process group).  PYGLM_COLLECTIVES_AT_WORLD1=1 runs
+    the collectives on a one-rank group all the same -- how tests/test_gpu_parallel.py executes the RCCL branches
+    (device-tensor all_reduce / all_gather_into_tensor / broadcast) on a one-GPU box."""
+    import os
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get('PYGLM_COLLECTIVES_AT_WORLD1') != '1'
+
+
 def _collective_tensor(t):
     """The tensor a collective of the current backend can take: nccl needs device tensors and gets
     them as they are; gloo gets host tensors."""
@@ -55,7 +66,7 @@ def allgather_rows_t(local, N):
     import torch
     dist = _dist()
     world, rank = world_rank()
-    if world == 1:
+    if alone():
         return local
     bounds = all_shard_bounds(N, world)
     width = max(hi - lo for lo, hi in bounds)
@@ -76,7 +87,7 @@ def allgather_rows(local, N, device=None):
     """numpy front end of allgather_rows_t (float64)."""
     import torch
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if world_rank()[0] == 1:
+    if alone():
         return local
     t = torch.from_numpy(local)
     if device is not None:
@@ -109,7 +120,7 @@ def time_shard_bounds(nT, rank, world, align=16):
 def allreduce_sum_t(t):
     """In-place sum over all ranks of a tensor, on its device."""
     dist = _dist()
-    if world_rank()[0] == 1:
+    if alone():
         return t
     c = _collective_tensor(t)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -122,7 +133,7 @@ def allreduce_sum(local, device=None):
     """numpy front end of allreduce_sum_t (float64)."""
     import torch
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if world_rank()[0] == 1:
+    if alone():
         return local
     t = torch.from_numpy(local.copy())
     if device is not None:
@@ -139,7 +150,7 @@ def broadcast_data(data, src=0, device=None):
     import torch
     dist = _dist()
     world, rank = world_rank()
-    if world == 1:
+    if alone():
         return data
     meta = [None]
     if rank == src:
