@@ -288,18 +288,22 @@ def main():
     ap.add_argument('--shard', choices=['time', 'neurons'], default='time')
     # dev-only: exercise the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo collectives)
     ap.add_argument('--debug-single-device', action='store_true')
+    ap.add_argument('--rccl-selftest', action='store_true',
+                    help='dev: run the multi-rank code path (process group on nccl = RCCL, barrier, all-reduce of the packed '
+                         '(ll, grad) block per step, per-rank gather) on ONE rank -- what a one-GPU box can execute of it')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    multi = world > 1 or args.rccl_selftest       # the code path with a process group and collectives
     # Build (if stale) BEFORE torch or anything else touches the GPU: a compiler child must never be
     # spawned from a process that has initialised HIP, least of all under rocprofv3 (build_hip raises
     # when the library is stale under a profiler and scrubs the preload variables otherwise).
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_hip()
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             ge.build_oracle()
 
     import torch
@@ -317,12 +321,16 @@ def main():
     if args.debug_single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo' if args.debug_single_device else 'nccl', rank=rank,
-                                world_size=world)
+        os.environ.setdefault('MASTER_PORT', '29541')
+        if args.debug_single_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            # device_id binds the communicator to this rank's GPU up front (no guessing from the global rank, eager init)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    if world > 1:
+    if multi:
         dist.barrier()                       # rank 0 has finished building
     from theano_pyglm_amd import _lib
 
@@ -344,7 +352,7 @@ def main():
     dev.set_basis(ib)
     if args.f32_features:
         dev.set_option(_lib.OPT_FEATURE_F32, 1)
-    if args.shard == 'time' or world == 1:
+    if args.shard == 'time' or not multi:
         n_lo, n_hi = 0, N
         t_lo, t_hi = PL.time_shard_bounds(nT, rank, world)
         dev.set_time_range(t_lo, t_hi)
@@ -364,7 +372,7 @@ def main():
     d_out = torch.zeros(npost * (1 + P), dtype=torch.float64, device='cuda')
     d_ll = d_out[:npost]
     d_grad = d_out[npost:].view(npost, P)
-    if world > 1 and args.shard == 'neurons':
+    if multi and args.shard == 'neurons':
         sizes = [b - a for a, b in PL.all_shard_bounds(N, world)]
         gather = [torch.zeros(s, dtype=torch.float64, device='cuda') for s in sizes]
     torch.cuda.synchronize()
@@ -381,10 +389,10 @@ def main():
     def step(record):
         dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr(),
                         n_lo, n_hi)
-        if world > 1 and record and not args.debug_single_device:
+        if multi and record and not args.debug_single_device:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(bench_stream)
-        if world > 1:
+        if multi:
             if args.debug_single_device:         # gloo: collectives on host copies
                 dev.sync()
                 if args.shard == 'time':
@@ -411,7 +419,7 @@ def main():
     dev.set_option(_lib.OPT_TIMING, TIMING_EVERY)
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dev.set_option(_lib.OPT_TIMING, TIMING_EVERY)    # (restarts the sampling phase: evaluation 0, 4, 8, ... of the region)
@@ -419,12 +427,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     local_elapsed = elapsed
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device='cpu' if args.debug_single_device else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -434,7 +442,7 @@ def main():
     n_timed, kern_ms, call_ms = dev.timing_summary(reset=True)
     dev.set_option(_lib.OPT_TIMING, 1)               # the short A/B loops below time every evaluation
     per_rank = None
-    if world > 1:
+    if multi:
         # what every rank paid per step: its own wall clock, its fused kernels, its whole evaluation (prep + fused +
         # finalize) and the collective (HIP events on the stream; includes waiting for the slowest rank)
         coll_ms = float(np.mean([a.elapsed_time(b) for a, b in coll_events])) if coll_events else None
@@ -443,7 +451,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     alt = None
-    if world == 1 and not args.f32_features and info['kernel_version'] == 5 and not args.no_ab:
+    if not multi and not args.f32_features and info['kernel_version'] == 5 and not args.no_ab:
         # the same evaluation with the features regenerated from the spike events inside the kernel
         # (the north star's fused filter kernel, PGL_OPT_KERNEL=3) -- reported beside the headline
         dev.set_option(_lib.OPT_KERNEL, 3)
@@ -460,7 +468,7 @@ def main():
                "frac": info['flops'] / (alt_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
         dev.set_option(_lib.OPT_KERNEL, 0)
     allf64 = None
-    if world == 1 and not args.f32_features and not args.no_ab:
+    if not multi and not args.f32_features and not args.no_ab:
         # the same evaluation with the all-f64 rate epilogue (PGL_OPT_EPI_F64: no single-precision exp(-x)
         # correction), so that the effect of that term is visible beside every headline number
         dev.set_option(_lib.OPT_EPI_F64, 1)
@@ -485,7 +493,7 @@ def main():
     achieved = info['flops'] / (kern_ms * 1e-3) / 1e12
     ll_host = d_ll.cpu().numpy()
     assert np.all(np.isfinite(ll_host)), "non-finite ll"
-    if world > 1:
+    if multi:
         # the sharded evaluation must equal the single-rank evaluation of the whole recording
         if args.shard == 'time':
             ll_pop = ll_host                                   # all-reduced: full ll of all N neurons
@@ -517,7 +525,7 @@ def main():
                             % (N, args.seconds, nT, B, R),
                 "sharding": ("time bins split over %d rank(s), all neurons per rank, S replicated, "
                              "all-reduce of the packed (ll, grad) block per step" % world)
-                if (args.shard == 'time' or world == 1) else
+                if (args.shard == 'time' or not multi) else
                             ("post-synaptic neurons block-partitioned over %d rank(s); S replicated; "
                              "all-gather of ll per step" % world),
                 "feature_staging": "f32" if args.f32_features else "f64",
@@ -554,7 +562,7 @@ def main():
             out["roofline"]["all_f64_epilogue"] = allf64
         if per_rank is not None:
             out["per_rank"] = per_rank
-        if world == 1 and N == 128 and nT == 600000 and not args.f32_features:
+        if not multi and N == 128 and nT == 600000 and not args.f32_features:
             tr = pmc_traffic(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
@@ -562,15 +570,22 @@ def main():
             mb = pmc_mfma_busy(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if mb is not None:
                 out["roofline"]["mfma_busy_pmc"] = mb
-        if world == 1 and not args.no_map and not args.f32_features:
+        if not multi and not args.no_map and not args.f32_features:
             out["secondary"] = map_wall_clock(S, N, dt)
-        if world == 1 and not args.no_mcmc and not args.f32_features:
+        if not multi and not args.no_mcmc and not args.f32_features:
             out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
-        print(json.dumps(out))
+        # RCCL prints a banner through C stdio: flush it first so that the JSON line is the last line of stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     dev.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

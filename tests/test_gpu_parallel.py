@@ -138,7 +138,7 @@ def _worker_rccl(port, data0, out):
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     from theano_pyglm_amd import parallel as PL
     from theano_pyglm_amd.inference.coord_descent import coord_descent
     from theano_pyglm_amd.inference.parallel_coord_descent import parallel_coord_descent, parallel_compute_log_p
@@ -196,3 +196,23 @@ def test_rccl_collectives_execute_on_a_one_rank_group():
     assert np.allclose(rows_n, rows_ref, rtol=1e-9, atol=1e-12)
     assert np.allclose(rows_t, rows_ref, rtol=1e-9, atol=1e-12)
     assert np.isclose(lpt, lpr, rtol=1e-10) and np.isfinite(lpy)
+
+
+def test_bench_multi_rank_path_on_rccl_one_rank():
+    """bench.py's N > 1 code path (process group on nccl bound to the rank's GPU, barrier, all-reduce of the packed
+    (ll, grad) block resp. all-gather of the ll shards on the bench stream, MAX over ranks, per-rank gather) executes
+    on RCCL with one rank; the JSON record is the last line of stdout and carries the per-rank block."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for shard in ('time', 'neurons'):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, 'bench.py', '--rccl-selftest', '--shard', shard, '--steps', '4', '--warmup', '1',
+                            '--seconds', '60', '--neurons', '64'], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=400)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec['n_gpus'] == 1 and rec['steps'] == 4 and rec['value'] > 0
+        assert rec['per_rank'] and rec['per_rank'][0]['collective_ms'] is not None
+        assert 'roofline' in rec
