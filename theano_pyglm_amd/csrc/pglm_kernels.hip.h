@@ -3288,6 +3288,14 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 #define PGL_GQ PGL_GRB
 #endif
 //                               band-queue entries per wave (the band elements of one weight: <= PGL_GRB)
+// Occupancy of k_gibbs_rate_cols (tools/ubench/occ_gibbs_ubench.hip, hipOccupancyMaxActiveBlocksPerMultiprocessor): four
+// workgroups per CU up to 40 KB of LDS and 128 VGPRs, three up to 53 KB -- and three are 15-20 % slower.  The kernel sits
+// at 40.9 KB / ~115 VGPRs on purpose.  Measured round 3 and dropped because they cross that step or pay more than they
+// save: 384-bin sub-blocks (six segments per weight: better filled f64 passes, 46-54 KB) 1.55 ms against 1.40; per-lane
+// accumulators for all weights in registers through the VGPR index register (164 VGPRs) 1.53 ms; a band queue whose
+// leftovers travel on to the next weights (ring of 320 / 512 entries, three lane-partial vectors in flight, a lane adds
+// its result to the weight that owns its queue position: f64 passes at full lanes) 1.44 / 1.71 ms against 1.30 -- the
+// bookkeeping around every pass costs more than the half-empty passes it removes.
 
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
 __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
