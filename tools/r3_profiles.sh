@@ -27,6 +27,11 @@ echo "== Gibbs"
 bash tools/prof_gibbs.sh > $R/prof_gibbs.log 2>&1; cp gpurun_out/prof_gibbs/stats.csv $R/r03_gibbs_kernel_stats.csv; cp gpurun_out/prof_gibbs/pmc.json $R/r03_gibbs_pmc.json; head -5 $R/r03_gibbs_kernel_stats.csv
 python3 tools/gibbs_kernel_only.py 2>&1 | tail -5 | tee $R/r03_gibbs_launch.txt
 python3 tools/gibbs_x_hist.py 2>&1 | tail -11 > $R/r03_gibbs_x_hist.txt
+python3 tools/gibbs_ablate.py 2>&1 | grep "^dbg" | tee $R/r03_gibbs_ablation.txt
+python3 tools/gibbs_sweep_profile.py 2>&1 | tail -7 | tee $R/r03_gibbs_sweep.txt
+./tools/ubench/occ_gibbs_ubench 2>&1 | grep "workgroups\|shared" | tee $R/r03_gibbs_occupancy.txt
+echo "== VALU issue costs (tools/ubench/valu_rates_ubench.hip)"
+./tools/ubench/valu_rates_ubench 2>&1 | grep "waves/WG 16" | tee $R/r03_valu_issue_costs.txt
 echo "== MAP"
 python3 tools/map_bench.py 128 600 default 2>&1 | tail -4 | tee $R/r03_map.txt
 python3 tools/map_bench.py 32 300 default 2>&1 | tail -4 | tee -a $R/r03_map.txt
@@ -44,5 +49,9 @@ echo "== two ranks on one GPU (gloo): both shardings of bench.py"
 for sh in time neurons; do
   python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 --shard $sh --debug-single-device --no-cpu-baseline --no-map --no-mcmc 2>/dev/null | grep '"metric"' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$sh', d['value'], d['ms_per_step'], json.dumps(d.get('per_rank')))"
 done | tee $R/r03_two_rank_single_gpu.txt
+echo "== bench.py multi-rank path on RCCL, one rank"
+for sh in time neurons; do python3 bench.py --rccl-selftest --shard $sh --steps 20 --warmup 3 2>/dev/null | tail -1; done | tee $R/r03_rccl_selftest.jsonl | cut -c1-300
+echo "== GPU test suite"
+python3 -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $R/r03_gpu_tests.txt
 rm -rf gpurun_out/pmc_C2 gpurun_out/pmc_C5 gpurun_out/prof_gibbs
 ls $R

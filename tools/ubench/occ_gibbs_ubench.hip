@@ -2,7 +2,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cmath>
-#include "/root/repo/theano_pyglm_amd/csrc/pglm_kernels.hip.h"
+#include "../../theano_pyglm_amd/csrc/pglm_kernels.hip.h"
 int main()
 {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
