@@ -180,6 +180,14 @@ def mcmc_inner_ll(S, N, dt):
     for _ in range(reps):
         ll = h.gibbs_ll_cols(cols, pre, aw, ws)
     per_launch = (time.perf_counter() - t0) / reps
+    # the launch shape of a sweep step: the pair (j -> n) of every n -- one presynaptic neuron for all columns
+    pre1 = np.full(N, 11)
+    aw1 = (A * W)[pre1, cols]
+    h.gibbs_ll_cols(cols, pre1, aw1, ws)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        h.gibbs_ll_cols(cols, pre1, aw1, ws)
+    per_launch_step = (time.perf_counter() - t0) / reps
     sweeps = []
     for _ in range(2):
         upd.n_ars_evals = 0
@@ -189,10 +197,14 @@ def mcmc_inner_ll(S, N, dt):
     popn.release_data()
     return {"metric": "MCMC inner-ll batches/s (11 ll values per (n_pre, n_post) pair, sparse_weighted_model)",
             "value": N / per_launch, "unit": "batches/s", "pairs_per_launch": N, "ms_per_launch": per_launch * 1e3,
+            "sweep_step": {"ms_per_launch": per_launch_step * 1e3, "batches_per_s": N / per_launch_step,
+                           "note": "all columns share the presynaptic neuron (what update_all launches): pair currents "
+                                   "from its filtered spike train instead of the event windows"},
             "finite_fraction": float(np.isfinite(ll).mean()),
             "sweep_s": sweeps[1], "first_sweep_s": sweeps[0], "pairs_per_sweep": N * N,
             "ars_launches_last_sweep": upd.n_ars_evals,
-            "kernels": "k_gibbs_rate_cols (f32 log1p term where |x| >= 12, compacted f64 band) + k_gibbs_spike_cols"}
+            "kernels": "k_gibbs_rate_cols (max(x,0) in f64 + log1p(exp(-|x|)) in f32 where |x| >= 12, compacted f64 band) + "
+                       "k_gibbs_spike_cols"}
 
 
 def usable_cores():
