@@ -21,6 +21,8 @@ for trial in range(60):
     for _ in range(3):
         K = int(rng.randint(1, 17)); nc = int(rng.randint(1, 2 * N + 2))
         cols = rng.randint(0, N, size=nc); pre = rng.randint(0, N, size=nc)
+        if rng.rand() < 0.4:
+            pre[:] = pre[0]          # a sweep step: one presynaptic neuron for all columns (filtered-spike-train path)
         ws = rng.standard_normal((nc, K)) * rng.choice([0.1, 1.0, 30.0, 1e3])
         aw = p.Weff[pre, cols]
         d.set_option(_lib.OPT_GIBBS_KERNEL, 1); old = d.gibbs_ll_cols(cols, pre, aw, ws)
