@@ -117,6 +117,18 @@ def _worker_bcast(rank, world, port, out):
     t = torch.full((3,), float(rank + 1), dtype=torch.float64)
     PL.allreduce_sum_t(t)
     rows = PL.allgather_rows_t(torch.arange(lo, hi, dtype=torch.float64)[:, None] * torch.ones(1, 2, dtype=torch.float64), 5)
+    # PYGLM_CHECK_RANKS: equal payloads pass, diverged payloads raise on every rank instead of hanging
+    os.environ['PYGLM_CHECK_RANKS'] = '1'
+    t2 = torch.full((4,), 1.0, dtype=torch.float64)
+    PL.allreduce_sum_t(t2)
+    assert np.array_equal(t2.numpy(), np.full(4, float(world)))
+    try:
+        PL.allreduce_sum_t(torch.zeros(3 + rank, dtype=torch.float64))
+        diverged = False
+    except RuntimeError as e:
+        diverged = 'diverged' in str(e)
+    assert diverged
+    os.environ['PYGLM_CHECK_RANKS'] = '0'
     out.put((rank, got, full, t.numpy(), rows.numpy()))
     dist.destroy_process_group()
 

@@ -118,10 +118,21 @@ def time_shard_bounds(nT, rank, world, align=16):
 
 
 def allreduce_sum_t(t):
-    """In-place sum over all ranks of a tensor, on its device."""
+    """In-place sum over all ranks of a tensor, on its device.  With PYGLM_CHECK_RANKS=1 the element count is first
+    compared across ranks (one extra small all-reduce + host sync per call): a rank whose launch list has diverged
+    fails with a message instead of hanging the job in a size-mismatched collective."""
+    import os
     dist = _dist()
     if alone():
         return t
+    if os.environ.get('PYGLM_CHECK_RANKS') == '1':
+        import torch
+        n = torch.tensor([t.numel(), -t.numel()], dtype=torch.int64, device=_collective_tensor(t).device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        hi, lo = int(n[0]), -int(n[1])
+        if hi != lo:
+            raise RuntimeError("all-reduce payloads differ across ranks: %d .. %d elements (rank %d has %d) -- the "
+                               "lock-step launch lists have diverged" % (lo, hi, dist.get_rank(), t.numel()))
     c = _collective_tensor(t)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     if c is not t:
