@@ -1,5 +1,5 @@
 """Experimental build: compile pglm_capi.hip with -save-temps, rewrite the device assembly (VOP2 v_cndmask_b32 ->
-VOP3 encoding: tools/ubench/valu_rates.hip measures the e32 form at 16-20 cycles per instruction and SIMD when
+VOP3 encoding: tools/ubench/valu_rates_ubench.hip measures the e32 form at 16-20 cycles per instruction and SIMD when
 several SIMDs issue it, 4.35 for e64), reassemble and relink.  Usage: asm_patch_build.py <out.so> [extra hipcc flags]"""
 import os, re, shlex, subprocess, sys
 out = os.path.abspath(sys.argv[1]); extra = sys.argv[2:]
