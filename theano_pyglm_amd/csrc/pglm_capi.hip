@@ -1932,7 +1932,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
             gp.hs_region = std::max(gp.hs_region, h->B * (PGL_GRB + 2) + gp.CP * 8);
         }
         const size_t lds = ((size_t)gp.hs_region + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
-                            (size_t)4 * PGL_GQ + (size_t)gp.CP * gp.nsplit * PGL_KMAX + (size_t)gp.CP) * 8 +
+                            (size_t)4 * PGL_GQ + (size_t)128 + (size_t)gp.CP) * 8 +     // (band queue, log1p table, max |w|)
                            (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
         auto rate_kernel = k_gibbs_rate_cols;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rate_kernel),

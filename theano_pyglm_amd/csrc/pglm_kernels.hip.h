@@ -3297,6 +3297,55 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 // its result to the weight that owns its queue position: f64 passes at full lanes) 1.44 / 1.71 ms against 1.30 -- the
 // bookkeeping around every pass costs more than the half-empty passes it removes.
 
+// log1p(t) for t = exp(-a) in (0, 1] through a 32-interval table (1 KB, copied to LDS): t0 = (2j + 1) / 64,
+// {r0 = 1 / (1 + t0), c0 = -t0 r0, L0 = log1p(t0)} rounded from 80-bit values; u = t r0 + c0 = (t - t0) / (1 + t0),
+// |u| <= 1/64, log1p(t) = L0 + log1p(u) with eight series terms (u^9 / 9 < 7e-18).  One LDS gather and ten
+// multiply-adds instead of frexp + division + 7-term polynomial: absolute error < 2e-16 (1.3e-12 relative at the
+// small end, t ~ 6e-6), tools/ubench/proto_math.py.  Only for elements known to lie in the band (a < 12).
+__constant__ double PGL_L1PT[32][4] = {
+    {0x1.f81f81f81f820p-1, -0x1.f81f81f81f820p-7, 0x1.fc0a8b0fc03e4p-7, 0.0},
+    {0x1.e9131abf0b767p-1, -0x1.6ece540f4898dp-5, 0x1.77458f632dcfcp-5, 0.0},
+    {0x1.dae6076b981dbp-1, -0x1.28cfc4a33f129p-4, 0x1.341d7961bd1d1p-4, 0.0},
+    {0x1.cd85689039b0bp-1, -0x1.93d4bb7e327a9p-4, 0x1.a926d3a4ad563p-4, 0.0},
+    {0x1.c0e070381c0e0p-1, -0x1.f8fc7e3f1f8fcp-4, 0x1.0d77e7cd08e59p-3, 0.0},
+    {0x1.b4e81b4e81b4fp-1, -0x1.2c5f92c5f92c6p-3, 0x1.44d2b6ccb7d1ep-3, 0.0},
+    {0x1.a98ef606a63bep-1, -0x1.59c427e56710ap-3, 0x1.7ab890210d909p-3, 0.0},
+    {0x1.9ec8e951033d9p-1, -0x1.84dc5abbf309cp-3, 0x1.af3c94e80bff3p-3, 0.0},
+    {0x1.948b0fcd6e9e0p-1, -0x1.add3c0ca4587ep-3, 0x1.e27076e2af2e6p-3, 0.0},
+    {0x1.8acb90f6bf3aap-1, -0x1.d4d1bc2503159p-3, 0x1.0a324e27390e3p-2, 0.0},
+    {0x1.8181818181818p-1, -0x1.f9f9f9f9f9fa0p-3, 0x1.22941fbcf7966p-2, 0.0},
+    {0x1.78a4c8178a4c8p-1, -0x1.0eb66fd0eb670p-2, 0x1.3a64c556945eap-2, 0.0},
+    {0x1.702e05c0b8170p-1, -0x1.1fa3f47e8fd20p-2, 0x1.51aad872df82dp-2, 0.0},
+    {0x1.6816816816817p-1, -0x1.2fd2fd2fd2fd3p-2, 0x1.686c81e9b14afp-2, 0.0},
+    {0x1.6058160581606p-1, -0x1.3f4fd3f4fd3f5p-2, 0x1.7eaf83b82afc3p-2, 0.0},
+    {0x1.58ed2308158edp-1, -0x1.4e25b9efd4e26p-2, 0x1.947941c2116fbp-2, 0.0},
+    {0x1.51d07eae2f815p-1, -0x1.5c5f02a3a0fd6p-2, 0x1.a9cec9a9a084ap-2, 0.0},
+    {0x1.4afd6a052bf5bp-1, -0x1.6a052bf5a814bp-2, 0x1.beb4d9da71b7cp-2, 0.0},
+    {0x1.446f86562d9fbp-1, -0x1.7720f353a4c0ap-2, 0x1.d32fe7e00ebd5p-2, 0.0},
+    {0x1.3e22cbce4a902p-1, -0x1.83ba68636adfbp-2, 0x1.e744261d68788p-2, 0.0},
+    {0x1.3813813813814p-1, -0x1.8fd8fd8fd8fd9p-2, 0x1.faf588f78f31fp-2, 0.0},
+    {0x1.323e34a2b10bfp-1, -0x1.9b8396ba9de81p-2, 0x1.0723e5c1cdf40p-1, 0.0},
+    {0x1.2c9fb4d812ca0p-1, -0x1.a6c0964fda6c1p-2, 0x1.109f39e2d4c97p-1, 0.0},
+    {0x1.27350b8812735p-1, -0x1.b195e8efdb196p-2, 0x1.19ee6b467c96fp-1, 0.0},
+    {0x1.21fb78121fb78p-1, -0x1.bc090fdbc0910p-2, 0x1.23130d7bebf43p-1, 0.0},
+    {0x1.1cf06ada2811dp-1, -0x1.c61f2a4bafdc6p-2, 0x1.2c0e9ed448e8cp-1, 0.0},
+    {0x1.1811811811812p-1, -0x1.cfdcfdcfdcfddp-2, 0x1.34e289d9ce1d3p-1, 0.0},
+    {0x1.135c81135c811p-1, -0x1.d946fdd946fdep-2, 0x1.3d9026a7156fbp-1, 0.0},
+    {0x1.0ecf56be69c90p-1, -0x1.e26152832c6e0p-2, 0x1.4618bc21c5ec2p-1, 0.0},
+    {0x1.0a6810a6810a7p-1, -0x1.eb2fdeb2fdeb3p-2, 0x1.4e7d811b75bb1p-1, 0.0},
+    {0x1.0624dd2f1a9fcp-1, -0x1.f3b645a1cac08p-2, 0x1.56bf9d5b3f399p-1, 0.0},
+    {0x1.0204081020408p-1, -0x1.fbf7efdfbf7f0p-2, 0x1.5ee02a9241675p-1, 0.0},
+};
+__device__ __forceinline__ double pgl_log1p_tab(const double t, const double* __restrict__ TB)
+{
+    const int j = min((int)((float)t * 32.0f), 31);
+    const double* te = TB + 4 * j;
+    const double u = fma(t, te[0], te[1]);
+    const double q = fma(u, fma(u, fma(u, fma(u, fma(u, fma(u, fma(u, -0.125, 1.0 / 7.0), -1.0 / 6.0), 0.2), -0.25),
+                                       1.0 / 3.0), -0.5), 1.0);
+    return fma(u, q, te[2]);
+}
+
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
 __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
 {
@@ -3389,7 +3438,8 @@ __global__ __launch_bounds__(256) void k_gibbs_pre_features(const GibbsColsParam
         if (b < p.B) fs[(size_t)b * p.fs_stride + (t - p.t_lo)] = acc[b];
 }
 
-__global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p)
+// (four waves per SIMD = four workgroups per CU is the operating point: the register allocator is held to 128 VGPRs)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gibbs_rate_cols(const GibbsColsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = PGL_GRB, XS = RB + 2, NJ = RB / 32, NSEG = RB / 64;
@@ -3401,8 +3451,9 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
     double* X0 = HS + p.hs_region;                                  // [CP][XS] bias + I_stim + I_net of the sub-block
     double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
     double* Qx = Wl + CP * PGL_KMAX;                                // [4][PGL_GQ]
-    double* PS = Qx + 4 * PGL_GQ;                                   // [CP * NSPLIT][PGL_KMAX]
-    double* WM = PS + CP * NSPLIT * PGL_KMAX;                       // [CP] largest |candidate weight| of the column
+    double* TB = Qx + 4 * PGL_GQ;                                   // [32][4] log1p table (pgl_log1p_tab)
+    double* PS = X0;                                                // [CP * NSPLIT][PGL_KMAX] block results: X0 is dead by then
+    double* WM = TB + 128;                                          // [CP] largest |candidate weight| of the column
     int2* evS = reinterpret_cast<int2*>(WM + CP);                   // [CP][PGL_GECAP]
     int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP); // [CP][PGL_GNL] first event of the sub-block's window
     int* WH = WL + CP * PGL_GNL;                                    // [CP][PGL_GNL] one past its last event
@@ -3426,7 +3477,7 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
         const int cc = blockIdx.y * CP + i / PGL_KMAX, k = i % PGL_KMAX;
         Wl[i] = (cc < p.ncols && k < K) ? p.w[(size_t)cc * K + k] : 0.0;
     }
-    for (int i = tid; i < CP * NSPLIT * PGL_KMAX; i += 256) PS[i] = 0.0;
+    if (tid < 128) TB[tid] = (&PGL_L1PT[0][0])[tid];
     for (int i = tid; i < CP * PGL_GNL; i += 256) {
         const int ci = i / PGL_GNL, sb = i % PGL_GNL;
         const int cc = blockIdx.y * CP + ci;
@@ -3585,10 +3636,16 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
                 for (int base = 0; base < qn; base += 64) {         // one call site: the f64 code exists once
                     const bool v = base + lane < qn;
                     const double xq = v ? Qxw[base + lane] : 20.0;
-                    const double lam = pgl_lambda_only(xq, 1, PGL_C);
-                    // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700
-                    // (incl. +inf): lam = x, nothing beyond the max term
-                    const double d = (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
+                    double d;
+                    if (!careful) {
+                        // band proper: |x| < 12 is known -- exp in f64, log1p through the table
+                        d = pgl_log1p_tab(pgl_exp(-fabs(xq), PGL_C), TB);
+                    } else {
+                        const double lam = pgl_lambda_only(xq, 1, PGL_C);
+                        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700
+                        // (incl. +inf): lam = x, nothing beyond the max term
+                        d = (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
+                    }
                     accq += v ? d : 0.0;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -3676,6 +3733,9 @@ __global__ __launch_bounds__(256) void k_gibbs_rate_cols(const GibbsColsParams p
 __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams p)
 {
     __shared__ double red[4][PGL_KMAX];
+    __shared__ double TB[128];                                      // log1p table (pgl_log1p_tab)
+    if (threadIdx.x < 128) TB[threadIdx.x] = (&PGL_L1PT[0][0])[threadIdx.x];
+    __syncthreads();
     const int tid = threadIdx.x, c = blockIdx.y, K = p.K;
     const int n = p.cols[c], np = p.pre[c];
     const int i = p.elo[c] + blockIdx.x * 256 + tid;
@@ -3701,7 +3761,15 @@ __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams 
         for (int k = 0; k < PGL_KMAX; ++k) {
             if (k < K) {
                 const double x = fma(p.w[(size_t)c * K + k], ic, x0);
-                acc[k] = sv * pgl_log(pgl_lambda_only(x, 1, PGL_C), PGL_C);
+                // softplus per lane without wave-uniform regimes (the lanes are unrelated bins): exp, then the table
+                // where |x| < 12 and three series terms beyond (e < 6.2e-6: e^4 / 4 is 6e-17 of it); lam = 0 for
+                // x < -745 gives log(0) = -inf as the reference expression does
+                const double a = fabs(x);
+                const double e = pgl_exp(-a, PGL_C);
+                const double ser = e * fma(-e, fma(-e, 1.0 / 3.0, 0.5), 1.0);
+                const double tab = pgl_log1p_tab(e, TB);
+                const double lam = fmax(x, 0.0) + ((a < 12.0) ? tab : ser);
+                acc[k] = sv * pgl_log((x != x) ? x : lam, PGL_C);
             }
         }
     }
