@@ -3750,10 +3750,15 @@ __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams 
         const double* hs = p.hs + (size_t)c * p.R;
         const int lo = p.wlo[(size_t)tile * p.N + np], hi = p.whi[(size_t)tile * p.N + np];
         double ic = 0.0;
-        for (int q = lo; q < hi; ++q) {
-            const int2 ev = p.spk[q];
-            const int d = t - ev.x - 1;
-            if ((unsigned)d < (unsigned)p.R) ic = fma((double)ev.y, hs[d], ic);
+        if (p.fs) {                                                  // shared presynaptic neuron: its filtered spike train
+            const double* bt = p.theta + (size_t)n * p.P + p.woff + np * p.B;
+            for (int b = 0; b < p.B; ++b) ic = fma(p.fs[(size_t)b * p.fs_stride + (t - p.t_lo)], bt[b], ic);
+        } else {
+            for (int q = lo; q < hi; ++q) {
+                const int2 ev = p.spk[q];
+                const int d = t - ev.x - 1;
+                if ((unsigned)d < (unsigned)p.R) ic = fma((double)ev.y, hs[d], ic);
+            }
         }
         const double x0 = (p.theta[(size_t)n * p.P] + p.GX[(long long)t * p.xs + n]) - p.aw[c] * ic;
         const double sv = (double)e.y;
@@ -3773,12 +3778,27 @@ __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams 
             }
         }
     }
+    // the 16 lane-partial vectors through the pairwise merge tree of k_gibbs_rate_cols (15 merges + a quad butterfly
+    // instead of 16 six-step shuffle reductions through the LDS crossbar): weight k ends in quad bitrev4(k)
     const int lane = tid & 63, wave = tid >> 6;
+    {
+        double m1[8], m2[4], m3[2];
 #pragma unroll
-    for (int k = 0; k < PGL_KMAX; ++k) {
-        double v = acc[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) red[wave][k] = v;
+        for (int i = 0; i < 8; ++i) m1[i] = pgl_merge32(acc[2 * i], acc[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m2[i] = pgl_merge16(m1[2 * i], m1[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) m3[i] = pgl_merge_dpp<0x140, 8>(m2[2 * i], m2[2 * i + 1], lane);
+        double r = pgl_merge_dpp<0x141, 4>(m3[0], m3[1], lane);
+        int lo = __builtin_amdgcn_update_dpp(0, __double2loint(r), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r), 0xB1, 0xf, 0xf, true);
+        r += __hiloint2double(hi, lo);
+        lo = __builtin_amdgcn_update_dpp(0, __double2loint(r), 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(0, __double2hiint(r), 0x4E, 0xf, 0xf, true);
+        r += __hiloint2double(hi, lo);
+        const int q = lane >> 2;
+        const int k = ((q >> 3) & 1) | (((q >> 2) & 1) << 1) | (((q >> 1) & 1) << 2) | ((q & 1) << 3);
+        if ((lane & 3) == 0) red[wave][k] = r;
     }
     __syncthreads();
     if (tid < K)
