@@ -499,9 +499,20 @@ __device__ __forceinline__ bool pgl_rate_fx(const double (&x)[NE], const unsigne
     bool small = true;
 #pragma unroll
     for (int i = 0; i < NE; ++i) small = small && (e[i] < cthr);
-    if (!__all(small)) return false;
-    // ---- series regime: log1p(e) and 1/(1+e) from their alternating series (error < e^6) ----
     double l1p[NE], inv[NE];
+    if (!__all(small)) {
+        // ---- general regime (some |x| < 9.25: low firing rates): log1p(e) and 1/(1+e) in full, from the e at hand;
+        // the spike terms stay compacted below -- the fully general pgl_rate_terms_n (a second exp, log and
+        // reciprocal of lam for every element of a wave that holds a spike) is left for lam == 0 / NaN only ----
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const double u = 1.0 + e[i];
+            inv[i] = pgl_rcp(u);
+            l1p[i] = pgl_log(u, C) + (e[i] - (u - 1.0)) * inv[i];
+        }
+        PGL_ROW;
+    } else {
+    // ---- series regime: log1p(e) and 1/(1+e) from their alternating series (error < e^6) ----
 #pragma unroll
     for (int i = 0; i < NE; ++i) l1p[i] = fma(-e[i], 0.2, 0.25);
 #pragma unroll
@@ -527,6 +538,7 @@ __device__ __forceinline__ bool pgl_rate_fx(const double (&x)[NE], const unsigne
 #pragma unroll
     for (int i = 0; i < NE; ++i) inv[i] = fma(-e[i], inv[i], 1.0);
     PGL_ROW;
+    }
 #pragma unroll
     for (int i = 0; i < NE; ++i) lam[i] = fmax(x[i], 0.0) + l1p[i];
 #pragma unroll

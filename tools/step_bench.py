@@ -12,7 +12,10 @@ N, T, ib, kind, Ds, ws = {'C1': (4, 60.0, H.std_ibasis(), 'explinear', 0, 0.5),
                           'C2': (32, 300.0, H.std_ibasis(), 'explinear', 0, 0.5),
                           'C3': (128, 600.0, H.std_ibasis(), 'explinear', 0, 0.5),
                           'C5': (64, 300.0, H.st_ibasis(), 'exp', 9, 0.02)}[cfg]
-p = H.Problem(N, int(round(T / 0.001)), ib, kind=kind, Dstim=Ds, seed=1234, w_scale=ws)
+import os
+BIAS = os.environ.get('BIAS')          # e.g. BIAS=5 RATE=5: a low-rate population (currents inside the |x| < 12 band)
+p = H.Problem(N, int(round(T / 0.001)), ib, kind=kind, Dstim=Ds, seed=1234, w_scale=ws,
+              bias_mu=float(BIAS) if BIAS else None, rate_hz=float(os.environ.get('RATE', '20')))
 dev = p.device()
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 dev.set_stream(st.cuda_stream)
