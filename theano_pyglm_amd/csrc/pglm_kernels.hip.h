@@ -34,6 +34,12 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define PGL_MAXB 8
 #ifndef PGL_PRIO
 #define PGL_PRIO 1           // k_fused5: waves 4-7 lead the first half of every MFMA loop (s_setprio)
+#ifndef PGL_EPI_PRIO
+#define PGL_EPI_PRIO 1       // k_fused6 / k_fused7: issue priority of a wave inside its rate epilogue (s_setprio): the epilogue is
+                             // a chain of dependent VALU instructions between two workgroup barriers, the MFMA loops of the other
+                             // workgroups on the SIMD are throughput work that fills whatever it leaves -- measured C2 0.1447 ->
+                             // 0.1412 ms (priority 1, 2 and 3 alike), C5 and C1 within the noise
+#endif
 #endif
 #ifndef PGL_EBAR
 #define PGL_EBAR 1           // k_fused5: barrier between the epilogue and the backward loop
@@ -2223,6 +2229,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         PGL_PROF_MARK(4);
         // ---- epilogue: sum of the KSPLIT partials + bias -> ll terms, residuals; the elements of all MT
         // tiles go through the rate chains together (independent chains interleave) ----
+        if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(PGL_EPI_PRIO);
         if (active) {
             double xe[MT * EPW], rese[MT * EPW], terme[MT * EPW];
             bool vte[MT * EPW];
@@ -2285,6 +2292,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
             }
         }
         PGL_PROF_MARK(5);
+        if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         PGL_PROF_MARK(6);
         // ---- backward on this wave's K slice ----
@@ -2511,6 +2519,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         }
         PGL_PROF_MARK(3);
         // ---- epilogue on the accumulator registers ----
+        if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(PGL_EPI_PRIO);
         double rr[4];
         {
             bool done = false;
@@ -2557,6 +2566,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             }
         }
         PGL_PROF_MARK(4);
+        if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- backward over all K ----
         if (p.want_grad) {
             const double* fb = reinterpret_cast<const double*>(cur) + pgl_img_brow(grp) * RS + col;
