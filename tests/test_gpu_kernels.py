@@ -756,3 +756,50 @@ def test_kernel_families_agree_on_wild_parameters():
                 assert np.allclose(g[gf0], g0[gf0], rtol=1e-8, atol=1e-9 * scale), (trial, N, kind, kern, ver)
             seen_nonfinite += int((~gf1).sum())
     assert seen_nonfinite > 0
+
+
+@pytest.mark.gpu
+def test_narrow_post_blocks_of_a_wide_population_one_image_buffer():
+    """16 / 32 post neurons of a 128-neuron population (K = 640: a neuron-sharded rank, or a late line-search launch
+    of the lock-step MAP).  A 16-bin tile of 640 columns is 81 KB -- it does not fit the LDS twice -- so k_fused6 runs
+    with ONE image buffer (8 waves: K split 8 ways for one post tile, 4 ways for two).  Against the oracle, against
+    k_fused2 (option 95 = 2: in-kernel features), contiguous blocks, a neuron list, mixed regimes, a time sub-range
+    that is not a whole number of tiles, ll-only == ll+grad."""
+    N = 128
+    p = H.Problem(N, 16 * 150 + 7, H.std_ibasis(), kind='explinear', seed=61, weighted=True, w_scale=0.6)
+    p.theta[:40:3, 0] = np.linspace(-3.0, 9.0, 14)          # some neurons inside / below the |x| < 12 band
+    d = p.device()
+    W = np.ascontiguousarray(p.Weff)
+    for lo, hi in ((0, 16), (16, 48), (100, 128), (5, 21)):
+        d.set_option(95, 0)
+        ll, g = d.ll_grad(p.theta[lo:hi], W, lo, hi)
+        assert d.info(lo, hi)['kernel_version'] == 6
+        ll0, _ = d.ll_grad(p.theta[lo:hi], W, lo, hi, want_grad=False)
+        assert np.array_equal(ll, ll0)
+        lr, gr = p.oracle_ll_grad(lo, hi)
+        assert np.allclose(ll, lr, rtol=1e-10, atol=0) and np.allclose(g, gr, rtol=1e-9, atol=1e-9 * np.abs(gr).max())
+        d.set_option(95, 2)
+        ll2, g2 = d.ll_grad(p.theta[lo:hi], W, lo, hi)
+        assert d.info(lo, hi)['kernel_version'] == 2
+        assert np.allclose(ll, ll2, rtol=1e-12, atol=0) and np.allclose(g, g2, rtol=1e-11, atol=1e-11 * np.abs(g2).max())
+    d.set_option(95, 0)
+    import torch
+    idx = np.array([3, 77, 12, 120, 64, 9, 31], dtype=np.int32)
+    t_idx, t_th, t_W = torch.from_numpy(idx).cuda(), torch.from_numpy(p.theta[idx].copy()).cuda(), torch.from_numpy(W).cuda()
+    t_ll = torch.zeros(len(idx), dtype=torch.float64, device='cuda')
+    t_g = torch.zeros((len(idx), p.P), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    d.ll_grad_list_dev(t_idx.data_ptr(), len(idx), t_th.data_ptr(), t_W.data_ptr(), t_ll.data_ptr(), t_g.data_ptr())
+    d.sync()
+    lll, gl = t_ll.cpu().numpy(), t_g.cpu().numpy()
+    for j, n in enumerate(idx):
+        lr, gr = p.oracle_ll_grad(int(n), int(n) + 1)
+        assert np.allclose(lll[j], lr[0], rtol=1e-10, atol=0)
+        assert np.allclose(gl[j], gr[0], rtol=1e-9, atol=1e-9 * np.abs(gr).max())
+    d.set_time_range(160, 16 * 100 + 5)
+    ll, g = d.ll_grad(p.theta[:16], W, 0, 16)
+    assert d.info(0, 16)['kernel_version'] == 6
+    d.set_option(95, 2)
+    ll2, g2 = d.ll_grad(p.theta[:16], W, 0, 16)
+    assert np.allclose(ll, ll2, rtol=1e-12, atol=0) and np.allclose(g, g2, rtol=1e-11, atol=1e-11 * np.abs(g2).max())
+    d.close()

@@ -80,7 +80,7 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_epi64 = 0, opt_timing = 1;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1;
     long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
@@ -141,6 +141,7 @@ struct Plan {
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
     int mt;                             // version 6: 16-bin tiles per step
     int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
+    int sb6 = 0;                        // version 6: one image buffer per workgroup (k_fused6 DB = 0)
     int nw7, wg7;                       // version 7: waves per workgroup (1, 2, 4), workgroups per CU
     size_t lds;
     bool f32;
@@ -303,11 +304,25 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
                     if (lds6 <= 160 * 1024 && (mt == 1 || pl.nTiles >= 4)) mt6 = mt;
                 }
             }
+            pl.sb6 = 0;
+            if (mt6 == 0 && pl.nPT <= 2 && h->opt_sb6 != 2) {
+                // the row does not fit twice (K = 640: 81 KB per tile): 8-wave form with ONE image buffer, the only
+                // instantiations being <5,1> (one post tile, K split 8 ways) and <10,2> (two post tiles, 4 ways)
+                nw6 = 8; ptw6 = pl.nPT;
+                const int needw8 = (need + 8 / ptw6 - 1) / (8 / ptw6);
+                ktw6 = (ptw6 == 1) ? 5 : 10;
+                const size_t lds1 = (size_t)pgl_img_bytes(ktw6 * (8 / ptw6)) + (size_t)8 * 2048 + 256 + (size_t)8 * 384;
+                if (needw8 <= ktw6 && needw8 > ktw6 / 2 && lds1 <= 160 * 1024) {
+                    mt6 = 1;
+                    pl.sb6 = 1;
+                }
+            }
             if (mt6 > 0) {
                 const int ktall = ktw6 * (nw6 / ptw6);
                 bool ok = true;
                 if (h->opt_kernel == 0 && find_img(h, ktall << 8, pl.tile0, pl.nTiles) < 0)
                     ok = img_room(h, (size_t)pl.nTiles * pgl_img_bytes(ktall));
+                if (!ok) pl.sb6 = 0;
                 if (ok) {
                     pl.version = 6;
                     pl.mt = mt6; pl.nw6 = nw6; pl.PTW = ptw6; pl.KTW = ktw6; pl.KSPLIT = nw6 / ptw6;
@@ -352,7 +367,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     int wgPerCU = (pl.version == 7) ? pl.wg7 : 1;
     if (pl.version == 6) {
         // as many workgroups per CU as registers and LDS allow (4-wave form at C2: three)
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
+        pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
         wgPerCU = fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
@@ -379,7 +394,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         return PGL_OK;
     }
     if (pl.version == 6) {
-        pl.lds = (size_t)2 * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
+        pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -522,12 +537,12 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
 }
 
 // occ != nullptr: no launch, *occ = workgroups of this instantiation a CU holds with pl.lds bytes of LDS
-template <int KTW, int PTW, int MT, int NW>
+template <int KTW, int PTW, int MT, int NW, int DB = 1>
 static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ)
 {
-    constexpr size_t need = (size_t)2 * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256 + (size_t)NW * 384;
+    constexpr size_t need = (size_t)(DB ? 2 : 1) * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256 + (size_t)NW * 384;
     if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
-        auto kern = k_fused6<KTW, PTW, MT, NW>;
+        auto kern = k_fused6<KTW, PTW, MT, NW, DB>;
         hipError_t e = ensure_dyn_lds(kern, pl.lds);
         if (e != hipSuccess) return e;
         if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, NW * 64, pl.lds);
@@ -561,6 +576,11 @@ static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream
         }
         return hipErrorInvalidValue;
     }
+    if (pl.sb6) {                                  // one image buffer: 640-column rows for one or two post tiles
+        if (pl.mt == 1 && pl.PTW == 1 && pl.KTW == 5) return launch_fused6_t<5, 1, 1, 8, 0>(pl, fp, s, occ);
+        if (pl.mt == 1 && pl.PTW == 2 && pl.KTW == 10) return launch_fused6_t<10, 2, 1, 8, 0>(pl, fp, s, occ);
+        return hipErrorInvalidValue;
+    }
     switch (pl.PTW * 4 + pl.mt) {
     case 1 * 4 + 1: return launch_fused6_k<1, 1, 8>(pl, fp, s, occ);
     case 1 * 4 + 2: return launch_fused6_k<1, 2, 8>(pl, fp, s, occ);
@@ -575,8 +595,8 @@ static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream
 // workgroups per CU of the k_fused6 instantiation a plan selects (registers and LDS), cached per shape
 static int fused6_wg_per_cu(const Plan& pl)
 {
-    static int cache[11][5][3][9];             // [KTW][PTW][mt][nw6]; 0 = not asked yet
-    int& c = cache[pl.KTW][pl.PTW][pl.mt][pl.nw6];
+    static int cache[2][11][5][3][9];          // [sb6][KTW][PTW][mt][nw6]; 0 = not asked yet
+    int& c = cache[pl.sb6 ? 1 : 0][pl.KTW][pl.PTW][pl.mt][pl.nw6];
     if (c == 0) {
         int occ = 0;
         FusedParams fp{};
@@ -743,6 +763,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
+    case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer form of k_fused6
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
     case PGL_OPT_EPI_F64: h->opt_epi64 = value ? 1 : 0; return PGL_OK;

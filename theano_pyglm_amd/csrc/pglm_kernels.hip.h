@@ -2039,7 +2039,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 // filled by the other's MFMAs) for post blocks of one or two tiles.
 // Same partial layout as k_fused2 (k_finalize / k_finalize_ll reduce it).
 // ---------------------------------------------------------------------------
-template <int KTW, int PTW, int MT, int NW>
+template <int KTW, int PTW, int MT, int NW, int DB = 1>
 __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 {
     constexpr int TT = 16;
@@ -2063,8 +2063,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     const int pt = pb * PTW + ptl;
     const bool active = pt < p.nPT;
 
-    unsigned char* bufs = smem;                                          // [2][MT][IMG]
-    double* Xp = reinterpret_cast<double*>(smem + (size_t)2 * MT * IMG); // [MT][NW][4][64] partial currents
+    // DB = 0: ONE image buffer per workgroup, for rows too long to hold twice (a 16-bin tile of 640 columns is 81 KB:
+    // the narrow post blocks of a wide population) -- the next step's images are requested behind a fourth barrier,
+    // when the backward loop has read the current ones
+    unsigned char* bufs = smem;                                          // [DB ? 2 : 1][MT][IMG]
+    double* Xp = reinterpret_cast<double*>(smem + (size_t)(DB ? 2 : 1) * MT * IMG); // [MT][NW][4][64] partial currents
     // residuals [MT][PTW][4][64]: they take the place of the k-slice-0 partials -- element (m, ptl, r, lane) of both
     // is read (partial) and then written (residual) by the one wave that owns register r in the epilogue, and the
     // next step's partials are only written behind the "landed" barrier, when every wave has read its residuals
@@ -2153,7 +2156,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     int par = 0;
     PGL_PROF_DECL
     for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
-        const unsigned char* cur = bufs + (size_t)par * MT * IMG;
+        const unsigned char* cur = bufs + (size_t)(DB ? par : 0) * MT * IMG;
         __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's pieces of the step landed
         PGL_PROF_MARK(0);
         __syncthreads();                                  // ... everybody's; the other buffer is free
@@ -2168,9 +2171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         // the images of the next step: PWV pieces of 1 KiB per wave, one every DS forward MFMAs (PGL_DMA_IL), the
         // whole burst up front for waves without MFMA work
         const bool more = tile + MT < tile_end;
-        unsigned char* const nxt = bufs + (size_t)(par ^ 1) * MT * IMG;
+        unsigned char* const nxt = bufs + (size_t)(DB ? (par ^ 1) : 0) * MT * IMG;
         constexpr int NCH = IMG / 1024, PPI = (NCH + NW - 1) / NW, PWV = MT * PPI, NMF = MT * KSW;
-        constexpr int DS = (PGL_DMA_IL && NMF >= PWV) ? NMF / PWV : 0;
+        constexpr int DS = (DB && PGL_DMA_IL && NMF >= PWV) ? NMF / PWV : 0;
         auto piece = [&](const int j) {
             typedef __attribute__((address_space(1))) void gvoid;
             typedef __attribute__((address_space(3))) void lvoid;
@@ -2184,7 +2187,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         };
         if (more) {
             load_counts(tile + MT);
-            if (DS == 0 || !active) {
+            if (DB && (DS == 0 || !active)) {
 #pragma unroll
                 for (int j = 0; j < PWV; ++j) piece(j);
             }
@@ -2319,6 +2322,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
             }
         }
         PGL_PROF_MARK(7);
+        if (!DB && more) {
+            __syncthreads();                              // every wave has read the images of this step
+#pragma unroll
+            for (int j = 0; j < PWV; ++j) piece(j);
+        }
     }
     PGL_PROF_STORE(1);
 
