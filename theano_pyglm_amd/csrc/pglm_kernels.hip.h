@@ -2153,6 +2153,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         for (int e = 0; e < EPW; ++e) cptr[e] += (size_t)MT * ctile;
     };
     load_counts(tile_beg);
+    // One image buffer and a short K slice per wave (DB = 0, KTW <= 5: one post tile of a 640-column row): the wave also
+    // fetches its BACKWARD fragments of the tile while the image is there (20 doubles), so that the buffer is free from
+    // the "partials" barrier on and the next tile's image travels during the epilogue and the backward MFMAs
+    constexpr bool BREG = (DB == 0 && MT == 1 && KTW <= 5);
+    double fbreg[BREG ? 4 * KTW : 1], fareg[BREG ? KSW : 1];
     int par = 0;
     PGL_PROF_DECL
     for (int tile = tile_beg; tile < tile_end; tile += MT, par ^= 1) {
@@ -2192,6 +2197,25 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 for (int j = 0; j < PWV; ++j) piece(j);
             }
         }
+        if constexpr (BREG) {
+            // all the fragments of the tile this wave will need, forward and backward, into registers; then the buffer
+            // is free and the next image travels during the whole tile
+            if (active) {
+                const double* fa = reinterpret_cast<const double*>(cur) + pgl_img_row(col) * RS + kcol0 + grp;
+#pragma unroll
+                for (int s = 0; s < KSW; ++s) fareg[s] = pgl_lds_f64(fa + 4 * s);
+                if (p.want_grad) {
+                    const double* fb = reinterpret_cast<const double*>(cur) + pgl_img_brow(grp) * RS + kcol0 + col;
+#pragma unroll
+                    for (int s = 0; s < 4 * KTW; ++s) fbreg[s] = pgl_lds_f64(fb + (2 * (s / KTW)) * RS + 16 * (s % KTW));
+                }
+            }
+            __syncthreads();                              // every wave holds its fragments
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < PWV; ++j) piece(j);
+            }
+        }
         PGL_PROF_MARK(2);
         // ---- forward over this wave's K slice, tile by tile ----
 #pragma unroll
@@ -2202,12 +2226,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 const double* fa = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + pgl_img_row(col) * RS + kcol0 + grp;
                 constexpr int PA = (KSW < 4) ? KSW : 4;
                 double ar[PA];
+                if constexpr (!BREG) {
 #pragma unroll
-                for (int s = 0; s < PA; ++s) ar[s] = pgl_lds_f64(fa + 4 * s);
+                    for (int s = 0; s < PA; ++s) ar[s] = pgl_lds_f64(fa + 4 * s);
+                }
 #pragma unroll
                 for (int s = 0; s < KSW; ++s) {
-                    const double a = ar[s % PA];
-                    if (s + PA < KSW) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
+                    const double a = BREG ? fareg[BREG ? s : 0] : ar[s % PA];
+                    if (!BREG && s + PA < KSW) ar[s % PA] = pgl_lds_f64(fa + 4 * (s + PA));
                     if (s & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wreg[s], acc1, 0, 0, 0);
                     else
@@ -2308,6 +2334,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                 for (int r = 0; r < 4; ++r) rr[r] = Rb[((size_t)m * RBS + ptl) * 256 + r * 64 + lane];
                 const double* fb = reinterpret_cast<const double*>(cur + (size_t)m * IMG) + pgl_img_brow(grp) * RS + kcol0 + col;
                 constexpr int NS = 4 * KTW;
+                if constexpr (BREG) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(fbreg[s], rr[s / KTW], G[s % KTW], 0, 0, 0);
+                        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
                 constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
                 double ar[PD];
 #pragma unroll
@@ -2319,10 +2352,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
                     G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rr[s / KTW], G[s % KTW], 0, 0, 0);
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+                }
             }
         }
         PGL_PROF_MARK(7);
-        if (!DB && more) {
+        if (!DB && !BREG && more) {
             __syncthreads();                              // every wave has read the images of this step
 #pragma unroll
             for (int j = 0; j < PWV; ++j) piece(j);
