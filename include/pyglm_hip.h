@@ -58,7 +58,8 @@ typedef struct pgl_context* pgl_handle;
                                 * (nT/16 * 2 * ~41 KB at K = 640: 3.1 GB for nT = 600 000) */
 
 #define PGL_OPT_GIBBS_KERNEL 4 /* pgl_gibbs_ll_cols with the explinear nonlinearity: 0 = auto (regime-split kernels: single
-                                * precision for the log1p(exp(-|x|)) term where |x| >= 12, compacted f64 elsewhere,
+                                * precision for the log1p(exp(-|x|)) term where |x| >= 12, compacted f64 elsewhere (log1p
+                                * through a 32-interval table: < 2e-16 absolute),
                                 * spike terms from the event lists); 1 = the all-f64 one-thread-per-(column, weight)
                                 * kernel (always used for the exp nonlinearity) */
 #define PGL_OPT_EPI_F64 5      /* 1 = all-f64 rate epilogue of the fused ll+grad kernels.  Default 0: in waves whose currents
@@ -69,6 +70,11 @@ typedef struct pgl_context* pgl_handle;
                                 * (default), n > 1 = a sample, 0 = none.  An event between two kernels of a stream costs ~6 us of
                                 * GPU idle time; loops that queue evaluations back to back (optimisers, bench.py) sample or
                                 * switch the events off */
+
+/* Development switches (not part of the drop-in surface; results stay valid unless stated): 95 = 2 keeps the narrow post
+ * blocks of a wide population off the one-image-buffer form of k_fused6 (they run on k_fused2); 97 = waves per block of
+ * the partial reduction; 98 / 99 = kernel-internal ablation bits of the fused / Gibbs kernels (99 != 0 invalidates the
+ * Gibbs results except bit 0x1000: event-window pair currents although all columns share the presynaptic neuron). */
 
 const char* pgl_last_error(void);
 int pgl_version(void);
