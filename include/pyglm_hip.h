@@ -73,8 +73,9 @@ typedef struct pgl_context* pgl_handle;
 
 /* Development switches (not part of the drop-in surface; results stay valid unless stated): 95 = 2 keeps the narrow post
  * blocks of a wide population off the one-image-buffer form of k_fused6 (they run on k_fused2); 97 = waves per block of
- * the partial reduction; 98 / 99 = kernel-internal ablation bits of the fused / Gibbs kernels (99 != 0 invalidates the
- * Gibbs results except bit 0x1000: event-window pair currents although all columns share the presynaptic neuron). */
+ * the partial reduction; 98 = post tiles per workgroup of the K-split kernels; 99 = kernel-internal ablation bits of the
+ * fused / Gibbs kernels (!= 0 invalidates the results, except bit 0x1000: event-window pair currents although all columns
+ * share the presynaptic neuron, and bits 8-11: forced sub-block count of k_gibbs_rate_cols). */
 
 const char* pgl_last_error(void);
 int pgl_version(void);
