@@ -411,6 +411,8 @@ def test_separable_stimulus_matches_dense_and_oracle():
         sep = p.device()
         sep.set_stimulus_separable(stim, dt_stim, ibt, ibx)
         assert sep.P == 1 + Bt + Bx + N * 3
+        # dt_stim = 100 dt: the frame-rate kernels (5 frame values per bin); dt_stim = 13 dt would need 26: tap-rate kernels
+        assert sep.info()['stim_path'] == (2 if dt_stim == 0.1 else 1)
         th_s = np.concatenate((p.theta[:, :1], w_t, w_x, p.theta[:, 1:]), axis=1)
         ll_s, g_s = sep.ll_grad(th_s, p.Weff)
         assert np.allclose(ll_s, ll_d, rtol=1e-11)
@@ -441,6 +443,69 @@ def test_separable_stimulus_matches_dense_and_oracle():
         with pytest.raises(_lib.PglError):
             sep.get_stim_features()
         dense.close()
+        sep.close()
+
+
+def test_separable_stimulus_frame_rate_kernels():
+    """The frame-rate form of the separable stimulus (k_sepf_fwd / k_sepf_bwd / k_sepf_finish + the MFMA GEMMs, impulse
+    columns on resident tiles through the slab-input form of k_fused7) against the tap-rate kernels of the same handle
+    (dev option 94) and against the oracle on the dense features (bkgd.py:214-227, 303-340; basis.py:238-273): one to
+    four post tiles, q = 100 / 50 / 150 bins per frame (5, 8 and 4 frame values per bin), one to three temporal bases,
+    recordings that end before / behind the last frame, time ranges that cut frames."""
+    from tests import helpers as H
+    from theano_pyglm_amd import _lib
+    rng = np.random.RandomState(78)
+    ibt3 = H.golden()['lr2d_ibasis_t']
+    cases = ((6, 3000, 24, 0.1, 25, 3, None),        # frames end at bin 2400: clamped tail
+             (40, 4000, 32, 0.05, 90, 2, 7),         # q = 50 -> 8 frame values; non-identity spatial basis; frames outlast the bins
+             (64, 2512, 16, 0.15, 17, 1, None),      # q = 150 -> 4 frame values, recording not a multiple of the frame
+             (20, 1600, 8, 0.1, 16, 3, None))
+    for N, nT, D, dt_stim, Tstim, Bt, Bx_ in cases:
+        Bx = D if Bx_ is None else Bx_
+        ibt = np.ascontiguousarray(ibt3[:, :Bt])
+        stim = rng.randn(Tstim, D)
+        ibx = None if Bx_ is None else rng.randn(D, Bx)
+        p = H.Problem(N, nT, H.st_ibasis(), kind='exp', seed=5 + N, w_scale=0.02)
+        w_t, w_x = 0.3 * rng.randn(N, Bt), 0.3 * rng.randn(N, Bx) / np.sqrt(Bx / 8.0)
+        sep = p.device()
+        sep.set_stimulus_separable(stim, dt_stim, ibt, ibx)
+        th_s = np.concatenate((p.theta[:, :1], w_t, w_x, p.theta[:, 1:]), axis=1)
+        assert sep.info()['stim_path'] == 2 and sep.info()['kernel_version'] == 7
+        ll_f, g_f = sep.ll_grad(th_s, p.Weff)
+        ll_only, _ = sep.ll_grad(th_s, p.Weff, want_grad=False)
+        assert np.allclose(ll_only, ll_f, rtol=1e-13)
+        # oracle on the dense features
+        fst = O.spatiotemporal_stim_features(stim, dt_stim, 0.001, nT, np.eye(D) if ibx is None else ibx, ibt)
+        th_d = np.concatenate((p.theta[:, :1], np.einsum('nt,nx->ntx', w_t, w_x).reshape(N, -1), p.theta[:, 1:]), axis=1)
+        p.fstim, p.Dstim, p.P, p.theta = fst, Bt * Bx, th_d.shape[1], th_d
+        ll0, g0 = p.oracle_ll_grad()
+        G = g0[:, 1:1 + Bt * Bx].reshape(N, Bt, Bx)
+        g_chain = np.concatenate((g0[:, :1], np.einsum('ntx,nx->nt', G, w_x), np.einsum('ntx,nt->nx', G, w_t),
+                                  g0[:, 1 + Bt * Bx:]), axis=1)
+        assert np.allclose(ll_f, ll0, rtol=1e-10), (N, np.max(np.abs(ll_f - ll0) / np.abs(ll0)))
+        for sl in (slice(0, 1), slice(1, 1 + Bt), slice(1 + Bt, 1 + Bt + Bx), slice(1 + Bt + Bx, None)):
+            assert H.rel_err(g_f[:, sl], g_chain[:, sl]) < 1e-9, (N, sl)
+        # neuron sub-range and time ranges that cut stimulus frames: partial sums add up
+        lo_n, hi_n = N // 3, N // 3 + max(1, N // 2)
+        a, b = sep.ll_grad(th_s[lo_n:hi_n], p.Weff, lo_n, hi_n)
+        assert np.allclose(a, ll_f[lo_n:hi_n], rtol=1e-12) and H.rel_err(b, g_f[lo_n:hi_n]) < 1e-11
+        acc_l, acc_g = 0.0, 0.0
+        cut1, cut2 = 16 * 21, 16 * 77
+        for lo, hi in ((0, cut1), (cut1, cut2), (cut2, nT)):
+            sep.set_time_range(lo, hi)
+            a, b = sep.ll_grad(th_s, p.Weff)
+            acc_l, acc_g = acc_l + a, acc_g + b
+        assert np.allclose(acc_l, ll_f, rtol=1e-11) and H.rel_err(acc_g, g_f) < 1e-10
+        sep.set_time_range(0, nT - 37)
+        a37, b37 = sep.ll_grad(th_s, p.Weff)
+        # the tap-rate kernels on the same handle
+        sep.set_option(94, 2)
+        assert sep.info()['stim_path'] == 1
+        a37t, b37t = sep.ll_grad(th_s, p.Weff)
+        assert np.allclose(a37, a37t, rtol=1e-12) and H.rel_err(b37, b37t) < 1e-11
+        sep.set_time_range(0, nT)
+        ll_t, g_t = sep.ll_grad(th_s, p.Weff)
+        assert np.allclose(ll_f, ll_t, rtol=1e-12) and H.rel_err(g_f, g_t) < 1e-11
         sep.close()
 
 

@@ -371,10 +371,10 @@ class DeviceGlm(object):
 
     def info(self, n_lo=0, n_hi=None):
         n_hi = self.N if n_hi is None else n_hi
-        v = np.zeros(12)
-        _chk(self.lib.pgl_info(self.h, int(n_lo), int(n_hi), _ptr(v), 12))
+        v = np.zeros(13)
+        _chk(self.lib.pgl_info(self.h, int(n_lo), int(n_hi), _ptr(v), 13))
         keys = ['blocks', 'threads', 'chunks', 'ktiles', 'lds_bytes', 'tile_rows', 'flops',
-                'bytes', 'events', 'kernel_version', 'resident_feature_bytes', 'streamed_bytes']
+                'bytes', 'events', 'kernel_version', 'resident_feature_bytes', 'streamed_bytes', 'stim_path']
         return dict(zip(keys, v.tolist()))
 
     # -- direct-form helpers --------------------------------------------------

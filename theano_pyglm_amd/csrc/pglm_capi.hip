@@ -71,6 +71,12 @@ struct pgl_context {
     int64_t sepT = 0;
     double sep_dt_stim = 0;
     DevBuf zf, zfT, sbt, Yf, Qb, Qf, spart;
+    // frame-rate form of the separable stimulus (dt_stim an integer multiple q of dt, J = ceil(Rt / q) + 2 <= 8 frame
+    // values per bin): coefficient table C[q (M + 1)][sepJ][sepBTp], see k_sepf_fwd
+    bool sepf = false;
+    int sepq = 0, sepM = 0, sepJ = 0, sepBTp = 0;
+    DevBuf sepC, YfT, Hb, wpart, QvT;
+    int opt_sepf = 0;                    // dev option 94: 2 = never take the frame-rate path
     const int* cur_pidx = nullptr;       // post-neuron list of the evaluation being enqueued (device)
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -197,7 +203,7 @@ static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(kt
 static int fused6_wg_per_cu(const Plan& pl);
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
-                     bool single_slice = true)
+                     bool single_slice = true, bool force7 = false)
 {
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
@@ -340,14 +346,14 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     // (measured, tools/small_shape_scan.py / config_table.py: 3-4 post tiles 46 TFLOP/s against 39 of the
     // K-split kernel at C5; with 1-2 post tiles only 2-6 waves fit a CU and the 4-wave K-split form wins)
     if ((pl.version == 2 || pl.version == 6) && !pl.f32 && single_slice && pl.nPT <= 4 && need <= 20 &&
-        ((h->opt_kernel == 0 && pl.nPT >= 3) || h->opt_kernel == 7) && h->opt_ptw == 0) {
+        ((h->opt_kernel == 0 && pl.nPT >= 3) || h->opt_kernel == 7 || force7) && h->opt_ptw == 0) {
         int kt7 = 0;
         for (int k : kKT7)
             if (k >= need) {
                 kt7 = k;
                 break;
             }
-        const int nw7 = (pl.nPT >= 3) ? 4 : pl.nPT;
+        const int nw7 = (pl.nPT >= 3 || force7) ? 4 : pl.nPT;       // force7: the slab-input form exists for 4 waves only
         const size_t lds7 = (size_t)2 * pgl_img_bytes(kt7) + 256 + (size_t)nw7 * 192 * 8;
         bool ok = kt7 > 0 && lds7 <= 160 * 1024;
         if (ok && h->opt_kernel == 0 && find_img(h, kt7 << 8, pl.tile0, pl.nTiles) < 0)
@@ -606,10 +612,10 @@ static int fused6_wg_per_cu(const Plan& pl)
     return c;
 }
 
-template <int KT, int NWV>
+template <int KT, int NWV, int XIO = 0>
 static hipError_t launch_fused7_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
-    auto kern = k_fused7<KT, NWV>;
+    auto kern = k_fused7<KT, NWV, XIO>;
     hipError_t e = ensure_dyn_lds(kern, pl.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NWV * 64), pl.lds, s, fp);
@@ -629,6 +635,24 @@ static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStre
     case 13: return launch_fused7_t<13, NWV>(pl, fp, s);
     case 16: return launch_fused7_t<16, NWV>(pl, fp, s);
     case 20: return launch_fused7_t<20, NWV>(pl, fp, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// slab-input form (separable stimulus at the frame rate): 4-wave workgroups only
+static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipStream_t s)
+{
+    if (pl.nw7 != 4) return hipErrorInvalidValue;
+    switch (pl.KT) {
+    case 1: return launch_fused7_t<1, 4, 1>(pl, fp, s);
+    case 2: return launch_fused7_t<2, 4, 1>(pl, fp, s);
+    case 3: return launch_fused7_t<3, 4, 1>(pl, fp, s);
+    case 5: return launch_fused7_t<5, 4, 1>(pl, fp, s);
+    case 7: return launch_fused7_t<7, 4, 1>(pl, fp, s);
+    case 10: return launch_fused7_t<10, 4, 1>(pl, fp, s);
+    case 13: return launch_fused7_t<13, 4, 1>(pl, fp, s);
+    case 16: return launch_fused7_t<16, 4, 1>(pl, fp, s);
+    case 20: return launch_fused7_t<20, 4, 1>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -663,6 +687,21 @@ static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream
     case 4: return launch_fused2_k<4, 8, PGL_CAP, double>(pl, fp, s);
     }
     return hipErrorInvalidValue;
+}
+
+// separable stimulus at the frame rate: which = 0 forward, 1 backward, 2 finish
+template <int J, int BT>
+static void launch_sepf(int which, const SepfParams& sp, hipStream_t s)
+{
+    const long long nF = sp.F1 - sp.F0 + 1;
+    const int nG = (sp.nPT + 3) / 4;
+    dim3 grid((unsigned)((nF + 3) / 4), (unsigned)nG);
+    if (which == 0) hipLaunchKernelGGL((k_sepf_fwd<J, BT>), grid, dim3(256), 0, s, sp);
+    else if (which == 1) hipLaunchKernelGGL((k_sepf_bwd<J, BT>), grid, dim3(256), 0, s, sp);
+    else {
+        const int nA = (int)((sp.Tstim + 3) / 4) * nG;
+        hipLaunchKernelGGL((k_sepf_finish<J, BT>), dim3(nA + nG * BT), dim3(256), 0, s, sp, nA, nG);
+    }
 }
 
 extern "C" {
@@ -763,6 +802,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
+    case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels
     case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer form of k_fused6
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
@@ -982,6 +1022,44 @@ static int launch_gemm_nt(pgl_handle h, const double* A, int lda, const double* 
     return PGL_OK;
 }
 
+// Frame-rate coefficient table of the separable stimulus (k_sepf_fwd): for bin t = q F + o, base = max(F - M, 0),
+//   C[t][j][bt] = sum_{tau = 1 .. min(Rt, t)} basis_t[tau-1][bt] * (weight of frame base + j in np.interp at bin t - tau)
+// for t < q (M + 1); later bins repeat the rows q M + o.  np.interp between frames f = s / q and f + 1 at bin s
+// weighs them (1 - a, a) with a = (s % q) / q (bkgd.py:303-340 interpolates on the dt grid; the clamp behind the
+// last frame is an index clamp in the kernels).  Only when dt_stim is an integer multiple of dt and J <= 8, Bt <= 4.
+static int build_frame_table(pgl_handle h, const double* basis_t, int Rt, int Bt, double dt_stim)
+{
+    h->sepf = false;
+    const double ratio = dt_stim / h->dt;
+    const long long q = llround(ratio);
+    if (q < 1 || std::fabs(ratio - (double)q) > 1e-9 * ratio) return PGL_OK;
+    const long long M = (Rt + q - 1) / q, J = M + 2;
+    if (J > 8 || Bt > 4) return PGL_OK;
+    const int Jp = (J <= 5 && Bt <= 3) ? 5 : 8, BTp = (J <= 5 && Bt <= 3) ? 3 : 4;
+    const long long rows = q * (M + 1);
+    if (rows * Jp * BTp > (1ll << 24)) return PGL_OK;
+    std::vector<double> C((size_t)rows * Jp * BTp, 0.0);
+    for (long long t = 0; t < rows; ++t) {
+        const long long F = t / q, base = std::max<long long>(F - M, 0);
+        double* row = C.data() + (size_t)t * Jp * BTp;
+        for (long long tau = 1; tau <= std::min<long long>(Rt, t); ++tau) {
+            const long long sb = t - tau, f = sb / q;
+            const double a = (double)(sb % q) / (double)q;
+            for (int bt = 0; bt < Bt; ++bt) {
+                const double b = basis_t[(size_t)(tau - 1) * Bt + bt];
+                row[(f - base) * BTp + bt] += b * (1.0 - a);
+                if (a != 0.0) row[(f + 1 - base) * BTp + bt] += b * a;
+            }
+        }
+    }
+    ENSURE(h->sepC, C.size() * 8);
+    HIPCHK(hipMemcpyAsync(h->sepC.p, C.data(), C.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->sepq = (int)q; h->sepM = (int)M; h->sepJ = Jp; h->sepBTp = BTp;
+    h->sepf = true;
+    return PGL_OK;
+}
+
 int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
                                const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt)
 {
@@ -1018,6 +1096,10 @@ int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, 
     if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_set_stimulus_separable: ") + hipGetErrorString(e));
     h->sep = true;
     h->sepBt = Bt; h->sepBx = Bx; h->sepRt = Rt; h->sepT = Tstim; h->sep_dt_stim = dt_stim;
+    {
+        int rc2 = build_frame_table(h, basis_t, Rt, Bt, dt_stim);
+        if (rc2) return rc2;
+    }
     h->Dstim = Bt + Bx;                       // layout of a theta row; NOT feature columns of the fused kernels
     h->Ktot = h->Kimp;
     h->gibbs_npost = -1;
@@ -1071,6 +1153,64 @@ static int sep_backward(pgl_handle h, const SepParams& sp, double* d_grad)
     HIPCHK(hipGetLastError());
     return launch_gemm_nt(h, (const double*)h->Qf.p, (int)h->sepT, (const double*)h->zfT.p, (int)h->sepT,
                           d_grad + 1 + h->sepBt, sp.P, npost, h->sepBx, (int)h->sepT);
+}
+
+static int launch_gemm_mfma(pgl_handle h, const double* A, long long sam, long long sak, const double* B,
+                            long long sbn, long long sbk, double* C, long long scm, long long scn, int M, int N, int K)
+{
+    const int mb = (M + 15) / 16;
+    if (mb >= 128) {       // many row tiles: 16 x 64 per wave; else one 16-column tile per workgroup (more workgroups)
+        hipLaunchKernelGGL(k_gemm_mfma<4>, dim3(mb, (N + 63) / 64), dim3(256), 0, h->stream, A, sam, sak, B, sbn, sbk,
+                           C, scm, scn, M, N, K);
+    } else {
+        hipLaunchKernelGGL(k_gemm_mfma<1>, dim3(mb, (N + 15) / 16), dim3(256), 0, h->stream, A, sam, sak, B, sbn, sbk,
+                           C, scm, scn, M, N, K);
+    }
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+static int launch_sepf_any(pgl_handle h, int which, const SepfParams& sp)
+{
+    if (h->sepJ == 5 && h->sepBTp == 3) launch_sepf<5, 3>(which, sp, h->stream);
+    else launch_sepf<8, 4>(which, sp, h->stream);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+// separable stimulus at the frame rate, forward: the slab Xbuf[tile - tile0][post tile][r][lane] = I_stim of the
+// npost rows of d_theta on the plan's tile range
+static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, SepfParams& sp)
+{
+    const int P = 1 + h->Dstim + h->Kimp, ldy = pl.nPT * 16;
+    ENSURE(h->YfT, (size_t)h->sepT * ldy * 8);
+    // z_n[f] = (stim . basis_x)[f, :] . w_x[n]  ->  YfT[f][n]
+    int rc = launch_gemm_mfma(h, (const double*)h->zf.p, h->sepBx, 1, d_theta + 1 + h->sepBt, P, 1, (double*)h->YfT.p,
+                              ldy, 1, (int)h->sepT, pl.npost, h->sepBx);
+    if (rc) return rc;
+    sp.Ctab = (const double*)h->sepC.p; sp.YfT = (const double*)h->YfT.p; sp.theta = d_theta;
+    sp.X = (double*)h->Xbuf.p; sp.Hb = nullptr; sp.wpart = nullptr; sp.QvT = nullptr; sp.grad = nullptr;
+    sp.P = P; sp.Bt = h->sepBt; sp.M = h->sepM; sp.q = h->sepq; sp.npost = pl.npost; sp.nPT = pl.nPT; sp.ldy = ldy;
+    sp.tile0 = pl.tile0; sp.nTiles = pl.nTiles; sp.Tstim = h->sepT;
+    const long long tb = (long long)pl.tile0 * 16, te = tb + (long long)pl.nTiles * 16;
+    sp.F0 = tb / h->sepq; sp.F1 = (te - 1) / h->sepq;
+    return launch_sepf_any(h, 0, sp);
+}
+
+// backward: the slab holds r = d ll / d x; writes the w_t and w_x columns of d_grad
+static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad)
+{
+    const long long nF = sp.F1 - sp.F0 + 1;
+    ENSURE(h->Hb, (size_t)nF * h->sepJ * sp.ldy * 8);
+    ENSURE(h->wpart, (size_t)nF * h->sepBTp * sp.ldy * 8);
+    ENSURE(h->QvT, (size_t)h->sepT * sp.ldy * 8);
+    sp.Hb = (double*)h->Hb.p; sp.wpart = (double*)h->wpart.p; sp.QvT = (double*)h->QvT.p; sp.grad = d_grad;
+    int rc = launch_sepf_any(h, 1, sp);
+    if (!rc) rc = launch_sepf_any(h, 2, sp);
+    if (rc) return rc;
+    // d ll / d w_x[n][x] = sum_f (stim . basis_x)[f][x] QvT[f][n]
+    return launch_gemm_mfma(h, (const double*)h->zfT.p, h->sepT, 1, (const double*)h->QvT.p, 1, sp.ldy,
+                            d_grad + 1 + h->sepBt, 1, sp.P, h->sepBx, sp.npost, (int)h->sepT);
 }
 
 int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
@@ -1260,7 +1400,7 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
     hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
-                       h->Rk, h->Dstim, ktl, kth, tile0, (unsigned char*)im.buf.p);
+                       h->Rk, h->sep ? 0 : h->Dstim, ktl, kth, tile0, (unsigned char*)im.buf.p);
     HIPCHK(hipGetLastError());
     im.key = key;
     im.tile0 = tile0;
@@ -1280,11 +1420,19 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
 {
     const std::vector<Slice> slices = make_slices(h);
     std::vector<Plan> plans(slices.size());
-    for (size_t i = 0; i < slices.size(); ++i) {
+    // separable stimulus at the frame rate: impulse columns on resident tiles (k_fused7, slab-input form), the stimulus
+    // current / its gradients by k_sepf_*; needs a short feature row (<= 4 post tiles, <= 320 columns)
+    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->cur_pidx && !h->opt_f32;
+    if (sepf) {
+        int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
+        if (rc) return rc;
+        sepf = plans[0].version == 7 && plans[0].nw7 == 4;
+    }
+    for (size_t i = 0; i < slices.size() && !sepf; ++i) {
         int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1 && !h->sep);
         if (rc) return rc;
     }
-    const bool sliced = slices.size() > 1 || h->sep;     // the separable stimulus rides on the 3-phase path
+    const bool sliced = !sepf && (slices.size() > 1 || h->sep);     // else the separable stimulus rides on the 3-phase path
     size_t maxG = 0, maxLL = 0;
     for (const Plan& pl : plans) {
         maxG = std::max(maxG, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
@@ -1303,7 +1451,40 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         h->ev = h->evr[h->ev_launches % pgl_context::NEV];
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
     }
-    if (!sliced) {
+    if (sepf) {
+        const Plan& pl = plans[0];
+        const bool direct = plan_reads_theta(pl);
+        int rc = direct ? PGL_OK : launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
+        if (rc) return rc;
+        ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
+        rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
+        if (rc) return rc;
+        if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        SepfParams sp;
+        rc = sepf_forward(h, pl, d_theta, sp);
+        if (rc) return rc;
+        FusedParams fp;
+        fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
+        if (direct) {
+            fp.theta = d_theta;
+            fp.Weff = d_Weff;
+        }
+        hipError_t e = launch_fused7_xio(pl, fp, h->stream);
+        if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
+        if (d_grad) {
+            rc = sepf_backward(h, sp, d_grad);
+            if (rc) return rc;
+            if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
+            if (rc) return rc;
+        } else {
+            if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+            hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(256), 0, h->stream,
+                               (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
+                               pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
+            HIPCHK(hipGetLastError());
+        }
+    } else if (!sliced) {
         const Plan& pl = plans[0];
         const bool direct = plan_reads_theta(pl);
         int rc = direct ? PGL_OK : launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
@@ -1599,10 +1780,20 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
     const std::vector<Slice> slices = make_slices(h);
     Plan pl;
-    int rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1);
+    // the stimulus path an evaluation would take: 0 none / dense feature columns, 1 separable by the tap-rate kernels on
+    // the 3-phase path, 2 separable at the frame rate (k_sepf_*, impulse columns on resident tiles)
+    int stim_path = h->sep ? 1 : 0;
+    int rc = PGL_OK;
+    if (h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32) {
+        rc = make_plan(h, n_lo, n_hi, slices[0], pl, true, true);
+        if (rc) return rc;
+        if (pl.version == 7 && pl.nw7 == 4) stim_path = 2;
+    }
+    if (stim_path != 2) rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1 && !h->sep);
     if (rc) return rc;
     const double P = 1.0 + h->Dstim + h->Kimp;
-    double v[12];
+    double v[13];
+    v[12] = stim_path;
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
     v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth)
             : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)pgl_img_bytes(pl.KT) : 0.0;   // resident feature bytes
@@ -1616,10 +1807,10 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     const double nrows = (double)(h->t_hi - h->t_lo);
     v[6] = 4.0 * nrows * (double)h->Ktot * (double)pl.npost;
     // nT*N*1 (u8 counts) + nT*Dstim*8 + params in + (ll+grad) out
-    v[7] = nrows * h->N + nrows * h->Dstim * 8.0 + 8.0 * pl.npost * P +
-           8.0 * pl.npost * (1.0 + P);
+    v[7] = nrows * h->N + (h->sep ? (double)h->sepT * h->sepBx * 8.0 : nrows * h->Dstim * 8.0) + 8.0 * pl.npost * P +
+           8.0 * pl.npost * (1.0 + P);          // separable: the projected stimulus at its frame rate
     v[8] = (double)h->nnz;
-    for (int i = 0; i < n_info && i < 12; ++i) info[i] = v[i];
+    for (int i = 0; i < n_info && i < 13; ++i) info[i] = v[i];
     return PGL_OK;
 }
 

@@ -2392,7 +2392,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 //   image of a tile = [16][RS] f64 as for k_fused6 (one part), double-buffered per workgroup.
 // Partials as k_fused5 (KSPLIT = 1).
 // ---------------------------------------------------------------------------
-template <int KT, int NWV>
+// XIO = 1: the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] (the stimulus current of a separable
+// stimulus, k_sepf_fwd) and the residuals r = d ll / d x are written back to the same slab (for k_sepf_bwd)
+template <int KT, int NWV, int XIO = 0>
 __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
 {
     constexpr int TT = 16;
@@ -2453,12 +2455,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         }
     }
     unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
+    double xib[XIO ? 4 : 1], xin[XIO ? 4 : 1];
+    double* const xslab = XIO ? p.Xbuf + (size_t)(active ? pt : 0) * 256 + lane : nullptr;
+    const size_t xstride = (size_t)p.nPT * 256;
     auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long long tg = (long long)tile * TT + grp + 4 * r;
             const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
             dst[r] = p.S[tc * p.Nall + nglob];
+        }
+        if constexpr (XIO != 0) {
+            const double* xs_ = xslab + (size_t)(tile - p.tile0) * xstride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xin[r] = xs_[r * 64];
         }
     };
     if (tile_beg < tile_end) {
@@ -2477,6 +2487,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         PGL_PROF_MARK(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) scb[r] = scn[r];
+        if constexpr (XIO != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xib[r] = xin[r];
+        }
         // the image of the next tile: PWV pieces of 1 KiB per wave, issued between the MFMAs (PGL_DMA_IL) of the
         // forward loop when the Wmat fragments live in registers -- with the streamed Wmat ring a DMA in flight
         // would sit in front of the ring loads in the in-order vmcnt queue -- else of the backward loop; waves
@@ -2569,6 +2583,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 double xs[4], term4 = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
+                if constexpr (XIO != 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xs[r] += xib[r];
+                }
                 const double* cg = PGL_C;
                 asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
                 done = pgl_rate4(xs, scb, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
@@ -2590,6 +2608,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * h2 + e;
                         xe[e] = bias_l + (acc0[r] + acc1[r]);
+                        if constexpr (XIO != 0) xe[e] += xib[r];
                         se[e] = (double)scb[r];
                         const long long tg = (long long)t0 + grp + 4 * r;
                         vte[e] = valid_n && (tg < p.t_hi);
@@ -2609,6 +2628,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         }
         PGL_PROF_MARK(4);
         if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (XIO != 0) {
+            if (p.want_grad) {
+                double* xs_ = xslab + (size_t)(tile - p.tile0) * xstride;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs_[r * 64] = rr[r];
+            }
+        }
         // ---- backward over all K ----
         if (p.want_grad) {
             const double* fb = reinterpret_cast<const double*>(cur) + pgl_img_brow(grp) * RS + col;
@@ -4234,6 +4260,261 @@ __global__ __launch_bounds__(64) void k_sep_wt_grad(const SepParams p, const dou
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (threadIdx.x == 0) grad[(size_t)j * p.P + 1 + b] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Separable stimulus at the FRAME rate (dt_stim = q dt, q integer; bkgd.py:303-340 interpolates the stimulus
+// linearly between frames, basis.py:238-273 filters it causally).  The interpolated projection y_n is piecewise
+// linear over q-bin frames, so the Rt-tap convolution of bin t = q F + o collapses to J = ceil(Rt / q) + 2 frame
+// values:
+//   I_stim[t,n] = sum_{j<J} sum_{bt} C[row(t)][j][bt] w_t[n,bt] z_n[base(F) + j],   z_n = (stim . basis_x) . w_x[n]
+//   base(F) = max(F - M, 0),  M = ceil(Rt / q),  row(t) = t for t < q M (the head, where bins t - tau < 0 are
+//   dropped),  q M + o from there on (periodic in the frame);  C is built once per stimulus on the host
+//   (build_frame_table): C[row][j][bt] = sum_tau basis_t[tau-1][bt] * (weight of frame base + j in y(t - tau)).
+// 15 multiply-adds per bin and neuron at the C5 stress shape instead of 300 taps; the frame index past the last
+// frame clamps (np.interp holds the last value).  Currents and residuals travel in the slab layout of the fused
+// kernels' accumulators: X[tile - tile0][post tile][r][lane], element (r, lane) = bin 16 tile + (lane >> 4) + 4 r of
+// neuron 16 pt + (lane & 15).
+//   forward   x[t,n]      = < C[row(t)], ZW_n >,  ZW_n[j][bt] = z_n[base + j] w_t[n,bt]      (k_sepf_fwd)
+//   backward  V_n[F][j][bt] = sum_o r[qF+o,n] C[row][j][bt];  d/dw_t[n,bt] = sum_F sum_j V z_n[base + j];
+//             H_n[F][j] = sum_bt V w_t[n,bt];  d/dz_n[f] = sum of the H[F][j] with base(F) + j = f   (k_sepf_bwd,
+//             k_sepf_finish);  d/dw_x = (stim . basis_x)^T d/dz  (k_gemm_mfma)
+// A wave owns one frame F and 64 neurons (4 post tiles): the table row is wave-uniform (scalar loads).
+// ---------------------------------------------------------------------------
+struct SepfParams {
+    const double* __restrict__ Ctab;     // [q (M + 1)][J][BT]
+    const double* __restrict__ YfT;      // [Tstim][ldy] frame-rate projections z_n (transposed; written by k_gemm_mfma)
+    const double* __restrict__ theta;    // (npost, P) rows [bias, w_t(Bt), w_x(Bx), w_imp]
+    double* __restrict__ X;              // slab: currents (forward, written) / residuals (backward, read)
+    double* __restrict__ Hb;             // [F1 - F0 + 1][J][ldy]
+    double* __restrict__ wpart;          // [F1 - F0 + 1][BT][ldy]
+    double* __restrict__ QvT;            // [Tstim][ldy]  d ll / d z_n[f]
+    double* __restrict__ grad;           // (npost, P): the w_t columns are written by k_sepf_finish
+    int P, Bt, M, q, npost, nPT, ldy, tile0, nTiles;
+    long long Tstim, F0, F1;             // frames that hold bins of the tile range
+};
+
+template <int J, int BT>
+__global__ __launch_bounds__(256) void k_sepf_fwd(const SepfParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+    const int pt = blockIdx.y * 4 + grp;
+    const int n = pt * 16 + col;
+    const bool vp = pt < p.nPT, vn = vp && n < p.npost;
+    const long long F = p.F0 + (long long)blockIdx.x * 4 + wave;
+    if (F > p.F1) return;
+    const long long base = (F > p.M) ? F - p.M : 0;
+    double zw[J][BT];
+    {
+        double w[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) w[bt] = (vn && bt < p.Bt) ? p.theta[(size_t)n * p.P + 1 + bt] : 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            long long f = base + j;
+            if (f > p.Tstim - 1) f = p.Tstim - 1;
+            const double z = vn ? p.YfT[(size_t)f * p.ldy + n] : 0.0;
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) zw[j][bt] = z * w[bt];
+        }
+    }
+    const long long tb = (long long)p.tile0 * 16, te = tb + (long long)p.nTiles * 16;
+    const long long t0 = F * p.q;
+    const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = (int)((te - t0 < p.q) ? te - t0 : p.q);
+    const double* __restrict__ crow = p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT);
+    double* const xl = p.X + (vp ? (size_t)pt * 256 + col : 0);
+    for (int o = o_lo; o < o_hi; ++o) {
+        const double* __restrict__ cr = crow + (size_t)o * (J * BT);
+        double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                if ((j * BT + bt) & 1)
+                    x1 = fma(cr[j * BT + bt], zw[j][bt], x1);
+                else
+                    x0 = fma(cr[j * BT + bt], zw[j][bt], x0);
+            }
+        const long long tl = t0 + o - tb;
+        if (vp) xl[(size_t)(tl >> 4) * p.nPT * 256 + (size_t)(((tl & 15) >> 2) * 64 + (tl & 3) * 16)] = x0 + x1;
+    }
+}
+
+template <int J, int BT>
+__global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+    const int pt = blockIdx.y * 4 + grp;
+    const int n = pt * 16 + col;
+    const bool vp = pt < p.nPT, vn = vp && n < p.npost;
+    const long long F = p.F0 + (long long)blockIdx.x * 4 + wave;
+    if (F > p.F1) return;
+    const long long base = (F > p.M) ? F - p.M : 0;
+    double V[J][BT];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) V[j][bt] = 0.0;
+    const long long tb = (long long)p.tile0 * 16, te = tb + (long long)p.nTiles * 16;
+    const long long t0 = F * p.q;
+    const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = (int)((te - t0 < p.q) ? te - t0 : p.q);
+    const double* __restrict__ crow = p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT);
+    const double* const xl = p.X + (vp ? (size_t)pt * 256 + col : 0);
+    for (int o = o_lo; o < o_hi; ++o) {
+        const double* __restrict__ cr = crow + (size_t)o * (J * BT);
+        const long long tl = t0 + o - tb;
+        const double r = vn ? xl[(size_t)(tl >> 4) * p.nPT * 256 + (size_t)(((tl & 15) >> 2) * 64 + (tl & 3) * 16)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) V[j][bt] = fma(r, cr[j * BT + bt], V[j][bt]);
+    }
+    if (!vp) return;
+    double w[BT], gw[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        w[bt] = (vn && bt < p.Bt) ? p.theta[(size_t)n * p.P + 1 + bt] : 0.0;
+        gw[bt] = 0.0;
+    }
+    const size_t fo = (size_t)(F - p.F0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        long long f = base + j;
+        if (f > p.Tstim - 1) f = p.Tstim - 1;
+        const double z = vn ? p.YfT[(size_t)f * p.ldy + n] : 0.0;
+        double h = 0.0;
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            h = fma(V[j][bt], w[bt], h);
+            gw[bt] = fma(V[j][bt], z, gw[bt]);
+        }
+        p.Hb[(fo * J + j) * p.ldy + n] = h;
+    }
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) p.wpart[(fo * BT + bt) * p.ldy + n] = gw[bt];
+}
+
+// blocks [0, nA): QvT[f][n] = sum of the H[F][j][n] with base(F) + j = f (frames past the last one fold into it),
+// 4 frames x 64 neurons per block;  blocks [nA, ...): d ll / d w_t[n][bt] = sum_F wpart[F][bt][n] in a fixed order,
+// one block per (64 neurons, bt)
+template <int J, int BT>
+__global__ __launch_bounds__(256) void k_sepf_finish(const SepfParams p, const int nA, const int nG)
+{
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long nF = p.F1 - p.F0 + 1;
+    if ((int)blockIdx.x < nA) {
+        const int g = blockIdx.x % nG;
+        const long long f = (long long)(blockIdx.x / nG) * 4 + wave;
+        const int n = g * 64 + lane;
+        if (f >= p.Tstim || n >= p.ldy) return;
+        auto gather = [&](const long long fv) -> double {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {                 // frames F >= M: base = F - M
+                const long long F = fv + p.M - j;
+                if (F >= p.M && F >= p.F0 && F <= p.F1) a += p.Hb[((size_t)(F - p.F0) * J + j) * p.ldy + n];
+            }
+            if (fv < J)                                   // head frames F < M: base = 0, j = fv
+                for (long long F = p.F0; F < p.M && F <= p.F1; ++F) a += p.Hb[((size_t)(F - p.F0) * J + fv) * p.ldy + n];
+            return a;
+        };
+        double acc = gather(f);
+        if (f == p.Tstim - 1) {
+            long long fmax = p.F1 + 1;
+            if (fmax < J - 1) fmax = J - 1;
+            for (long long fv = f + 1; fv <= fmax; ++fv) acc += gather(fv);
+        }
+        p.QvT[(size_t)f * p.ldy + n] = acc;
+    } else {
+        const int b = blockIdx.x - nA;
+        const int g = b % nG, bt = b / nG;
+        const int n = g * 64 + lane;
+        double a = 0.0;
+        if (n < p.ldy)
+            for (long long F = wave; F < nF; F += 4) a += p.wpart[((size_t)F * BT + bt) * p.ldy + n];
+        red[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && n < p.npost && bt < p.Bt)
+            p.grad[(size_t)n * p.P + 1 + bt] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    }
+}
+
+// C[m][n] = sum_k A[m sam + k sak] B[n sbn + k sbk] on the f64 MFMA, any strides (8-byte loads); stored at
+// C[m scm + n scn].  A workgroup = 4 waves splitting K four ways in chunks of 16 (lane group kk owns k = 16 u + 4 kk
+// + v), each on a 16 (m) x 16 NT (n) tile; the four partial tiles are added in a fixed order through LDS.
+// grid = (ceil(M / 16), ceil(N / (16 NT))).
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_mfma(const double* __restrict__ A, long long sam, long long sak,
+                                                   const double* __restrict__ Bm, long long sbn, long long sbk,
+                                                   double* __restrict__ C, long long scm, long long scn,
+                                                   int M, int Nn, int Kd)
+{
+    __shared__ double red[3][NT][4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NT;
+    const double* ap = A + (size_t)((m0 + i < M) ? m0 + i : M - 1) * sam;
+    const double* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bp[t] = Bm + (size_t)((n0 + 16 * t + i < Nn) ? n0 + 16 * t + i : Nn - 1) * sbn;
+    d4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int nU = (Kd + 15) / 16;
+    double a[4], b[NT][4];
+    auto fetch = [&](const int u) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = 16 * u + 4 * kk + v;
+            const bool ok = k < Kd;
+            const size_t kc = ok ? k : 0;
+            const double av = ap[kc * sak];
+            a[v] = ok ? av : 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double bv = bp[t][kc * sbk];
+                b[t][v] = ok ? bv : 0.0;
+            }
+        }
+    };
+    if (wave < nU) fetch(wave);
+    for (int u = wave; u < nU; u += 4) {
+        double ca[4], cb[NT][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            ca[v] = a[v];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cb[t][v] = b[t][v];
+        }
+        if (u + 4 < nU) fetch(u + 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[v], cb[t][v], acc[t], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = ((acc[t][r] + red[0][t][r][lane]) + red[1][t][r][lane]) + red[2][t][r][lane];
+                const int m = m0 + kk + 4 * r, n = n0 + 16 * t + i;      // D[kk + 4 r][i] (see the fused kernels' epilogue)
+                if (m < M && n < Nn) C[(size_t)m * scm + (size_t)n * scn] = v;
+            }
     }
 }
 
