@@ -143,6 +143,92 @@ def test_c5_stress_wide_stimulus_reduced_T():
     dev.close()
 
 
+def _stim_window_features(stim, dt_stim, dt, w0, w1, ibt):
+    """Dense stimulus features (bkgd.py:303-340, identity spatial basis) of the bins [w0, w1): interpolation on the
+    dt grid, causal convolution inside the window -- rows >= Rt of the result are exact when w0 > 0."""
+    t = dt * np.arange(w0, w1)
+    t_stim = dt_stim * np.arange(stim.shape[0])
+    s = np.stack([np.interp(t, t_stim, stim[:, d]) for d in range(stim.shape[1])], axis=1)
+    f = O.convolve_with_basis(s, ibt)                          # (n, Bx, Bt)
+    return np.transpose(f, axes=[0, 2, 1]).reshape(w1 - w0, -1)
+
+
+def test_c5_stress_full_size_separable():
+    """BASELINE config 5 as written ("stimulus-conv kernel stressed"; SURVEY 8(d) stress variant): spatiotemporal_glm
+    N = 64, T = 300 s, D_stim = 1024 pixels (identity spatial basis), Bt = 3, stimulus frames of 100 bins, at FULL size
+    on the separable device path (frame-rate stimulus kernels + impulse columns on resident tiles).  Properties on
+    the whole recording (ll-only == ll+grad, chunk and time-shard additivity, directional derivative, frame-rate ==
+    tap-rate kernels) and oracle parity (dense features, bkgd.py:214-227 chain rule) on the head AND the tail of the
+    same handle."""
+    from theano_pyglm_amd.models import templates
+    N, nT, D, Bt = 64, 300000, 1024, 3
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = D
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
+    popn = Population(make_model(tmpl, N=N, dt=0.001))
+    bk = popn.glm.bkgd_model
+    ibt = np.ascontiguousarray(bk.ibasis_t)
+    Rt = ibt.shape[0]
+    rng = np.random.RandomState(1234 + 5)
+    stim = rng.randn(nT // 100, D)
+    p = H.Problem(N, nT, popn.glm.imp_model.ibasis, kind='exp', seed=1234 + 5, Dstim=0, w_scale=0.02)
+    w_t, w_x = 0.3 * rng.randn(N, Bt), 0.05 * rng.randn(N, D)
+    th = np.concatenate((p.theta[:, :1], w_t, w_x, p.theta[:, 1:]), axis=1)
+    dev = p.device()
+    dev.set_stimulus_separable(stim, 0.1, ibt, None)
+    info = dev.info()
+    assert info['stim_path'] == 2 and info['kernel_version'] == 7 and info['ktiles'] == 12
+    ll, g = dev.ll_grad(th, p.Weff)
+    assert np.all(np.isfinite(ll)) and np.all(np.isfinite(g))
+    ll_only, _ = dev.ll_grad(th, p.Weff, want_grad=False)
+    assert np.array_equal(ll, ll_only)
+    dev.set_option(_lib.OPT_NCHUNKS, 61)
+    ll_c, g_c = dev.ll_grad(th, p.Weff)
+    dev.set_option(_lib.OPT_NCHUNKS, 0)
+    assert np.allclose(ll_c, ll, rtol=1e-12) and H.rel_err(g_c, g) < 1e-11
+    ll_s, g_s = 0.0, 0.0
+    for r in range(8):
+        lo, hi = PL.time_shard_bounds(nT, r, 8)
+        dev.set_time_range(lo, hi)
+        a, b = dev.ll_grad(th, p.Weff)
+        ll_s, g_s = ll_s + a, g_s + b
+    dev.set_time_range(0, nT)
+    assert np.allclose(ll_s, ll, rtol=1e-12) and H.rel_err(g_s, g) < 1e-11
+    drc = rng.randn(*th.shape)
+    drc[:, 1 + Bt:1 + Bt + D] *= 0.05
+    eps = 1e-6
+    lp, _ = dev.ll_grad(th + eps * drc, p.Weff, want_grad=False)
+    lm, _ = dev.ll_grad(th - eps * drc, p.Weff, want_grad=False)
+    an = np.sum(g * drc, axis=1)
+    assert np.max(np.abs((lp - lm) / (2 * eps) - an)) < 1e-5 * np.max(np.abs(an))
+    # the tap-rate kernels (300 taps per bin, 3-phase path) on the whole recording
+    dev.set_option(94, 2)
+    assert dev.info()['stim_path'] == 1
+    ll_t, g_t = dev.ll_grad(th, p.Weff)
+    dev.set_option(94, 0)
+    assert np.allclose(ll, ll_t, rtol=1e-11) and H.rel_err(g, g_t) < 1e-10
+    # oracle: head [0, 6000) and tail [nT - 6000, nT) of the same handle, dense features + chain rule
+    neurons = (0, 33, 63)
+    nsub = 6000
+    for t_a, t_b in ((0, nsub), (nT - nsub, nT)):
+        w0 = max(0, t_a - 2 * Rt)
+        fst = _stim_window_features(stim, 0.1, 0.001, w0, t_b, ibt)[t_a - w0:]
+        fS = O.convolve_with_basis_fft(p.S[w0:t_b].astype(float), p.ibasis)[t_a - w0:]
+        q = H.Problem(N, t_b - t_a, p.ibasis, kind='exp', seed=0, Dstim=0)
+        q.S, q.Weff, q._fS, q.fstim, q.Dstim, q.P = p.S[t_a:t_b], p.Weff, fS, fst, Bt * D, 1 + Bt * D + N * 3
+        q.theta = np.concatenate((th[:, :1], np.einsum('nt,nx->ntx', w_t, w_x).reshape(N, -1), th[:, 1 + Bt + D:]), axis=1)
+        dev.set_time_range(t_a, t_b)
+        a, b = dev.ll_grad(th, p.Weff)
+        for n in neurons:
+            a0, b0 = q.oracle_ll_grad(n, n + 1)
+            G = b0[0, 1:1 + Bt * D].reshape(Bt, D)
+            b_chain = np.concatenate((b0[0, :1], G.dot(w_x[n]), w_t[n].dot(G), b0[0, 1 + Bt * D:]))
+            assert np.allclose(a[n], a0[0], rtol=LL_RTOL), (t_a, n)
+            for sl in (slice(0, 1), slice(1, 1 + Bt), slice(1 + Bt, 1 + Bt + D), slice(1 + Bt + D, None)):
+                assert H.rel_err(b[n, sl], b_chain[sl]) < G_RTOL, (t_a, n, sl)
+    dev.close()
+
+
 def test_explinear_mixed_regimes_in_one_wave():
     """explinear epilogue with currents spanning [-30, 30] inside every wave (lanes of one MFMA tile
     are 16 different neurons): series lanes (|x| > 9.25) and full log1p lanes side by side, x

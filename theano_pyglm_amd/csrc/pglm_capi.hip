@@ -340,7 +340,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     }
     // version 7: no K split at all -- one wave per post tile carries the whole feature row (<= 20 k-tiles)
     // through forward, epilogue and backward; small workgroups, several per CU (k_fused7)
-    static const int kKT7[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};
+    static const int kKT7[] = {1, 2, 3, 5, 7, 10, 12, 13, 16, 20};
     pl.nw7 = 0;
     pl.wg7 = 1;
     // (measured, tools/small_shape_scan.py / config_table.py: 3-4 post tiles 46 TFLOP/s against 39 of the
@@ -632,6 +632,7 @@ static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStre
     case 5: return launch_fused7_t<5, NWV>(pl, fp, s);
     case 7: return launch_fused7_t<7, NWV>(pl, fp, s);
     case 10: return launch_fused7_t<10, NWV>(pl, fp, s);
+    case 12: return launch_fused7_t<12, NWV>(pl, fp, s);
     case 13: return launch_fused7_t<13, NWV>(pl, fp, s);
     case 16: return launch_fused7_t<16, NWV>(pl, fp, s);
     case 20: return launch_fused7_t<20, NWV>(pl, fp, s);
@@ -650,6 +651,7 @@ static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipSt
     case 5: return launch_fused7_t<5, 4, 1>(pl, fp, s);
     case 7: return launch_fused7_t<7, 4, 1>(pl, fp, s);
     case 10: return launch_fused7_t<10, 4, 1>(pl, fp, s);
+    case 12: return launch_fused7_t<12, 4, 1>(pl, fp, s);
     case 13: return launch_fused7_t<13, 4, 1>(pl, fp, s);
     case 16: return launch_fused7_t<16, 4, 1>(pl, fp, s);
     case 20: return launch_fused7_t<20, 4, 1>(pl, fp, s);
@@ -699,8 +701,8 @@ static void launch_sepf(int which, const SepfParams& sp, hipStream_t s)
     if (which == 0) hipLaunchKernelGGL((k_sepf_fwd<J, BT>), grid, dim3(256), 0, s, sp);
     else if (which == 1) hipLaunchKernelGGL((k_sepf_bwd<J, BT>), grid, dim3(256), 0, s, sp);
     else {
-        const int nA = (int)((sp.Tstim + 3) / 4) * nG;
-        hipLaunchKernelGGL((k_sepf_finish<J, BT>), dim3(nA + nG * BT), dim3(256), 0, s, sp, nA, nG);
+        const int nA = (int)((sp.Tstim + 15) / 16) * nG;
+        hipLaunchKernelGGL((k_sepf_finish<J, BT>), dim3(nA + nG * BT), dim3(1024), 0, s, sp, nA, nG);
     }
 }
 
@@ -1158,12 +1160,14 @@ static int sep_backward(pgl_handle h, const SepParams& sp, double* d_grad)
 static int launch_gemm_mfma(pgl_handle h, const double* A, long long sam, long long sak, const double* B,
                             long long sbn, long long sbk, double* C, long long scm, long long scn, int M, int N, int K)
 {
+    // operands whose m / n index is the contiguous one load whole 128-byte lines per 16-lane group; a k-contiguous
+    // operand costs a line per lane (pick A for it: one tile per wave against NT of B)
     const int mb = (M + 15) / 16;
-    if (mb >= 128) {       // many row tiles: 16 x 64 per wave; else one 16-column tile per workgroup (more workgroups)
-        hipLaunchKernelGGL(k_gemm_mfma<4>, dim3(mb, (N + 63) / 64), dim3(256), 0, h->stream, A, sam, sak, B, sbn, sbk,
+    if ((long long)mb * ((N + 63) / 64) >= 128) {       // 16 x 64 per wave; else 16 x 16 (more workgroups)
+        hipLaunchKernelGGL(k_gemm_mfma<4>, dim3(mb, (N + 63) / 64), dim3(512), 0, h->stream, A, sam, sak, B, sbn, sbk,
                            C, scm, scn, M, N, K);
     } else {
-        hipLaunchKernelGGL(k_gemm_mfma<1>, dim3(mb, (N + 15) / 16), dim3(256), 0, h->stream, A, sam, sak, B, sbn, sbk,
+        hipLaunchKernelGGL(k_gemm_mfma<1>, dim3(mb, (N + 15) / 16), dim3(512), 0, h->stream, A, sam, sak, B, sbn, sbk,
                            C, scm, scn, M, N, K);
     }
     HIPCHK(hipGetLastError());
@@ -1184,9 +1188,9 @@ static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, Sep
 {
     const int P = 1 + h->Dstim + h->Kimp, ldy = pl.nPT * 16;
     ENSURE(h->YfT, (size_t)h->sepT * ldy * 8);
-    // z_n[f] = (stim . basis_x)[f, :] . w_x[n]  ->  YfT[f][n]
-    int rc = launch_gemm_mfma(h, (const double*)h->zf.p, h->sepBx, 1, d_theta + 1 + h->sepBt, P, 1, (double*)h->YfT.p,
-                              ldy, 1, (int)h->sepT, pl.npost, h->sepBx);
+    // z_n[f] = (stim . basis_x)[f, :] . w_x[n]  ->  YfT[f][n]   (m = n, n = f, k = x)
+    int rc = launch_gemm_mfma(h, d_theta + 1 + h->sepBt, P, 1, (const double*)h->zfT.p, 1, h->sepT, (double*)h->YfT.p,
+                              1, ldy, pl.npost, (int)h->sepT, h->sepBx);
     if (rc) return rc;
     sp.Ctab = (const double*)h->sepC.p; sp.YfT = (const double*)h->YfT.p; sp.theta = d_theta;
     sp.X = (double*)h->Xbuf.p; sp.Hb = nullptr; sp.wpart = nullptr; sp.QvT = nullptr; sp.grad = nullptr;
@@ -1209,7 +1213,7 @@ static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad)
     if (!rc) rc = launch_sepf_any(h, 2, sp);
     if (rc) return rc;
     // d ll / d w_x[n][x] = sum_f (stim . basis_x)[f][x] QvT[f][n]
-    return launch_gemm_mfma(h, (const double*)h->zfT.p, h->sepT, 1, (const double*)h->QvT.p, 1, sp.ldy,
+    return launch_gemm_mfma(h, (const double*)h->zf.p, 1, h->sepBx, (const double*)h->QvT.p, 1, sp.ldy,
                             d_grad + 1 + h->sepBt, 1, sp.P, h->sepBx, sp.npost, (int)h->sepT);
 }
 

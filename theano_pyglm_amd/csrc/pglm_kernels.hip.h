@@ -4324,10 +4324,12 @@ __global__ __launch_bounds__(256) void k_sepf_fwd(const SepfParams p)
     const long long tb = (long long)p.tile0 * 16, te = tb + (long long)p.nTiles * 16;
     const long long t0 = F * p.q;
     const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = (int)((te - t0 < p.q) ? te - t0 : p.q);
-    const double* __restrict__ crow = p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT);
+    // the table row is wave-uniform: constant address space = scalar loads, the multiply-adds take it from SGPRs
+    const pgl_k_cdp crow = (pgl_k_cdp)(p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT));
     double* const xl = p.X + (vp ? (size_t)pt * 256 + col : 0);
+#pragma unroll 2
     for (int o = o_lo; o < o_hi; ++o) {
-        const double* __restrict__ cr = crow + (size_t)o * (J * BT);
+        const pgl_k_cdp cr = crow + (size_t)o * (J * BT);
         double x0 = 0.0, x1 = 0.0;
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -4363,10 +4365,11 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
     const long long tb = (long long)p.tile0 * 16, te = tb + (long long)p.nTiles * 16;
     const long long t0 = F * p.q;
     const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = (int)((te - t0 < p.q) ? te - t0 : p.q);
-    const double* __restrict__ crow = p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT);
+    const pgl_k_cdp crow = (pgl_k_cdp)(p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT));
     const double* const xl = p.X + (vp ? (size_t)pt * 256 + col : 0);
+#pragma unroll 4
     for (int o = o_lo; o < o_hi; ++o) {
-        const double* __restrict__ cr = crow + (size_t)o * (J * BT);
+        const pgl_k_cdp cr = crow + (size_t)o * (J * BT);
         const long long tl = t0 + o - tb;
         const double r = vn ? xl[(size_t)(tl >> 4) * p.nPT * 256 + (size_t)(((tl & 15) >> 2) * 64 + (tl & 3) * 16)] : 0.0;
 #pragma unroll
@@ -4400,17 +4403,17 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
 }
 
 // blocks [0, nA): QvT[f][n] = sum of the H[F][j][n] with base(F) + j = f (frames past the last one fold into it),
-// 4 frames x 64 neurons per block;  blocks [nA, ...): d ll / d w_t[n][bt] = sum_F wpart[F][bt][n] in a fixed order,
+// 16 frames x 64 neurons per block;  blocks [nA, ...): d ll / d w_t[n][bt] = sum_F wpart[F][bt][n] in a fixed order,
 // one block per (64 neurons, bt)
 template <int J, int BT>
-__global__ __launch_bounds__(256) void k_sepf_finish(const SepfParams p, const int nA, const int nG)
+__global__ __launch_bounds__(1024) void k_sepf_finish(const SepfParams p, const int nA, const int nG)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long nF = p.F1 - p.F0 + 1;
     if ((int)blockIdx.x < nA) {
         const int g = blockIdx.x % nG;
-        const long long f = (long long)(blockIdx.x / nG) * 4 + wave;
+        const long long f = (long long)(blockIdx.x / nG) * 16 + wave;
         const int n = g * 64 + lane;
         if (f >= p.Tstim || n >= p.ldy) return;
         auto gather = [&](const long long fv) -> double {
@@ -4435,27 +4438,41 @@ __global__ __launch_bounds__(256) void k_sepf_finish(const SepfParams p, const i
         const int b = blockIdx.x - nA;
         const int g = b % nG, bt = b / nG;
         const int n = g * 64 + lane;
-        double a = 0.0;
-        if (n < p.ldy)
-            for (long long F = wave; F < nF; F += 4) a += p.wpart[((size_t)F * BT + bt) * p.ldy + n];
-        red[wave][lane] = a;
+        // wave w sums the frames w, w + 16, ... (four independent chains: the loads of a chain are a latency each)
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (n < p.ldy) {
+            long long F = wave;
+            for (; F + 48 < nF; F += 64) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] += p.wpart[((size_t)(F + 16 * u) * BT + bt) * p.ldy + n];
+            }
+            for (int u = 0; F < nF; F += 16, ++u) a[u & 3] += p.wpart[((size_t)F * BT + bt) * p.ldy + n];
+        }
+        red[wave][lane] = (a[0] + a[1]) + (a[2] + a[3]);
         __syncthreads();
-        if (wave == 0 && n < p.npost && bt < p.Bt)
-            p.grad[(size_t)n * p.P + 1 + bt] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (wave == 0 && n < p.npost && bt < p.Bt) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) v += red[w][lane];
+            p.grad[(size_t)n * p.P + 1 + bt] = v;
+        }
     }
 }
 
 // C[m][n] = sum_k A[m sam + k sak] B[n sbn + k sbk] on the f64 MFMA, any strides (8-byte loads); stored at
-// C[m scm + n scn].  A workgroup = 4 waves splitting K four ways in chunks of 16 (lane group kk owns k = 16 u + 4 kk
-// + v), each on a 16 (m) x 16 NT (n) tile; the four partial tiles are added in a fixed order through LDS.
+// C[m scm + n scn].  A workgroup = 8 waves splitting K eight ways in chunks of 32 (lane group kk owns k = 32 u + 8 kk
+// + v), each on a 16 (m) x 16 NT (n) tile; the eight partial tiles are added in a fixed order through LDS.  The
+// operands of the next chunk are in flight during the MFMAs of the current one (the shapes here -- a few hundred
+// tiles, K in the thousands -- are bound by the latency of their load rounds, not by the MFMA rate).
 // grid = (ceil(M / 16), ceil(N / (16 NT))).
 template <int NT>
-__global__ __launch_bounds__(256) void k_gemm_mfma(const double* __restrict__ A, long long sam, long long sak,
+__global__ __launch_bounds__(512) void k_gemm_mfma(const double* __restrict__ A, long long sam, long long sak,
                                                    const double* __restrict__ Bm, long long sbn, long long sbk,
                                                    double* __restrict__ C, long long scm, long long scn,
                                                    int M, int Nn, int Kd)
 {
-    __shared__ double red[3][NT][4][64];
+    constexpr int NWG = 8, KC = 8;
+    __shared__ double red[NWG - 1][NT][4][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, kk = lane >> 4;
@@ -4467,12 +4484,12 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const double* __restrict__ A,
     d4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    const int nU = (Kd + 15) / 16;
-    double a[4], b[NT][4];
+    const int nU = (Kd + 4 * KC - 1) / (4 * KC);
+    double a[KC], b[NT][KC];
     auto fetch = [&](const int u) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int k = 16 * u + 4 * kk + v;
+        for (int v = 0; v < KC; ++v) {
+            const int k = 4 * KC * u + KC * kk + v;
             const bool ok = k < Kd;
             const size_t kc = ok ? k : 0;
             const double av = ap[kc * sak];
@@ -4485,17 +4502,17 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const double* __restrict__ A,
         }
     };
     if (wave < nU) fetch(wave);
-    for (int u = wave; u < nU; u += 4) {
-        double ca[4], cb[NT][4];
+    for (int u = wave; u < nU; u += NWG) {
+        double ca[KC], cb[NT][KC];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < KC; ++v) {
             ca[v] = a[v];
 #pragma unroll
             for (int t = 0; t < NT; ++t) cb[t][v] = b[t][v];
         }
-        if (u + 4 < nU) fetch(u + 4);
+        if (u + NWG < nU) fetch(u + NWG);
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < KC; ++v)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[v], cb[t][v], acc[t], 0, 0, 0);
     }
@@ -4511,7 +4528,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const double* __restrict__ A,
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double v = ((acc[t][r] + red[0][t][r][lane]) + red[1][t][r][lane]) + red[2][t][r][lane];
+                double v = acc[t][r];
+#pragma unroll
+                for (int w = 0; w < NWG - 1; ++w) v += red[w][t][r][lane];
                 const int m = m0 + kk + 4 * r, n = n0 + 16 * t + i;      // D[kk + 4 r][i] (see the fused kernels' epilogue)
                 if (m < M && n < Nn) C[(size_t)m * scm + (size_t)n * scn] = v;
             }
