@@ -11,6 +11,11 @@ configuration the north-star target is quoted on), synthetic Poisson spikes.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts the N ranks itself: the parent --
+before torch or HIP are touched -- builds the library, spawns N fresh `python bench.py ...` processes with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON record as the last line of stdout and exits
+non-zero if any rank did.
+
 N>1 (total work fixed -> "scaling": "strong"), two shardings of the same evaluation:
   --shard time (default): every rank evaluates all N neurons on its own range of time bins
       (the likelihood is additive over time segments, population.py:41-43; features reach R bins
@@ -131,6 +136,7 @@ def map_wall_clock(S, N, dt):
         x = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)      # default path (GPU lock-step optimizer)
         walls.append(time.perf_counter() - t0)
     lp1 = popn.compute_log_p(x)
+    stats = getattr(popn, 'last_fit_stats', None) or {}
     popn.release_data()
     return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": min(walls[1:]),
             "first_call_s": walls[0], "sweeps_s": walls,
@@ -143,8 +149,10 @@ def map_wall_clock(S, N, dt):
             "neurons_stalled": getattr(popn, 'last_fit_stats', {}).get('stalled'),
             "neurons_at_maxiter": getattr(popn, 'last_fit_stats', {}).get('maxiter'),
             "optimizer": "lock-step batched BFGS (per-neuron line-search state machines, one launch per pending trial of "
-                         "the listed neurons, active set read back two launches late: no host sync per launch), initial "
-                         "inverse-Hessian scaling s.y/y.y, maxiter 225, gtol 1e-5, GPU-resident state on one stream"}
+                         "the listed neurons; bookkeeping: %s, active set read back %s launch(es) late: no host sync per "
+                         "launch), initial inverse-Hessian scaling %s, maxiter 225, gtol 1e-5, GPU-resident state on one "
+                         "stream" % (stats.get('bookkeeping', 'n/a'), stats.get('lag', 'n/a'),
+                                     's.y/y.y' if stats.get('init_scaling') else 'none (identity)')}
 
 
 def mcmc_inner_ll(S, N, dt):
@@ -205,6 +213,84 @@ def mcmc_inner_ll(S, N, dt):
             "ars_launches_last_sweep": upd.n_ars_evals,
             "kernels": "k_gibbs_rate_cols (max(x,0) in f64 + log1p(exp(-|x|)) in f32 where |x| >= 12, compacted f64 band) + "
                        "k_gibbs_spike_cols"}
+
+
+def st_ibasis(key, R=300, dt=0.001):
+    """spatiotemporal_glm bases (B=3, unit area): the committed 100-point tables interpolated to R taps, / dt_max
+    (impulse.py:92-112 / bkgd.py:274-301 with norm)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'basis_golden.npz'))
+    basis = g[key]
+    L, B = basis.shape
+    ib = np.zeros((R, B))
+    for b in range(B):
+        ib[:, b] = np.interp(np.linspace(0, 1, R), np.linspace(0, 1, L), basis[:, b])
+    return ib / (R * dt)
+
+
+def stim_stress(reps=20):
+    """Secondary block for BASELINE config 5 ("stimulus-conv kernel stressed"): SURVEY 8(d)'s stress variant --
+    spatiotemporal_glm N=64, T=300 s, D_stim=1024 pixels, identity spatial basis, Bt=3, frames of 100 bins -- on the
+    separable device path (frame-rate stimulus kernels + impulse columns on resident tiles), ll+grad per evaluation,
+    with the tap-rate kernels of the same handle beside it."""
+    import torch
+    from theano_pyglm_amd import _lib
+    N, T, D, Bt, dt, dt_stim = 64, 300.0, 1024, 3, 0.001, 0.1
+    nT = int(round(T / dt))
+    rng = np.random.default_rng(1234 + 5)
+    S = np.minimum(rng.poisson(20.0 * dt, size=(nT, N)), 10).astype(np.uint8)
+    stim = rng.standard_normal((int(round(T / dt_stim)), D))
+    ib = st_ibasis('st_imp_basis')
+    ibt = np.ascontiguousarray(np.load(os.path.join(ROOT, 'tests', 'golden', 'basis_golden.npz'))['lr2d_ibasis_t'])
+    dev = _lib.DeviceGlm(N, nT, 3, 300, 'exp', dt, device=torch.cuda.current_device())
+    dev.set_spikes(S)
+    dev.set_basis(ib)
+    dev.set_stimulus_separable(stim, dt_stim, ibt, None)
+    P = dev.P
+    theta = np.zeros((N, P))
+    theta[:, 0] = 1.0 + 0.3 * rng.standard_normal(N)
+    theta[:, 1:1 + Bt] = 0.3 * rng.standard_normal((N, Bt))
+    theta[:, 1 + Bt:1 + Bt + D] = 0.05 * rng.standard_normal((N, D))
+    theta[:, 1 + Bt + D:] = 0.02 * rng.standard_normal((N, N * 3))
+    stream = torch.cuda.current_stream()
+    dev.set_stream(stream.cuda_stream)
+    d_theta = torch.from_numpy(theta).cuda()
+    d_Weff = torch.ones((N, N), dtype=torch.float64, device='cuda')
+    d_ll = torch.zeros(N, dtype=torch.float64, device='cuda')
+    d_grad = torch.zeros((N, P), dtype=torch.float64, device='cuda')
+
+    def timed(n):
+        dev.set_option(_lib.OPT_TIMING, 0)
+        for _ in range(3):
+            dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            dev.ll_grad_dev(d_theta.data_ptr(), d_Weff.data_ptr(), d_ll.data_ptr(), d_grad.data_ptr())
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    info = dev.info()
+    ms = timed(reps)
+    ll = d_ll.cpu().numpy().copy()
+    dev.set_option(94, 2)                        # the tap-rate kernels (300 taps per bin) on the 3-phase path
+    ms_tap = timed(5)
+    ll_tap = d_ll.cpu().numpy().copy()
+    dev.set_option(94, 0)
+    dev.set_option(_lib.OPT_TIMING, 1)
+    dev.close()
+    flops_imp = 4.0 * nT * (N * 3) * N
+    return {"metric": "ll+grad evaluation, spatiotemporal_glm stress variant", "variant": "D_stim=1024 (32x32 pixels), "
+            "identity spatial basis Bx=1024, Bt=3, dt_stim=0.1 s, N=64, T=300 s (nT=300000), exp nonlinearity",
+            "value": ms, "unit": "ms per ll+grad (queued back to back, whole evaluation)", "evals_per_s": 1e3 / ms,
+            "stim_path": int(info['stim_path']), "kernel_version": int(info['kernel_version']),
+            "path": "k_gemm_mfma (z = stim.w_x at the frame rate) + k_sepf_fwd + k_fused7<12,4,1> (impulse columns on "
+                    "resident tiles, slab in / residual out) + k_sepf_bwd + k_sepf_finish + k_gemm_mfma + k_finalize",
+            "tap_rate_kernels_ms": ms_tap,
+            "max_rel_ll_diff_vs_tap_rate": float(np.max(np.abs(ll - ll_tap) / np.abs(ll_tap))),
+            "impulse_contraction_flops": flops_imp,
+            "impulse_contraction_frac_of_f64_mfma_peak": flops_imp / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+            "dense_equivalent_bytes": float(nT) * Bt * D * 8,
+            "device_bytes_stimulus": 2.0 * stim.size * 8}
 
 
 def usable_cores():
@@ -283,6 +369,37 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, env
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's record.  Runs before torch / HIP are imported: the
+    parent never initialises a GPU, the children are plain Popen processes (no exec from a GPU process)."""
+    import socket
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build_hip()                                  # once, here: the ranks find the library fresh
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0] or ''
+    codes = [pr.wait() for pr in procs]
+    lines = [ln for ln in out0.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        sys.stderr.write(ln + '\n')                 # anything rank 0 printed before its record (library banners)
+    if lines:
+        print(lines[-1], flush=True)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        return 3 if 3 in bad else bad[0]
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -294,6 +411,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
     ap.add_argument('--no-mcmc', action='store_true', help='skip the secondary MCMC inner-ll measurement')
+    ap.add_argument('--no-stim', action='store_true', help='skip the secondary stimulus stress-variant measurement (config 5)')
     ap.add_argument('--no-ab', action='store_true',
                     help='skip the A/B loops after the timed region (in-kernel features, all-f64 epilogue): profiler '
                          'passes use it so that per-kernel averages and counters describe the headline kernel only')
@@ -305,6 +423,8 @@ def main():
                          '(ll, grad) block per step, per-rank gather) on ONE rank -- what a one-GPU box can execute of it')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.rccl_selftest:
+        sys.exit(self_launch(args.gpus))          # (nothing has touched torch or HIP in this process)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -462,6 +582,54 @@ def main():
                 "evaluation_ms": call_ms, "collective_ms": coll_ms, "bins": int(t_hi - t_lo), "neurons": int(n_hi - n_lo)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
+    shard_neurons = None
+    rccl_ranks = dist.get_world_size() if multi else 1
+    if multi and args.shard == 'time' and world > 1:
+        # the split north_star names, measured behind the timed region: post-synaptic neurons block-partitioned
+        # (parallel_coord_descent.py:137-147), every rank on the whole recording, all-gather of the ll shards per step
+        a, b = PL.shard_bounds(N, rank, world)
+        dev.set_time_range(0, nT)
+        dn_theta = torch.from_numpy(theta[a:b].copy()).cuda()
+        dn_ll = torch.zeros(b - a, dtype=torch.float64, device='cuda')
+        dn_grad = torch.zeros((b - a, P), dtype=torch.float64, device='cuda')
+        sizes = [hi - lo for lo, hi in PL.all_shard_bounds(N, world)]
+        gat = [torch.zeros(sz, dtype=torch.float64, device='cuda') for sz in sizes]
+
+        def nstep():
+            dev.ll_grad_dev(dn_theta.data_ptr(), d_Weff.data_ptr(), dn_ll.data_ptr(), dn_grad.data_ptr(), a, b)
+            if args.debug_single_device:
+                dev.sync()
+                hl = [g.cpu() for g in gat]
+                dist.all_gather(hl, dn_ll.cpu())
+                for g, hg in zip(gat, hl):
+                    g.copy_(hg)
+            else:
+                dist.all_gather(gat, dn_ll)
+        nsteps = max(1, min(args.steps, 20))
+        for _ in range(2):
+            nstep()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dev.timing_summary(reset=True)
+        tn0 = time.perf_counter()
+        for _ in range(nsteps):
+            nstep()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tn = time.perf_counter() - tn0
+        _, nk_ms, nc_ms = dev.timing_summary(reset=True)
+        tt = torch.tensor([tn], dtype=torch.float64, device='cpu' if args.debug_single_device else 'cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mine_n = {"rank": rank, "ms_per_step": 1e3 * tn / nsteps, "kernel_ms": nk_ms, "evaluation_ms": nc_ms,
+                  "neurons": int(b - a), "bins": int(nT), "kernel_version": int(dev.info(a, b)['kernel_version'])}
+        per_rank_n = [None] * world
+        dist.all_gather_object(per_rank_n, mine_n)
+        ll_gathered = np.concatenate([g.cpu().numpy() for g in gat])
+        shard_neurons = {"ms_per_step": 1e3 * float(tt.item()) / nsteps, "steps": nsteps,
+                         "evals_per_s": nsteps / float(tt.item()), "collective": "all-gather of the per-neuron ll (%d B)" % (8 * N),
+                         "per_rank": per_rank_n, "_ll": ll_gathered}
+        t_lo, t_hi = PL.time_shard_bounds(nT, rank, world)
+        dev.set_time_range(t_lo, t_hi)
     alt = None
     if not multi and not args.f32_features and info['kernel_version'] == 5 and not args.no_ab:
         # the same evaluation with the features regenerated from the spike events inside the kernel
@@ -516,6 +684,9 @@ def main():
             ll_ref, _ = dev.ll_grad(theta, Weff, 0, N, want_grad=False)
             assert np.allclose(ll_pop, ll_ref, rtol=1e-10, atol=0), \
                 "sharded population ll differs from the single-rank evaluation"
+            if shard_neurons is not None:
+                assert np.allclose(shard_neurons.pop('_ll'), ll_ref, rtol=1e-10, atol=0), \
+                    "neuron-sharded population ll differs from the single-rank evaluation"
 
     if rank == 0:
         out = {
@@ -574,6 +745,10 @@ def main():
             out["roofline"]["all_f64_epilogue"] = allf64
         if per_rank is not None:
             out["per_rank"] = per_rank
+            out["rccl_ranks"] = rccl_ranks
+            out["collective_backend"] = dist.get_backend()
+        if shard_neurons is not None:
+            out["sharding_neurons"] = shard_neurons
         if not multi and N == 128 and nT == 600000 and not args.f32_features:
             tr = pmc_traffic(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
             if tr is not None:
@@ -586,6 +761,8 @@ def main():
             out["secondary"] = map_wall_clock(S, N, dt)
         if not multi and not args.no_mcmc and not args.f32_features:
             out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
+        if not multi and not args.no_stim and not args.f32_features:
+            out["secondary_stim"] = stim_stress()
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         # RCCL prints a banner through C stdio: flush it first so that the JSON line is the last line of stdout

@@ -216,3 +216,31 @@ def test_bench_multi_rank_path_on_rccl_one_rank():
         assert rec['n_gpus'] == 1 and rec['steps'] == 4 and rec['value'] > 0
         assert rec['per_rank'] and rec['per_rank'][0]['collective_ms'] is not None
         assert 'roofline' in rec
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset) starts both ranks itself (here on the one GPU of the
+    box, gloo collectives): the record says n_gpus = 2, carries both shardings -- the time-sharded headline with its
+    all-reduce and the neuron-sharded step with its all-gather (north_star's split) -- and is the last line of stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict((k, v) for k, v in os.environ.items()
+               if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'))
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--debug-single-device', '--steps', '3', '--warmup', '1',
+                        '--seconds', '60', '--neurons', '64'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['steps'] == 3 and rec['value'] > 0
+    assert len(rec['per_rank']) == 2 and sorted(p['rank'] for p in rec['per_rank']) == [0, 1]
+    sn = rec['sharding_neurons']
+    assert sn['ms_per_step'] > 0 and len(sn['per_rank']) == 2
+    assert sorted(p['neurons'] for p in sn['per_rank']) == [32, 32]
+    assert all(p['bins'] == 60000 for p in sn['per_rank'])
+    # a rank that cannot get its GPU makes the whole run fail (exit code 3), before any rendezvous
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--seconds', '60',
+                        '--neurons', '64'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 3, (r.returncode, r.stderr[-2000:])

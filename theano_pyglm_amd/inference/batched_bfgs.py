@@ -345,7 +345,8 @@ def _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gto
     population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
                                  'neuron_evaluations': neuron_evals[0],
                                  'converged_gtol': n_conv, 'stalled': n_frozen,
-                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'hip row kernels'}
+                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'hip row kernels',
+                                 'lag': lag, 'init_scaling': False}
     return f.cpu().numpy(), it, n_evals[0]
 
 
@@ -529,5 +530,6 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
     population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
                                  'neuron_evaluations': neuron_evals[0],
                                  'converged_gtol': n_conv, 'stalled': n_frozen,
-                                 'maxiter': M - n_conv - n_frozen}
+                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'torch tensor ops',
+                                 'lag': lag, 'init_scaling': bool(init_scaling)}
     return f.cpu().numpy(), it, n_evals[0]
