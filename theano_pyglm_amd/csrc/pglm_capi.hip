@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -437,6 +438,8 @@ template <typename K>
 static hipError_t ensure_dyn_lds(K kern, size_t bytes)
 {
     static std::map<std::pair<const void*, int>, size_t> have;      // (kernel, device) -> size already granted
+    static std::mutex mu;                                           // ctypes drops the GIL: one handle per thread is legal
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& h = have[std::make_pair(reinterpret_cast<const void*>(kern), dev)];
@@ -601,12 +604,31 @@ static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream
 // workgroups per CU of the k_fused6 instantiation a plan selects (registers and LDS), cached per shape
 static int fused6_wg_per_cu(const Plan& pl)
 {
+    // occupancy is a property of the kernel and the architecture (every device of a node is the same gfx950 part)
     static int cache[2][11][5][3][9];          // [sb6][KTW][PTW][mt][nw6]; 0 = not asked yet
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int& c = cache[pl.sb6 ? 1 : 0][pl.KTW][pl.PTW][pl.mt][pl.nw6];
     if (c == 0) {
         int occ = 0;
         FusedParams fp{};
         if (launch_fused6(pl, fp, nullptr, &occ) != hipSuccess || occ < 1) occ = (pl.nw6 == 4) ? 2 : 1;
+        c = occ;
+    }
+    return c;
+}
+
+// workgroups of k_gibbs_rate_cols a CU holds at `lds` bytes of dynamic LDS (occupancy query, cached per size)
+static int gibbs_rate_wg_per_cu(size_t lds)
+{
+    static std::map<size_t, int> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int& c = cache[lds];
+    if (c == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_gibbs_rate_cols, 256, lds) != hipSuccess || occ < 1)
+            occ = 3;
         c = occ;
     }
     return c;
@@ -2108,11 +2130,25 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         const int ygroups = (ncols + gp.CP - 1) / gp.CP;
         const long long nrows = h->t_hi - h->t_lo;
         const long long nsub = (nrows + PGL_GRB - 1) / PGL_GRB;
-        // sub-blocks per workgroup: three workgroups fit a CU (LDS); the grid should fill a whole number of rounds of
-        // those slots -- e.g. 3 136 workgroups on 768 slots run 5 rounds for 4.08 rounds of work.  Among the loop
-        // lengths that still amortise the per-workgroup staging (>= PGL_GNL / 4) take the best-filled one.
+        // every column with the same presynaptic neuron (a sweep step): its filtered spike train once per launch
+        bool same_pre = ncols >= 2 && !(h->opt_dbg & 0x1000);
+        for (int c = 1; c < ncols && same_pre; ++c) same_pre = n_pre[c] == n_pre[0];
+        gp.hs_region = gp.CP * h->Rk;
+        if (same_pre) gp.hs_region = std::max(gp.hs_region, h->B * (PGL_GRB + 2) + gp.CP * 8);
+        const size_t lds = ((size_t)gp.hs_region + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
+                            (size_t)4 * PGL_GQ + (size_t)128 + (size_t)gp.CP) * 8 +     // (band queue, log1p table, max |w|)
+                           (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
+        auto rate_kernel = k_gibbs_rate_cols;
         {
-            const long long slots = 3LL * h->numCU;
+            hipError_t e = ensure_dyn_lds(rate_kernel, lds);
+            if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
+        }
+        // sub-blocks per workgroup: the grid should fill a whole number of rounds of the CU slots the kernel really gets
+        // (occupancy query: four workgroups per CU at <= 40 KB of LDS and 128 VGPRs, three above) -- e.g. 3 136
+        // workgroups on 768 slots run 5 rounds for 4.08 rounds of work.  Among the loop lengths that still amortise the
+        // per-workgroup staging (>= PGL_GNL / 4) take the best-filled one.
+        {
+            const long long slots = (long long)gibbs_rate_wg_per_cu(lds) * h->numCU;
             int best = 1;
             double best_fill = 0.0;
             for (int nl = (nsub * ygroups <= slots) ? 1 : PGL_GNL; nl >= 1; --nl) {     // (fewer units than slots: one each)
@@ -2137,23 +2173,11 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.partS = gp.part + (size_t)nblk * ncols * PGL_KMAX;
         gp.hs = (double*)h->ghs.p;
         gp.dbg = h->opt_dbg & 0xff;
-        // every column with the same presynaptic neuron (a sweep step): its filtered spike train once per launch
-        bool same_pre = ncols >= 2 && !(h->opt_dbg & 0x1000);
-        for (int c = 1; c < ncols && same_pre; ++c) same_pre = n_pre[c] == n_pre[0];
-        gp.hs_region = gp.CP * h->Rk;
         if (same_pre) {
             gp.fs_stride = (nrows + 63) / 64 * 64;
             ENSURE(h->gfs, (size_t)h->B * gp.fs_stride * 8);
             gp.fs = (const double*)h->gfs.p;
-            gp.hs_region = std::max(gp.hs_region, h->B * (PGL_GRB + 2) + gp.CP * 8);
         }
-        const size_t lds = ((size_t)gp.hs_region + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
-                            (size_t)4 * PGL_GQ + (size_t)128 + (size_t)gp.CP) * 8 +     // (band queue, log1p table, max |w|)
-                           (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
-        auto rate_kernel = k_gibbs_rate_cols;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rate_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
         hipLaunchKernelGGL(k_gibbs_cols_setup, dim3((ncols * h->Rk + 255) / 256), dim3(256), 0, h->stream, gp);
         HIPCHK(hipGetLastError());
         if (same_pre) {

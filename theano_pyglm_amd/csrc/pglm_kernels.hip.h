@@ -32,6 +32,13 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define PGL_PW 8             // Wmat fragment prefetch depth (MFMA steps) of the forward passes
 #endif
 #define PGL_MAXB 8
+// timing-ablation switches of the tile loops (dev option 99, tools/quick_bench.py, tools/gibbs_ablate.py): compiled in
+// only with -DPGL_ABLATE (tools/build_variant.sh); the shipped library has none of these branches
+#ifdef PGL_ABLATE
+#define PGL_DBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define PGL_DBG(bit) (false)
+#endif
 #ifndef PGL_PRIO
 #define PGL_PRIO 1           // k_fused5: waves 4-7 lead the first half of every MFMA loop (s_setprio)
 #ifndef PGL_EPI_PRIO
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         int pf_new = -1;                           // -1: nothing to do; > NPF: restage at commit time
 #pragma unroll
         for (int q = 0; q < NPF; ++q) pf[q] = make_int2(0, 0);
-        if (tid < N && tile + 1 < tile_end && !(p.dbg & 2)) {
+        if (tid < N && tile + 1 < tile_end && !PGL_DBG(2)) {
             const int hi = s_lo[cur + tid] + s_cnt[cur + tid];
             const int cnt_n = s_cnt[nxt + tid];
             pf_new = s_lo[nxt + tid] + cnt_n - hi;
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             }
         }
         int w2lo = 0, w2cnt = 0;
-        if (tid < N && tile + 2 < tile_end && !(p.dbg & 32)) {
+        if (tid < N && tile + 2 < tile_end && !PGL_DBG(32)) {
             w2lo = p.wlo[(size_t)(tile + 2) * p.Nall + p.np0 + tid];
             w2cnt = p.whi[(size_t)(tile + 2) * p.Nall + p.np0 + tid] - w2lo;
         }
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             }
         }
         // ---- F tile from the staged events ----
-        if (!(p.dbg & 1)) {
+        if (!PGL_DBG(1)) {
             const unsigned char* phiBytes = reinterpret_cast<const unsigned char*>(phiE);
             if (B == 5)
                 gen_items<5, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         // ---- forward over this wave's K slice ----
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
         d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-        if (active && !(p.dbg & 8) && p.mode != 2) {
+        if (active && !PGL_DBG(8) && p.mode != 2) {
             const FT* fa = Fs + col * rsf + kcol0 + grp;
             const double* wr_s = wrow;
             asm volatile("" : "+s"(wr_s));
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 vte[e] = valid_n && (tg < p.t_hi) && emine;
                 xe[e] = x;
             }
-            if (p.dbg & 4) {
+            if PGL_DBG(4) {
 #pragma unroll
                 for (int e = 0; e < EPW; ++e) {
                     terme[e] = xe[e] * sc[e];
@@ -1046,7 +1053,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         __syncthreads();
 
         // ---- backward on this wave's K slice ----
-        if (active && p.want_grad && !(p.dbg & 16) && p.mode != 1) {
+        if (active && p.want_grad && !PGL_DBG(16) && p.mode != 1) {
             double rr[4];
             if (p.mode == 2) {              // residuals of the sliced path come from Xbuf
 #pragma unroll
@@ -1252,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
                 Fs[t * rsf + p.Kimp + j] = (tg < p.nT) ? p.fstim[tg * p.DsAll + p.ds0 + j] : 0.0;
             }
         }
-        if (!(p.dbg & 1)) {
+        if (!PGL_DBG(1)) {
             if (B == 5)
                 gen_items<5, CAP, FT>(Fs, rsf, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
                                       p.Kimp, tid, nthr, (t0 - t0_ref) * ESZ);
@@ -1276,7 +1283,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
         // ---- forward over all of K ----
         d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
         d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-        if (active && !(p.dbg & 8)) {
+        if (active && !PGL_DBG(8)) {
             const FT* fa = Fs + col * rsf + grp;
             const double* wr_s = wrow;
             asm volatile("" : "+s"(wr_s));
@@ -1341,7 +1348,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
                     const long long tg = (long long)t0 + grp + 4 * r;
                     vte[e] = valid_n && (tg < p.t_hi);
                 }
-                if (p.dbg & 4) {
+                if PGL_DBG(4) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         terme[e] = xe[e] * se[e];
@@ -1365,9 +1372,9 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
             for (int r = 0; r < 4; ++r) rr[r] = 0.0;
         }
         // ---- residuals to HBM for pass 2, backward for the first half of the columns ----
-        if (active && p.want_grad && !(p.dbg & 16)) {
+        if (active && p.want_grad && !PGL_DBG(16)) {
             double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
-            if (!(p.dbg & 512)) {
+            if (!PGL_DBG(512)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
             }
@@ -1422,7 +1429,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
                 Fdst[t * rsfh + p.Kimp - C0 + j] = (tg < p.nT) ? p.fstim[tg * p.DsAll + p.ds0 + j] : 0.0;
             }
         }
-        if (p.Kimp > C0 && !(p.dbg & 1)) {
+        if (p.Kimp > C0 && !PGL_DBG(1)) {
             FT* Fv = Fdst - C0;                    // column c of the full layout lands at c - C0
             if (B == 5)
                 gen_items<5, CAP, FT>(Fv, rsfh, phiBytes, RP, s_spk, s_lo + cur, s_cnt + cur, p.spk, t0, B,
@@ -1521,12 +1528,12 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
         // while its SIMD neighbour still generates).  Forcing that overlap -- waves 0-3 generate
         // first, 4-7 multiply first -- measured 5 % slower: one MFMA wave per SIMD does not fill
         // the pipe.
-        if (active && !(p.dbg & 512)) {
+        if (active && !PGL_DBG(512)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) rv[r] = rslab[(size_t)(tile - p.tile0) * rstride + r * 64];
         }
         if (more) gen_half(Fnext, tile + 1, ((tile + 1) & 1) * N);
-        if (active && !(p.dbg & 16)) bwd_half(Fcur, rv);
+        if (active && !PGL_DBG(16)) bwd_half(Fcur, rv);
         __syncthreads();
     }
 
@@ -1832,7 +1839,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
             constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
-            if (active && !(p.dbg & 8)) {
+            if (active && !PGL_DBG(8)) {
                 const double* faL = reinterpret_cast<const double*>(Lb) + pgl_img_row(col) * RSL + grp;
                 const double* faH = reinterpret_cast<const double*>(buf1) + pgl_img_row(col) * RSH + grp;
                 const double* wr_s = wrow;
@@ -1880,7 +1887,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 }
             }
             PGL_PROF_MARK(0);
-            const bool do_bwd = active && p.want_grad && !(p.dbg & 16);
+            const bool do_bwd = active && p.want_grad && !PGL_DBG(16);
             // every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The barrier also lines
             // the waves up for the epilogue.
             __syncthreads();
@@ -1889,7 +1896,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             double rr[4];
             if (active) {
                 bool done = false;
-                if (PGL_ENE == 4 && !(p.dbg & 4) && (long long)t0 + TT <= p.t_hi) {
+                if (PGL_ENE == 4 && !PGL_DBG(4) && (long long)t0 + TT <= p.t_hi) {
                     // whole tile inside the evaluated range: four elements at a time, fixed order
                     double xs[4], term4 = 0.0;
 #pragma unroll
@@ -1917,7 +1924,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                             const long long tg = (long long)t0 + grp + 4 * r;
                             vte[e] = valid_n && (tg < p.t_hi);
                         }
-                        if (p.dbg & 4) {
+                        if PGL_DBG(4) {
 #pragma unroll
                             for (int e = 0; e < ENE; ++e) {
                                 terme[e] = xe[e] * se[e];
@@ -1999,7 +2006,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             __syncthreads();                              // ... for every wave; H_{i-1}'s buffer is free
             PGL_PROF_MARK(1);
             const bool more = tile + 1 < tile_end;
-            const bool do_bwd = active && !(p.dbg & 16);
+            const bool do_bwd = active && !PGL_DBG(16);
             if (more) {
                 if (!do_bwd) pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, Hn, wave, lane);
                 if (active) {
@@ -2282,7 +2289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
             // the spike terms compacted (log lam and 1/lam once per step for the ~2 % of elements with a spike instead
             // of for every element of every wave that holds one: ~90 f64 instructions per tile and wave at C2)
             bool done = false;
-            if (KSPLIT <= 4 && tile + MT <= tile_end && (long long)(tile + MT) * TT <= p.t_hi && !(p.dbg & 4)) {
+            if (KSPLIT <= 4 && tile + MT <= tile_end && (long long)(tile + MT) * TT <= p.t_hi && !PGL_DBG(4)) {
                 const double* cg = PGL_C;
                 asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
                 double termx = 0.0;
@@ -3611,14 +3618,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto eval_item = [&](const int item, const int sb, const long long tb0, const int nb, double& accv) {
         const int c = item / NSPLIT, sp = item % NSPLIT;
         const int cc = blockIdx.y * CP + c;
-        if (cc >= p.ncols || (p.dbg & 2)) return;
+        if (cc >= p.ncols || PGL_DBG(2)) return;
         const int tseg = sp * nseg * 64 + lane;                     // bin of segment 0 inside the sub-block
         // pair current of the lane's bins: every event of the column's window adds count * h[t - s - 1]
         double icr[NSEG];
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) icr[sg] = 0.0;
         if (FSM) {
-            if (!(p.dbg & 1)) {
+            if (!PGL_DBG(1)) {
                 for (int b = 0; b < p.B; ++b) {
                     const double bt = BT[c * 8 + b];                // wave-uniform
 #pragma unroll
@@ -3633,7 +3640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool staged = cnt <= PGL_GECAP;
             const double* hs = HS + c * R;
             const int tr = (int)tb0 + tseg - 1;                     // d = tr + 64*sg - e.x
-            if (!(p.dbg & 1)) {
+            if (!PGL_DBG(1)) {
                 for (int q = 0; q < cnt; ++q) {
                     const int2 e = staged ? evS[c * PGL_GECAP + q] : p.spk[lo + q];
                     const double ecnt = (double)e.y;
@@ -3693,7 +3700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float af = fabsf((float)x[sg]);
                 const bool f = (af >= PGL_GFAST) && !careful;
                 bl[sg] = !f;
-                const float ee = (p.dbg & 32) ? af : __builtin_amdgcn_exp2f(af * -1.44269504088896340736f);
+                const float ee = PGL_DBG(32) ? af : __builtin_amdgcn_exp2f(af * -1.44269504088896340736f);
                 e[sg] = f ? ee : 0.0f;
             }
             double accl = 0.0;
@@ -3709,7 +3716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             bool anyb = false;
 #pragma unroll
             for (int sg = 0; sg < NSEG; ++sg) anyb = anyb || bl[sg];
-            if (__ballot(anyb) != 0ull && !(p.dbg & 16)) {
+            if (__ballot(anyb) != 0ull && !PGL_DBG(16)) {
                 int qn = 0;
                 double accq = 0.0;
 #pragma unroll
@@ -3741,7 +3748,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_wave_barrier();
                 accl += accq;
             }
-            if (p.dbg & 64) accv += accl + (double)fmaf(acc2, -0.5f, acc1); else push(accl + (double)fmaf(acc2, -0.5f, acc1), k);
+            if PGL_DBG(64) accv += accl + (double)fmaf(acc2, -0.5f, acc1); else push(accl + (double)fmaf(acc2, -0.5f, acc1), k);
         }
         for (int k = K; k < PGL_KMAX; ++k) push(0.0, k);            // flush the pending levels
     };
@@ -3759,13 +3766,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (FSM) {
             for (int i = tid; i < p.B * RB; i += 256) {
                 const int b = i / RB, tt = i - b * RB;
-                FS[b * XS + tt] = (tt < nb && !(p.dbg & 4)) ? p.fs[(size_t)b * p.fs_stride + (tb0 - p.t_lo) + tt] : 0.0;
+                FS[b * XS + tt] = (tt < nb && !PGL_DBG(4)) ? p.fs[(size_t)b * p.fs_stride + (tb0 - p.t_lo) + tt] : 0.0;
             }
         } else {
             for (int i = tid; i < CP * PGL_GECAP; i += 256) {
                 const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
                 const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
-                if (cnt <= PGL_GECAP && j < cnt && !(p.dbg & 4)) evS[i] = p.spk[lo + j];
+                if (cnt <= PGL_GECAP && j < cnt && !PGL_DBG(4)) evS[i] = p.spk[lo + j];
             }
         }
         if (ra < RPB) {
@@ -3773,7 +3780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < NJ; ++j) {
                 const int tt = ra + j * RPB;
                 if (tt < RB)
-                    X0[ca * XS + tt] = (a_valid && tt < nb && !(p.dbg & 8)) ? biasa + p.GX[(tb0 + tt) * p.xs + na] : 0.0;
+                    X0[ca * XS + tt] = (a_valid && tt < nb && !PGL_DBG(8)) ? biasa + p.GX[(tb0 + tt) * p.xs + na] : 0.0;
             }
         }
         __syncthreads();

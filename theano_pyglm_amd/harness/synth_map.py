@@ -55,6 +55,7 @@ def main():
     ap.add_argument('-d', '--dataFile', required=True)
     ap.add_argument('-r', '--resultsDir', default='.')
     ap.add_argument('--sequential', action='store_true', help='per-neuron scipy fits (the reference loop)')
+    ap.add_argument('--batched', action='store_true', help='(deprecated, no-op: the GPU lock-step sweep is the default)')
     args = ap.parse_args()
     with open(args.dataFile, 'rb') as f:
         data = pickle.load(f)

@@ -60,7 +60,7 @@ def get_xv_models(model, grid=None):
     return models
 
 
-def run_xv(popn, data, models, train_frac=0.75, batched='torch', rng=None, verbose=True):
+def run_xv(popn, data, models, train_frac=0.75, batched=None, rng=None, verbose=True):
     """test/synth_map_with_xv.py:23-90.  Returns (best_x, best_ind, train_lps, xv_lls, total_lls)."""
     T_split = data['T'] * train_frac
     train_data = popn.preprocess_data(segment_data(data, (0, T_split)))

@@ -239,6 +239,12 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
                                  row_kernels)
             stream.synchronize()
     finally:
+        # also on the error path: kernels still queued on `stream` read the optimizer state and the handles' scratch;
+        # let them finish before the caching allocator reuses the tensors and the handles go back to their own streams
+        try:
+            stream.synchronize()
+        except Exception:
+            pass
         for h in handles:
             h.set_stream(None)
     return out

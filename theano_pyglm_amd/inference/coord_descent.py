@@ -215,7 +215,18 @@ def resolve_batched(population, batched):
     False / True / 'torch' force the sequential / numpy lock-step / GPU lock-step sweep."""
     if batched is None:
         from theano_pyglm_amd.inference.batched_bfgs import supported
-        return 'torch' if supported(population) else False
+        if not supported(population):
+            return False
+        # the GPU optimizer needs torch with a visible device and a library that exports the row kernels; without them
+        # the default stays what it always was, the sequential sweep (which raises PglError itself if there is no GPU)
+        try:
+            import torch
+            from theano_pyglm_amd import _lib
+            if not torch.cuda.is_available() or not hasattr(_lib.load(), 'pgl_bfgs_update_dev'):
+                return False
+        except Exception:
+            return False
+        return 'torch'
     return batched
 
 
