@@ -1,5 +1,5 @@
 """One BASELINE configuration evaluated a few times (for rocprofv3 / PMC passes; dev tool).
-    python tools/cfg_loop.py C1|C2|C3|C5 [reps]"""
+    python tools/cfg_loop.py C1|C2|C3|C5|C5S [reps]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
@@ -9,9 +9,17 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N, T, ib, kind, Ds, ws = {'C1': (4, 60.0, H.std_ibasis(), 'explinear', 0, 0.5),
                           'C2': (32, 300.0, H.std_ibasis(), 'explinear', 0, 0.5),
                           'C3': (128, 600.0, H.std_ibasis(), 'explinear', 0, 0.5),
-                          'C5': (64, 300.0, H.st_ibasis(), 'exp', 9, 0.02)}[cfg]
+                          'C5': (64, 300.0, H.st_ibasis(), 'exp', 9, 0.02),
+                          'C5S': (64, 300.0, H.st_ibasis(), 'exp', 0, 0.02)}[cfg]
 p = H.Problem(N, int(round(T / 0.001)), ib, kind=kind, Dstim=Ds, seed=1234, w_scale=ws)
 dev = p.device()
+theta = p.theta
+if cfg == 'C5S':          # stress variant: D_stim = 1024 pixels, identity spatial basis, Bt = 3, separable device path
+    rng = np.random.default_rng(1234 + 5)
+    stim = rng.standard_normal((int(round(T / 0.1)), 1024))
+    dev.set_stimulus_separable(stim, 0.1, np.ascontiguousarray(H.golden()['lr2d_ibasis_t']), None)
+    theta = np.concatenate((p.theta[:, :1], 0.3 * rng.standard_normal((N, 3)), 0.05 * rng.standard_normal((N, 1024)),
+                            p.theta[:, 1:]), axis=1)
 for i in range(reps):
-    ll, g = dev.ll_grad(p.theta, p.Weff)
+    ll, g = dev.ll_grad(theta, p.Weff)
 print(cfg, dev.info()['kernel_version'], "fused %.3f ms total %.3f ms" % dev.last_timing())

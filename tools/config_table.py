@@ -13,7 +13,7 @@ import os
 ONLY = [t for t in os.environ.get('CFG_ONLY', '').split(',') if t]    # e.g. CFG_ONLY="C2 standard_glm,C5 spatio"
 
 
-def run(name, N, T, ibasis, kind, Dstim=0, kernel=0, n_hi=None):
+def run(name, N, T, ibasis, kind, Dstim=0, kernel=0, n_hi=None, sep_D=0, tap_rate=False):
     if ONLY and not any(name.startswith(t) for t in ONLY):
         return
     nT = int(round(T / 0.001))
@@ -22,6 +22,14 @@ def run(name, N, T, ibasis, kind, Dstim=0, kernel=0, n_hi=None):
     if kernel:
         dev.set_option(_lib.OPT_KERNEL, kernel)
     n_hi = N if n_hi is None else n_hi
+    if sep_D:             # separable stimulus (stress variant of C5): theta rows [bias, w_t(3), w_x(D), w_ir]
+        rng = np.random.default_rng(1234 + 5)
+        stim = rng.standard_normal((int(round(T / 0.1)), sep_D))
+        dev.set_stimulus_separable(stim, 0.1, np.ascontiguousarray(H.golden()['lr2d_ibasis_t']), None)
+        if tap_rate:
+            dev.set_option(94, 2)
+        p.theta = np.concatenate((p.theta[:, :1], 0.3 * rng.standard_normal((N, 3)), 0.05 * rng.standard_normal((N, sep_D)),
+                                  p.theta[:, 1:]), axis=1)
     th = p.theta[:n_hi]
     for i in range(6):
         ll, g = dev.ll_grad(th, p.Weff, 0, n_hi)
@@ -47,6 +55,8 @@ run("C3 standard_glm", 128, 600.0, H.std_ibasis(), 'explinear')
 run("C5 spatiotemporal (D_stim=3)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9)
 run("C5 (resident K-split)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9, kernel=6)
 run("C5 (in-kernel features)", 64, 300.0, H.st_ibasis(), 'exp', Dstim=9, kernel=2)
+run("C5 stress (D_stim=1024, separable, frame-rate kernels)", 64, 300.0, H.st_ibasis(), 'exp', sep_D=1024)
+run("C5 stress (D_stim=1024, separable, tap-rate kernels)", 64, 300.0, H.st_ibasis(), 'exp', sep_D=1024, tap_rate=True)
 for nh in (64, 32, 16):
     run("C3 neuron shard", 128, 600.0, H.std_ibasis(), 'explinear', n_hi=nh)
 run("C3 neuron shard 64 (two-pass resident)", 128, 600.0, H.std_ibasis(), 'explinear', kernel=4, n_hi=64)
