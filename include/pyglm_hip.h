@@ -122,7 +122,13 @@ int pgl_get_stim_features(pgl_handle h, double* fstim_out);
  * -- one GEMM at the stimulus frame rate plus a 1-D convolution per neuron; gradients by the transposed
  * operations.  After this call a theta row is [bias, w_t(Bt), w_x(Bx), w_imp(N*B)] (the reference's own
  * packing order of 'bkgd': 'w_t' < 'w_x', packvec.py:22) with P = 1 + Bt + Bx + N*B, and gradients come
- * back in that layout (no host chain rule).  basis_x (D,Bx) row-major or NULL = identity. */
+ * back in that layout (no host chain rule).  basis_x (D,Bx) row-major or NULL = identity.
+ * When dt_stim is an integer multiple q of dt, ceil(Rt / q) + 2 <= 8 and Bt <= 4 (the reference's frames of 100
+ * bins with Rt = 300 qualify) the evaluation runs at the FRAME rate: the interpolated projection is piecewise
+ * linear over q-bin frames, so the Rt taps of a bin collapse to <= 8 frame values through a coefficient table
+ * built here (k_sepf_fwd / k_sepf_bwd), and the impulse columns run on resident feature tiles; other ratios,
+ * calls over more than 64 neurons and neuron lists keep the tap-rate kernels (same results to 1e-12;
+ * pgl_info[12] tells which). */
 int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
                                const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt);
 
@@ -281,7 +287,10 @@ int pgl_set_stream(pgl_handle h, void* stream);
  * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins), [9]=kernel the call would use
  * (1 4-wave, 2 K-split, 3 K-split with f32 features, 4 two-pass, 5 two-pass on resident feature
  * tiles, 6 K-split on resident feature tiles, 7 single pass without K split on resident tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
- * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab). */
+ * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab), [12]=stimulus path of the
+ * call: 0 none / dense feature columns, 1 separable by the tap-rate kernels, 2 separable at the frame rate.
+ * (For a separable stimulus [6] counts the impulse contraction only and [7] the projected stimulus at its frame
+ * rate.) */
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info);
 
 #ifdef __cplusplus

@@ -185,7 +185,7 @@ static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
 static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel (on the fly)
 // resident-tile kernel: (L, H) k-tile pairs; pass 1 (forward + L columns of G) gets the smaller share
 #ifndef PGL_SPLIT_L
-#define PGL_SPLIT_L 18       // L / H k-tiles of the 40-k-tile (K = 640) split; measured: 18/22
+#define PGL_SPLIT_L 18       // L / H k-tiles of the 40-k-tile (K = 640) split; measured: 18/22 (see docs/NOTEBOOK.md §4.1)
 #endif
 static const int kKTP[][2] = {{1, 1}, {2, 2}, {3, 3}, {5, 5}, {7, 7}, {9, 11}, {12, 14}, {14, 18},
                               {PGL_SPLIT_L, 40 - PGL_SPLIT_L}};

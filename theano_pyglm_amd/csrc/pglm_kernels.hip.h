@@ -4295,7 +4295,7 @@ struct SepfParams {
     const double* __restrict__ theta;    // (npost, P) rows [bias, w_t(Bt), w_x(Bx), w_imp]
     double* __restrict__ X;              // slab: currents (forward, written) / residuals (backward, read)
     double* __restrict__ Hb;             // [F1 - F0 + 1][J][ldy]
-    double* __restrict__ wpart;          // [F1 - F0 + 1][BT][ldy]
+    double* __restrict__ wpart;          // [workgroups of k_sepf_bwd = ceil(frames / 4)][BT][ldy]
     double* __restrict__ QvT;            // [Tstim][ldy]  d ll / d z_n[f]
     double* __restrict__ grad;           // (npost, P): the w_t columns are written by k_sepf_finish
     int P, Bt, M, q, npost, nPT, ldy, tile0, nTiles;
@@ -4361,8 +4361,9 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
     const int pt = blockIdx.y * 4 + grp;
     const int n = pt * 16 + col;
     const bool vp = pt < p.nPT, vn = vp && n < p.npost;
+    __shared__ double gws[4][BT][64];
     const long long F = p.F0 + (long long)blockIdx.x * 4 + wave;
-    if (F > p.F1) return;
+    const bool vF = F <= p.F1;               // (no early return: the workgroup meets at a barrier below)
     const long long base = (F > p.M) ? F - p.M : 0;
     double V[J][BT];
 #pragma unroll
@@ -4371,7 +4372,7 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
         for (int bt = 0; bt < BT; ++bt) V[j][bt] = 0.0;
     const long long tb = (long long)p.tile0 * 16, te = tb + (long long)p.nTiles * 16;
     const long long t0 = F * p.q;
-    const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = (int)((te - t0 < p.q) ? te - t0 : p.q);
+    const int o_lo = (int)((tb > t0) ? tb - t0 : 0), o_hi = vF ? (int)((te - t0 < p.q) ? te - t0 : p.q) : 0;
     const pgl_k_cdp crow = (pgl_k_cdp)(p.Ctab + (size_t)(((F < p.M) ? F : p.M) * p.q) * (J * BT));
     const double* const xl = p.X + (vp ? (size_t)pt * 256 + col : 0);
 #pragma unroll 4
@@ -4384,7 +4385,6 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) V[j][bt] = fma(r, cr[j * BT + bt], V[j][bt]);
     }
-    if (!vp) return;
     double w[BT], gw[BT];
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) {
@@ -4396,17 +4396,25 @@ __global__ __launch_bounds__(256) void k_sepf_bwd(const SepfParams p)
     for (int j = 0; j < J; ++j) {
         long long f = base + j;
         if (f > p.Tstim - 1) f = p.Tstim - 1;
-        const double z = vn ? p.YfT[(size_t)f * p.ldy + n] : 0.0;
+        const double z = (vn && vF) ? p.YfT[(size_t)f * p.ldy + n] : 0.0;
         double h = 0.0;
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) {
             h = fma(V[j][bt], w[bt], h);
             gw[bt] = fma(V[j][bt], z, gw[bt]);
         }
-        p.Hb[(fo * J + j) * p.ldy + n] = h;
+        if (vp && vF) p.Hb[(fo * J + j) * p.ldy + n] = h;
     }
+    // d / d w_t: the four frames of the workgroup in a fixed order -> one partial per workgroup
 #pragma unroll
-    for (int bt = 0; bt < BT; ++bt) p.wpart[(fo * BT + bt) * p.ldy + n] = gw[bt];
+    for (int bt = 0; bt < BT; ++bt) gws[wave][bt][lane] = gw[bt];
+    __syncthreads();
+    if (wave == 0 && vp) {
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt)
+            p.wpart[((size_t)blockIdx.x * BT + bt) * p.ldy + n] =
+                ((gws[0][bt][lane] + gws[1][bt][lane]) + gws[2][bt][lane]) + gws[3][bt][lane];
+    }
 }
 
 // blocks [0, nA): QvT[f][n] = sum of the H[F][j][n] with base(F) + j = f (frames past the last one fold into it),
@@ -4445,17 +4453,19 @@ __global__ __launch_bounds__(1024) void k_sepf_finish(const SepfParams p, const 
         const int b = blockIdx.x - nA;
         const int g = b % nG, bt = b / nG;
         const int n = g * 64 + lane;
-        // wave w sums the frames w, w + 16, ... (four independent chains: the loads of a chain are a latency each)
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        // wave w sums the workgroup partials w, w + 16, ... of k_sepf_bwd (eight independent chains: the loads of a
+        // chain are a latency each)
+        const long long nW = (nF + 3) / 4;
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (n < p.ldy) {
             long long F = wave;
-            for (; F + 48 < nF; F += 64) {
+            for (; F + 16 * 7 < nW; F += 16 * 8) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] += p.wpart[((size_t)(F + 16 * u) * BT + bt) * p.ldy + n];
+                for (int u = 0; u < 8; ++u) a[u] += p.wpart[((size_t)(F + 16 * u) * BT + bt) * p.ldy + n];
             }
-            for (int u = 0; F < nF; F += 16, ++u) a[u & 3] += p.wpart[((size_t)F * BT + bt) * p.ldy + n];
+            for (int u = 0; F < nW; F += 16, ++u) a[u & 7] += p.wpart[((size_t)F * BT + bt) * p.ldy + n];
         }
-        red[wave][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+        red[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         __syncthreads();
         if (wave == 0 && n < p.npost && bt < p.Bt) {
             double v = 0.0;

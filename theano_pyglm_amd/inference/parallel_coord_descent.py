@@ -18,7 +18,7 @@ neurons and summing (:16-55).  Here rank r
 Every rank returns the same state dict.
 
 `shard='time'` is the alternative split for populations whose per-rank neuron blocks would be narrow
-(at N = 128 on 8 GPUs a rank owns 16 neurons and the MFMA tiles run a third full): every
+(at N = 128 on 8 GPUs a rank owns 16 neurons and the MFMA tiles run a third full, docs/NOTEBOOK.md §4.1c): every
 rank evaluates ALL neurons on its own range of time bins (`Population.set_time_shard`; the likelihood
 is additive over time segments, population.py:41-43), one all-reduce of the packed (ll, grad) block per
 evaluation replaces the end-of-sweep gathers, and all ranks run the identical lock-step optimizer on
@@ -146,7 +146,7 @@ def _time_sharded_sweeps(population, x, maxiter, atol, verbose):
     return x
 
 
-NARROW_SHARD = 64      # neurons per rank below which the time split is the default (DESIGN §5: a 16-neuron
+NARROW_SHARD = 64      # neurons per rank below which the time split is the default (DESIGN.md §5: a 16-neuron
                        # shard of a 128-neuron population runs at a third of the 128-wide MFMA rate)
 
 

@@ -1,4 +1,4 @@
-"""Timing of every BASELINE.json configuration on one GPU (numbers quoted in DESIGN.md §6.0).
+"""Timing of every BASELINE.json configuration on one GPU (profiles/rNN_config_table.md).
     python tools/config_table.py [out.json]"""
 import json, sys, time
 import numpy as np
