@@ -17,7 +17,10 @@ tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
 t0 = time.time()
 def tame(x):
     for g in x['glms']:
-        g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (3.0 / np.sqrt(D))
+        g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
+        g['bkgd']['w_t'] = np.asarray(g['bkgd']['w_t']) * 0.5
+        g['bias']['bias'] = 2.5 + 0.3 * np.asarray(g['bias']['bias'])
+        g['imp']['w_ir'] = np.asarray(g['imp']['w_ir']) * 0.3
 model, popn_true, data = make_dataset(tmpl, N, T, seed=1234 + 5, adjust=tame)
 print("data: %.1f s; rates %.1f..%.1f Hz" % (time.time() - t0, data['S'].sum(0).min() / T, data['S'].sum(0).max() / T), flush=True)
 x_true = data['vars']
