@@ -20,7 +20,7 @@ def tame(x):
         g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
         g['bkgd']['w_t'] = np.asarray(g['bkgd']['w_t']) * 0.5
         g['bias']['bias'] = 2.5 + 0.3 * np.asarray(g['bias']['bias'])
-        g['imp']['w_ir'] = np.asarray(g['imp']['w_ir']) * 0.3
+        g['imp']['w_ir'] = np.asarray(g['imp']['w_ir']) * 0.1
 model, popn_true, data = make_dataset(tmpl, N, T, seed=1234 + 5, adjust=tame)
 print("data: %.1f s; rates %.1f..%.1f Hz" % (time.time() - t0, data['S'].sum(0).min() / T, data['S'].sum(0).max() / T), flush=True)
 x_true = data['vars']
