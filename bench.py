@@ -278,6 +278,30 @@ def stim_stress(reps=20):
     dev.set_option(94, 0)
     dev.set_option(_lib.OPT_TIMING, 1)
     dev.close()
+    # one MAP sweep of the same model and data through the host mirror (coord_descent default: STA warm start of the stimulus
+    # weights on the device, then all 64 per-neuron BFGS fits in lock step -- HIP row kernels, neuron lists through the
+    # frame-rate stimulus kernels; the template's N(0, 0.001) impulse prior runs every fit into the reference's maxiter = 225)
+    import copy
+    from theano_pyglm_amd.models import templates
+    from theano_pyglm_amd.models.model_factory import make_model
+    from theano_pyglm_amd.population import Population
+    from theano_pyglm_amd.inference import coord_descent as cd
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = D
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
+    popn = Population(make_model(tmpl, N=N, dt=dt))
+    popn.add_data({'S': S, 'N': N, 'dt': dt, 'T': T, 'stim': stim, 'dt_stim': dt_stim})
+    x0 = popn.sample(np.random.RandomState(0))
+    for g in x0['glms']:
+        g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
+    t0 = time.perf_counter()
+    cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    map_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    map_s = time.perf_counter() - t0
+    map_stats = dict(getattr(popn, 'last_fit_stats', None) or {})
+    popn.release_data()
     flops_imp = 4.0 * nT * (N * 3) * N
     return {"metric": "ll+grad evaluation, spatiotemporal_glm stress variant", "variant": "D_stim=1024 (32x32 pixels), "
             "identity spatial basis Bx=1024, Bt=3, dt_stim=0.1 s, N=64, T=300 s (nT=300000), exp nonlinearity",
@@ -290,7 +314,9 @@ def stim_stress(reps=20):
             "impulse_contraction_flops": flops_imp,
             "impulse_contraction_frac_of_f64_mfma_peak": flops_imp / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
             "dense_equivalent_bytes": float(nT) * Bt * D * 8,
-            "device_bytes_stimulus": 2.0 * stim.size * 8}
+            "device_bytes_stimulus": 2.0 * stim.size * 8,
+            "map_sweep_s": map_s, "map_first_call_s": map_first, "map_stats": map_stats,
+            "map_path": "coord_descent(maxiter=1) default: pgl_sta warm start + lock-step BFGS (P = %d per neuron)" % P}
 
 
 def usable_cores():

@@ -572,6 +572,71 @@ def test_lockstep_row_kernels_equal_tensor_op_bookkeeping(std4):
     pb.release_data()
 
 
+def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
+    """spatiotemporal_glm with a wide stimulus (separable device path at the frame rate): the lock-step optimizer runs on
+    the HIP row kernels with neuron LISTS (pgl_ll_grad_list_dev through the frame-rate stimulus kernels) and gives the
+    iterates of the tensor-op bookkeeping on neuron ranges; a list call equals the range call row by row."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch, _Packing
+    from theano_pyglm_amd.models import templates
+    import torch
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = 40
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': 40}
+    tmpl['bkgd']['sigma'] = 0.05
+
+    def tame(x):
+        for xn in x['glms']:
+            xn['bias']['bias'] = np.array([2.0])
+
+    N = 6
+    model, popn_gen, data = make_dataset(tmpl, N, 6.0, seed=43, check=True, adjust=tame)
+    popn_gen.release_data()
+    # the fitted model: a wider impulse prior (the template's N(0, 0.001) needs more than 225 BFGS iterations)
+    tmpl_fit = copy.deepcopy(tmpl)
+    tmpl_fit['impulse']['sigma'] = 0.5
+    popn = Population(make_model(tmpl_fit, N=N, dt=0.001))
+    popn.add_data(dict((k, v) for k, v in data.items() if not k.startswith('_') and k not in ('fstim', 'preprocessed')))
+    assert popn.glm.bkgd_model.separable
+    h = popn._handle(popn._current)
+    assert h.info()['stim_path'] == 2
+    pk = _Packing(popn, torch)
+    assert pk.identity and pk.list_launch
+    # a neuron list == the range call, row by row
+    x = popn.sample(np.random.RandomState(44))
+    tame(x)
+    th = popn.theta_matrix(x)
+    W = popn.W_eff(x)
+    ll_r, g_r = h.ll_grad(th, W)
+    idx = np.array([4, 1, 5], dtype=np.int32)
+    d_idx = torch.from_numpy(idx).cuda()
+    d_th = torch.from_numpy(np.ascontiguousarray(th[idx])).cuda()
+    d_W = torch.from_numpy(np.ascontiguousarray(W)).cuda()
+    d_ll = torch.zeros(3, dtype=torch.float64, device='cuda')
+    d_g = torch.zeros((3, th.shape[1]), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    h.ll_grad_list_dev(d_idx.data_ptr(), 3, d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+    h.sync()
+    assert np.allclose(d_ll.cpu().numpy(), ll_r[idx], rtol=1e-12)
+    assert np.max(np.abs(d_g.cpu().numpy() - g_r[idx])) < 1e-10 * np.max(np.abs(g_r))
+    # row kernels (lists) against tensor-op bookkeeping
+    x0 = popn.sample(np.random.RandomState(45))
+    tame(x0)
+    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+    fa, ita, eva = fit_glms_batched_torch(popn, xa, row_kernels=True)
+    sa = dict(popn.last_fit_stats)
+    fb, itb, evb = fit_glms_batched_torch(popn, xb, row_kernels=False, lag=1)
+    sb = dict(popn.last_fit_stats)
+    assert sa.pop('bookkeeping') == 'hip row kernels' and sb.pop('bookkeeping') == 'torch tensor ops'
+    assert sa['neuron_evaluations'] < sb['neuron_evaluations']          # lists: finished neurons drop out of the launches
+    # (~165 BFGS iterations: list launches sum the listed rows in another order than range launches, the two
+    #  trajectories drift apart by rounding and may stop an iteration apart -- at the same optimum)
+    assert abs(ita - itb) <= 3 and np.allclose(fa, fb, rtol=1e-8, atol=0), (sa, sb, fa, fb)
+    for n in range(N):
+        assert np.allclose(popn.glm.theta_row(xa['glms'][n]), popn.glm.theta_row(xb['glms'][n]), rtol=1e-3, atol=1e-5)
+    assert sa['converged_gtol'] + sa['stalled'] == N
+    popn.release_data()
+
+
 def test_all_f64_epilogue_option_and_identity_rows():
     """PGL_OPT_EPI_F64 (run-time switch of the single-precision exp(-x) correction): same ll and gradient to 1e-12 in
     the regime where the correction is used (currents > 12), bit-identical outside it; pgl_identity_rows_dev touches

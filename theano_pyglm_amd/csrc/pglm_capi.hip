@@ -793,7 +793,7 @@ int pgl_destroy(pgl_handle h)
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
-                      &h->spart};
+                      &h->spart, &h->sepC, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
@@ -1448,7 +1448,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     std::vector<Plan> plans(slices.size());
     // separable stimulus at the frame rate: impulse columns on resident tiles (k_fused7, slab-input form), the stimulus
     // current / its gradients by k_sepf_*; needs a short feature row (<= 4 post tiles, <= 320 columns)
-    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->cur_pidx && !h->opt_f32;
+    // (neuron lists are fine here: the stimulus kernels work on the listed rows, the fused kernel maps rows to neurons)
+    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32;
     if (sepf) {
         int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
         if (rc) return rc;
@@ -1688,7 +1689,8 @@ int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, doubl
                            double lam)
 {
     if (!h || !d_Xt || !d_ll_f || !d_grad_g || L <= 0) return fail(PGL_ERR_ARG, "bad argument");
-    if (P != 1 + h->Dstim + h->Kimp || h->sep) return fail(PGL_ERR_ARG, "rows must be theta rows [bias, w_stim, w_ir]");
+    // (separable stimulus: the stimulus block of a row is [w_t, w_x], both under N(0, stim_sigma) -- bkgd.py:223-224 with mu = 0)
+    if (P != 1 + h->Dstim + h->Kimp) return fail(PGL_ERR_ARG, "rows must be theta rows [bias, w_stim, w_ir]");
     if (prior_kind != 0 && prior_kind != 1) return fail(PGL_ERR_ARG, "prior kind: 0 Gaussian, 1 group lasso");
     HIPCHK(hipSetDevice(h->device));
     BfgsPrior q;

@@ -57,18 +57,28 @@ class _Packing(object):
             self.bk, self.nbk = 'none', 0
         self.dirichlet = isinstance(glm.imp_model, DirichletImpulses)
         self.Pp = 1 + self.nbk + self.N * self.B
-        self.list_launch = self.bk != 'st_sep'       # pgl_ll_grad_list_dev: not with the separable stimulus
+        # pgl_ll_grad_list_dev with a separable stimulus: only when the device evaluates it at the frame rate
+        # (pgl_info 'stim_path' == 2; the tap-rate kernels take neuron ranges only)
+        sepf = False
+        if self.bk == 'st_sep' and getattr(population, '_current', None) is not None:
+            try:
+                sepf = population._handle(population._current).info()['stim_path'] == 2
+            except Exception:
+                sepf = False
+        self.list_launch = self.bk != 'st_sep' or sepf
         # the row IS the device's theta row and its prior is one of the forms the row kernels know
-        # (pgl_bfgs_objective_dev): the whole state machine then runs as HIP row kernels
-        self.identity = self.bk in ('none', 'basis') and not self.dirichlet and \
-            isinstance(glm.imp_model.prior, (Gaussian, GroupLasso))
+        # (pgl_bfgs_objective_dev): the whole state machine then runs as HIP row kernels.  Separable stimulus: the block
+        # [w_t, w_x] under N(0, sigma) (bkgd.py:223-224 with the template's mu = 0)
+        self.identity = (self.bk in ('none', 'basis') or (self.bk == 'st_sep' and sepf and float(bk.mu) == 0.0)) and \
+            not self.dirichlet and isinstance(glm.imp_model.prior, (Gaussian, GroupLasso))
+        self.stim_sigma = float(bk.sigma) if self.bk == 'st_sep' else 0.01
 
     def prior_params(self):
         """(kind, mu_b, sg_b, stim_sigma, mu, sigma, lam) for pgl_bfgs_objective_dev."""
         glm = self.glm
         pr = glm.imp_model.prior
         kind = 1 if isinstance(pr, GroupLasso) else 0
-        return (kind, float(glm.bias_model.mu_bias), float(glm.bias_model.sig_bias), 0.01, float(pr.mu),
+        return (kind, float(glm.bias_model.mu_bias), float(glm.bias_model.sig_bias), self.stim_sigma, float(pr.mu),
                 float(pr.sigma), float(getattr(pr, 'lam', 0.0)))
 
     # -- state dict <-> rows -------------------------------------------------------------------

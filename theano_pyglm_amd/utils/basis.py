@@ -155,4 +155,6 @@ def project_onto_basis(f, basis, lam=0):
     assert f.shape[0] == R, "Function is not the same length as the basis!"
     if f.ndim == 1:
         f = f.reshape(R, 1)
+    if lam == 0 and R == B and np.array_equal(basis, np.eye(R)):
+        return f.copy()                         # identity basis (a pixel stimulus): the solve returns f itself
     return np.linalg.solve(basis.T.dot(basis) + lam * np.eye(B), basis.T.dot(f))

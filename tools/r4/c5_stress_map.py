@@ -32,10 +32,15 @@ popn.add_data(dict(clean))
 print("stim path:", popn._handle(popn._current).info()['stim_path'], "separable:", popn.glm.bkgd_model.separable, flush=True)
 x0 = popn.sample(np.random.RandomState(3))
 lp0 = popn.compute_log_p(x0)
+import cProfile, pstats, os
 for rep in range(2):
+    pr = cProfile.Profile()
     t0 = time.time()
+    if os.environ.get('CPROF'): pr.enable()
     x_inf = coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    if os.environ.get('CPROF'): pr.disable()
     print("MAP sweep %.2f s" % (time.time() - t0), popn.last_fit_stats, flush=True)
+if os.environ.get('CPROF'): pstats.Stats(pr).sort_stats('tottime').print_stats(14)
 lp1 = popn.compute_log_p(x_inf)
 ll_true = popn_true.compute_ll(x_true)
 print("log p: initial %.1f -> MAP %.1f; ll MAP %.1f vs ll true %.1f" % (lp0, lp1, popn.compute_ll(x_inf), ll_true))
