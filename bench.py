@@ -227,7 +227,7 @@ def st_ibasis(key, R=300, dt=0.001):
     return ib / (R * dt)
 
 
-def stim_stress(reps=20):
+def stim_stress(reps=20, with_map=False):
     """Secondary block for BASELINE config 5 ("stimulus-conv kernel stressed"): SURVEY 8(d)'s stress variant --
     spatiotemporal_glm N=64, T=300 s, D_stim=1024 pixels, identity spatial basis, Bt=3, frames of 100 bins -- on the
     separable device path (frame-rate stimulus kernels + impulse columns on resident tiles), ll+grad per evaluation,
@@ -281,6 +281,10 @@ def stim_stress(reps=20):
     # one MAP sweep of the same model and data through the host mirror (coord_descent default: STA warm start of the stimulus
     # weights on the device, then all 64 per-neuron BFGS fits in lock step -- HIP row kernels, neuron lists through the
     # frame-rate stimulus kernels; the template's N(0, 0.001) impulse prior runs every fit into the reference's maxiter = 225)
+    map_s = map_first = None
+    map_stats = {}
+    if not with_map:
+        return _stim_record(locals())
     import copy
     from theano_pyglm_amd.models import templates
     from theano_pyglm_amd.models.model_factory import make_model
@@ -302,6 +306,13 @@ def stim_stress(reps=20):
     map_s = time.perf_counter() - t0
     map_stats = dict(getattr(popn, 'last_fit_stats', None) or {})
     popn.release_data()
+    return _stim_record(locals())
+
+
+def _stim_record(v):
+    nT, N, Bt, D, ms, ms_tap, ll, ll_tap, info, stim, P = (v[k] for k in ('nT', 'N', 'Bt', 'D', 'ms', 'ms_tap', 'll', 'll_tap',
+                                                                           'info', 'stim', 'P'))
+    map_s, map_first, map_stats = v['map_s'], v['map_first'], v['map_stats']
     flops_imp = 4.0 * nT * (N * 3) * N
     return {"metric": "ll+grad evaluation, spatiotemporal_glm stress variant", "variant": "D_stim=1024 (32x32 pixels), "
             "identity spatial basis Bx=1024, Bt=3, dt_stim=0.1 s, N=64, T=300 s (nT=300000), exp nonlinearity",
@@ -438,6 +449,8 @@ def main():
     ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
     ap.add_argument('--no-mcmc', action='store_true', help='skip the secondary MCMC inner-ll measurement')
     ap.add_argument('--no-stim', action='store_true', help='skip the secondary stimulus stress-variant measurement (config 5)')
+    ap.add_argument('--stim-map', action='store_true',
+                    help='also time a MAP sweep of the stress variant (two sweeps of ~17 s: not part of the default run)')
     ap.add_argument('--no-ab', action='store_true',
                     help='skip the A/B loops after the timed region (in-kernel features, all-f64 epilogue): profiler '
                          'passes use it so that per-kernel averages and counters describe the headline kernel only')
@@ -788,7 +801,7 @@ def main():
         if not multi and not args.no_mcmc and not args.f32_features:
             out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
         if not multi and not args.no_stim and not args.f32_features:
-            out["secondary_stim"] = stim_stress()
+            out["secondary_stim"] = stim_stress(with_map=args.stim_map)
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         # RCCL prints a banner through C stdio: flush it first so that the JSON line is the last line of stdout

@@ -35,6 +35,8 @@ for k, v in d.items():
         print("%-40s fetch %.1f MB (x2 for 16-byte streams) write %.1f MB  MFMA busy %.3f" % (k[:40], g('FETCH_SIZE') / 1024, g('WRITE_SIZE') / 1024,
               g('SQ_VALU_MFMA_BUSY_CYCLES') / (g('GRBM_GUI_ACTIVE') / 8 * 1024)))
 PY
+echo "== C5 stress: MAP sweep through the host mirror (bench.py --stim-map)"
+python3 bench.py --steps 5 --warmup 2 --no-map --no-mcmc --no-cpu-baseline --no-ab --stim-map 2>/dev/null | tail -1 | python3 -c "import sys, json; d = json.loads(sys.stdin.read())['secondary_stim']; print(json.dumps(d, indent=1))" | tee $R/r04_C5stress_bench_block.json | grep -E '"value"|map_sweep|iterations|evaluations'
 echo "== phase profiles"
 for c in C2 C5 C1; do PYGLM_HIP_LIB=$L/libpyglm_hip_prof.so python3 tools/phase_profile_small.py $c 2>&1 | tail -18 > $R/r04_phase_$c.txt; tail -16 $R/r04_phase_$c.txt; done
 PYGLM_HIP_LIB=$L/libpyglm_hip_prof.so python3 tools/phase_profile.py 128 600 2>&1 | tail -24 > $R/r04_phase_C3.txt; cat $R/r04_phase_C3.txt
