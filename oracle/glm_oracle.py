@@ -201,6 +201,44 @@ def spatiotemporal_stim_features(stim, dt_stim, dt, nT, ibasis_x, ibasis_t):
     return f.reshape(nT, -1)
 
 
+def frame_rate_table(ibasis_t, q):
+    """The identity behind the device's frame-rate stimulus kernels (k_sepf_*), restated in numpy so that it can be
+    checked on the CPU against the reference's own convolution: with the stimulus interpolated linearly between
+    frames q bins apart (bkgd.py:303-313) and filtered causally with Rt taps (basis.py:238-273, 201-236), bin
+    t = q F + o sees only the J = ceil(Rt / q) + 2 frame values base(F) .. base(F) + J - 1, base(F) = max(F - M, 0),
+    M = ceil(Rt / q):
+        conv(interp(z), ibasis_t)[t, bt] = sum_j C[row(t), j, bt] z[base(F) + j]
+    with row(t) = t for t < q M (bins t - tau < 0 dropped), q M + o after.  Returns (C, M, J)."""
+    Rt, Bt = ibasis_t.shape
+    M = -(-Rt // q)
+    J = M + 2
+    C = np.zeros((q * (M + 1), J, Bt))
+    for t in range(q * (M + 1)):
+        base = max(t // q - M, 0)
+        for tau in range(1, min(Rt, t) + 1):
+            s = t - tau
+            f, a = s // q, (s % q) / float(q)
+            C[t, f - base] += ibasis_t[tau - 1] * (1.0 - a)
+            if a != 0.0:
+                C[t, f + 1 - base] += ibasis_t[tau - 1] * a
+    return C, M, J
+
+
+def frame_rate_features(z, ibasis_t, q, nT):
+    """conv(interp(z), ibasis_t) (nT, Bx, Bt) through frame_rate_table; frames past the last one repeat it
+    (np.interp holds the last value)."""
+    C, M, J = frame_rate_table(ibasis_t, q)
+    Tz = z.shape[0]
+    out = np.zeros((nT,) + z.shape[1:] + (ibasis_t.shape[1],))
+    for t in range(nT):
+        F = t // q
+        base = max(F - M, 0)
+        row = t if t < q * M else q * M + t % q
+        idx = np.minimum(base + np.arange(J), Tz - 1)
+        out[t] = np.einsum('jb,j...->...b', C[row], z[idx])
+    return out
+
+
 def project_onto_basis(f, basis, lam=0.0):
     """basis.py:416-436: beta = inv(basis^T basis + lam I) basis^T f, shape (B,1)."""
     R, B = basis.shape

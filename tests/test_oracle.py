@@ -206,6 +206,27 @@ def test_sta_oracle_definition():
     assert np.allclose(wb['w_stim'].reshape(D, 3), np.outer(wx, wt), atol=1e-12)
 
 
+def test_frame_rate_form_of_the_stimulus_filter_equals_the_reference_convolution():
+    """The piecewise-linear identity the device's frame-rate stimulus kernels are built on (oracle.frame_rate_table)
+    against the reference-pinned convolution: interpolate-then-filter (bkgd.py:303-340, basis.py:238-273; the golden
+    `lr2d_*` vectors pin convolve_with_low_rank_2d_basis itself) for frames of 100, 50 and 150 bins, recordings that
+    end before / behind the last frame, and the first Rt bins where early taps are dropped."""
+    g = H.golden()
+    ibt = g['lr2d_ibasis_t']
+    rng = np.random.RandomState(3)
+    for q, Tz, nT in ((100, 9, 1000), (50, 30, 1400), (150, 5, 700)):
+        z = rng.randn(Tz, 4)
+        s = O.interp_stim(z, q * 0.001, 0.001, nT)
+        ref = O.convolve_with_basis(s, ibt)                 # (nT, 4, Bt)
+        got = O.frame_rate_features(z, ibt, q, nT)
+        assert np.max(np.abs(got - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+    # the golden vectors of the reference's own low-rank convolution, through the same identity: its stimulus IS the
+    # bin-rate series, i.e. frames of one bin
+    stim, bx = g['lr2d_stim'], g['lr2d_ibasis_x']
+    got = O.frame_rate_features(stim.dot(bx), ibt, 1, stim.shape[0])         # (T, Bx, Bt)
+    assert got.shape == g['lr2d_fstim'].shape and np.allclose(got, g['lr2d_fstim'], atol=1e-12)
+
+
 def test_blocked_c_baseline_matches_reference_dataflow():
     """oracle/glm_blocked.c (B2, all neurons per time tile) == oracle/glm_oracle.c (B1, per neuron)."""
     from oracle import c_oracle as CO
