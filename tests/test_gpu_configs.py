@@ -485,6 +485,41 @@ def test_c4_inner_ll_full_size(c4):
     h.set_time_range(0, nT)
 
 
+def test_c4_inner_ll_whole_recording_oracle(c4):
+    """The collapsed-Gibbs inner ll (gibbs.py:835-864, 910-937, 1002-1032) of C4 on the WHOLE recording (600 000 bins)
+    against the numpy oracle, for an edge, a diagonal entry and non-edges: all 11 quadrature weights of every pair, both
+    device implementations (batched columns and the single-column path)."""
+    from oracle import c_oracle as CO
+    model, popn, data, x = c4
+    N, nT = 128, 600000
+    h = popn._handle(data)
+    A = np.asarray(x['net']['graph']['A']).reshape(N, N)
+    W = np.asarray(x['net']['weights']['W'], float).reshape(N, N)
+    edges = np.argwhere((A != 0) & ~np.eye(N, dtype=bool))
+    e_pre, e_post = int(edges[0][0]), int(edges[0][1])
+    pairs = [(e_pre, e_post), (5, 5), (77, 3), (0, 127)]
+    upd = G.CollapsedGibbsNetworkColumnUpdate(rng=np.random.RandomState(1))
+    upd.preprocess(popn)
+    theta = popn.theta_matrix(x)
+    Weff = A * W
+    ws = []
+    for n_pre, n_post in pairs:
+        mu, sg = (upd.mu_w_ref, upd.sigma_w_ref) if n_pre == n_post else (upd.mu_w, upd.sigma_w)
+        ws.append(np.concatenate((O.gauss_hermite_nodes(mu, sg)[0], [0.0])))
+    ws = np.array(ws)
+    cols, pre = np.array([q for _, q in pairs]), np.array([q for q, _ in pairs])
+    h.set_time_range(0, nT)
+    h.gibbs_prepare_all(theta, Weff)
+    ll_b = h.gibbs_ll_cols(cols, pre, Weff[pre, cols], ws)
+    fS = CO.features(data['S'], popn.glm.imp_model.ibasis)              # (nT, N, B): 3 GB, the C feature builder
+    close = lambda a, b, rtol: np.allclose(a, b, rtol=rtol, atol=0, equal_nan=True)
+    for i, (n_pre, n_post) in enumerate(pairs):
+        ref = _oracle_inner_ll(popn, x, data['S'], n_pre, n_post, ws[i], fS)
+        assert close(ll_b[i], ref, 1e-10), (n_pre, n_post, ll_b[i], ref)
+        h.gibbs_prepare(n_post, theta[n_post], Weff[:, n_post])
+        assert close(h.gibbs_ll(n_pre, Weff[n_pre, n_post], ws[i]), ref, 1e-10)
+
+
 def test_c4_column_update_and_sweep_full_size(c4):
     """One full column update (128 pairs, reference order) and one batched sweep of all 16 384 pairs at
     C4 size keep the state consistent: compute_log_p of the device == oracle on a sub-range."""
