@@ -715,6 +715,11 @@ static hipError_t launch_fused2(const Plan& pl, const FusedParams& fp, hipStream
 
 // separable stimulus at the frame rate: which = 0 forward, 1 backward, 2 finish
 template <int J, int BT>
+static void launch_sepf(int which, const SepfParams& sp, hipStream_t s);
+// (the thin GEMMs of the separable stimulus: k_gemm_kc when the k-contiguous operands are 16-byte aligned, else k_gemm_mfma)
+static inline bool gemm_aligned(const void* p, long long ld) { return ((uintptr_t)p % 16) == 0 && (ld % 2) == 0; }
+
+template <int J, int BT>
 static void launch_sepf(int which, const SepfParams& sp, hipStream_t s)
 {
     const long long nF = sp.F1 - sp.F0 + 1;
@@ -1210,9 +1215,18 @@ static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, Sep
 {
     const int P = 1 + h->Dstim + h->Kimp, ldy = pl.nPT * 16;
     ENSURE(h->YfT, (size_t)h->sepT * ldy * 8);
-    // z_n[f] = (stim . basis_x)[f, :] . w_x[n]  ->  YfT[f][n]   (m = n, n = f, k = x)
-    int rc = launch_gemm_mfma(h, d_theta + 1 + h->sepBt, P, 1, (const double*)h->zfT.p, 1, h->sepT, (double*)h->YfT.p,
-                              1, ldy, pl.npost, (int)h->sepT, h->sepBx);
+    // z_n[f] = (stim . basis_x)[f, :] . w_x[n]  ->  YfT[f][n]
+    int rc = PGL_OK;
+    const double* wx = d_theta + 1 + h->sepBt;
+    if (gemm_aligned(h->zf.p, h->sepBx) && gemm_aligned(wx, P)) {      // m = f, n = n, k = x (even): both operands k-contiguous
+        hipLaunchKernelGGL((k_gemm_kc<4, 1, 8>), dim3((unsigned)((h->sepT + 15) / 16), (unsigned)((pl.npost + 63) / 64)), dim3(512),
+                           0, h->stream, (const double*)h->zf.p, (long long)h->sepBx, wx, (long long)P, (double*)h->YfT.p,
+                           (long long)ldy, 1LL, (int)h->sepT, pl.npost, h->sepBx);
+        HIPCHK(hipGetLastError());
+    } else {                                                           // m = n, n = f, k = x
+        rc = launch_gemm_mfma(h, wx, P, 1, (const double*)h->zfT.p, 1, h->sepT, (double*)h->YfT.p, 1, ldy, pl.npost,
+                              (int)h->sepT, h->sepBx);
+    }
     if (rc) return rc;
     sp.Ctab = (const double*)h->sepC.p; sp.YfT = (const double*)h->YfT.p; sp.theta = d_theta;
     sp.X = (double*)h->Xbuf.p; sp.Hb = nullptr; sp.wpart = nullptr; sp.QvT = nullptr; sp.grad = nullptr;
@@ -1235,6 +1249,13 @@ static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad)
     if (!rc) rc = launch_sepf_any(h, 2, sp);
     if (rc) return rc;
     // d ll / d w_x[n][x] = sum_f (stim . basis_x)[f][x] QvT[f][n]
+    if (gemm_aligned(h->zfT.p, h->sepT)) {                             // m = x (rows of zfT: f contiguous), n = n, k = f
+        hipLaunchKernelGGL((k_gemm_kc<1, 0, 16>), dim3((unsigned)((h->sepBx + 15) / 16), (unsigned)((sp.npost + 15) / 16)), dim3(512),
+                           0, h->stream, (const double*)h->zfT.p, (long long)h->sepT, (const double*)h->QvT.p, (long long)sp.ldy,
+                           d_grad + 1 + h->sepBt, 1LL, (long long)sp.P, h->sepBx, sp.npost, (int)h->sepT);
+        HIPCHK(hipGetLastError());
+        return PGL_OK;
+    }
     return launch_gemm_mfma(h, (const double*)h->zf.p, 1, h->sepBx, (const double*)h->QvT.p, 1, sp.ldy,
                             d_grad + 1 + h->sepBt, 1, sp.P, h->sepBx, sp.npost, (int)h->sepT);
 }

@@ -4554,6 +4554,92 @@ __global__ __launch_bounds__(512) void k_gemm_mfma(const double* __restrict__ A,
     }
 }
 
+// C[m][n] = sum_k A[m][k] B[n][k] for the two thin GEMMs of the separable stimulus (0.4 GFLOP each, 25 MB streamed once:
+// what matters is how the bytes travel, not the MFMA rate).  A is k-contiguous and 16-byte aligned (lda even): a lane
+// loads two consecutive k per request (global_load_dwordx4), rows 16 lanes apart, so a wave reads 64-byte runs of 16
+// rows and its whole share of K is ONE contiguous run per row (DRAM pages stay open) -- against single 8-byte loads that
+// were bound by the texture addresser (k-contiguous) or by DRAM page misses (m-contiguous, rows 24 KB apart).  K even.
+// B: BK = 1 k-contiguous and aligned like A (B[n ldb + k]);  BK = 0 n-contiguous (B[k ldb + n], 128-byte lines).
+// A workgroup = 8 waves sharing one 16 x 16 NT tile, each wave a contiguous eighth of K in chunks of 8 k (lane group
+// kk owns k = 8 c + 2 kk, + 1); NB chunks are requested together (one latency per batch), the eight partial tiles are
+// added in a fixed order through LDS.  Stored at C[m scm + n scn].  grid = (ceil(M / 16), ceil(N / (16 NT))).
+template <int NT, int BK, int NB>
+__global__ __launch_bounds__(512) void k_gemm_kc(const double* __restrict__ A, long long lda,
+                                                 const double* __restrict__ Bm, long long ldb,
+                                                 double* __restrict__ C, long long scm, long long scn,
+                                                 int M, int Nn, int Kd)
+{
+    constexpr int NWG = 8;
+    __shared__ double red[NWG - 1][NT][4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NT;
+    const double* ap = A + (size_t)((m0 + i < M) ? m0 + i : M - 1) * lda;
+    const double* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = (n0 + 16 * t + i < Nn) ? n0 + 16 * t + i : Nn - 1;
+        bp[t] = BK ? Bm + (size_t)n * ldb : Bm + n;
+    }
+    d4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int nC = (Kd + 7) / 8;                          // chunks of 8 k
+    const int cpw = (nC + NWG - 1) / NWG;
+    const int c_beg = wave * cpw, c_end = (c_beg + cpw < nC) ? c_beg + cpw : nC;
+    for (int cb = c_beg; cb < c_end; cb += NB) {
+        pgl_d2 a2[NB], b2[NB][NT];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int k = 8 * (cb + c) + 2 * kk;
+            const bool ok = (cb + c < c_end) && k < Kd;   // (Kd is even: a pair is inside or outside as a whole)
+            const size_t kc = ok ? k : 0;                  // (a clamped address for the tail)
+            const pgl_d2 av = *reinterpret_cast<const pgl_d2*>(ap + kc);
+            a2[c].x = ok ? av.x : 0.0;
+            a2[c].y = ok ? av.y : 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pgl_d2 bv;
+                if (BK) {
+                    bv = *reinterpret_cast<const pgl_d2*>(bp[t] + kc);
+                } else {
+                    bv.x = bp[t][kc * ldb];
+                    bv.y = bp[t][(kc + 1) * ldb];
+                }
+                b2[c][t].x = ok ? bv.x : 0.0;
+                b2[c][t].y = ok ? bv.y : 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[c].x, b2[c][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[c].y, b2[c][t].y, acc[t], 0, 0, 0);
+            }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[t][r];
+#pragma unroll
+                for (int w = 0; w < NWG - 1; ++w) v += red[w][t][r][lane];
+                const int m = m0 + kk + 4 * r, n = n0 + 16 * t + i;
+                if (m < M && n < Nn) C[(size_t)m * scm + (size_t)n * scn] = v;
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Spike-triggered average (pyglm/utils/sta.py:6-85) from the event lists:
 //   A[i,l,d] = sum_t S[t,n_i] * istim[t-l, d] / sum_t S[t,n_i],  l = 0..L-1 (t-l < 0 -> 0)
