@@ -572,6 +572,50 @@ def test_lockstep_row_kernels_equal_tensor_op_bookkeeping(std4):
     pb.release_data()
 
 
+def test_separable_stimulus_frame_rate_randomised_shapes():
+    """Randomised shapes for the frame-rate stimulus kernels against the tap-rate kernels of the same handle: frame
+    lengths from 2 to 150 bins, temporal filters of 20 to 300 taps with 1 to 4 bases (3 to 8 frame values per bin, both
+    template instantiations), odd and even numbers of spatial bases (both GEMM kernels), stimulus shorter and longer
+    than the recording, random neuron ranges and time ranges."""
+    from tests import helpers as H
+    rng = np.random.RandomState(2024)
+    done = 0
+    while done < 14:
+        Rt = int(rng.choice([20, 47, 100, 233, 300]))
+        q = int(rng.randint(max(2, -(-Rt // 6)), 151))
+        if -(-Rt // q) + 2 > 8:
+            continue
+        Bt = int(rng.randint(1, 5))
+        N = int(rng.choice([1, 5, 16, 17, 33, 64]))
+        nT = int(rng.randint(20, 190)) * 16 + int(rng.randint(0, 16))
+        D = int(rng.randint(2, 24))
+        Bx = D if rng.rand() < 0.5 else int(rng.randint(1, 12))
+        Tstim = max(2, int(nT / q * rng.choice([0.5, 1.0, 1.3])) + int(rng.randint(0, 3)))
+        ibt = rng.randn(Rt, Bt) / np.sqrt(Rt)
+        ibx = None if Bx == D else rng.randn(D, Bx)
+        stim = rng.randn(Tstim, D)
+        p = H.Problem(N, nT, H.st_ibasis(), kind='exp' if rng.rand() < 0.5 else 'explinear', seed=100 + done, w_scale=0.02,
+                      bias_mu=1.0)
+        dev = p.device()
+        dev.set_stimulus_separable(stim, q * 0.001, ibt, ibx)
+        assert dev.info()['stim_path'] == 2, (Rt, q, Bt)
+        th = np.concatenate((p.theta[:, :1], 0.3 * rng.randn(N, Bt), 0.3 * rng.randn(N, Bx) / np.sqrt(Bx), p.theta[:, 1:]), axis=1)
+        n_lo = int(rng.randint(0, N))
+        n_hi = int(rng.randint(n_lo + 1, N + 1))
+        t_lo = 16 * int(rng.randint(0, nT // 32))
+        t_hi = int(rng.randint(t_lo + 1, nT + 1))
+        dev.set_time_range(t_lo, t_hi)
+        ll_f, g_f = dev.ll_grad(th[n_lo:n_hi], p.Weff, n_lo, n_hi)
+        dev.set_option(94, 2)
+        assert dev.info()['stim_path'] == 1
+        ll_t, g_t = dev.ll_grad(th[n_lo:n_hi], p.Weff, n_lo, n_hi)
+        case = (Rt, q, Bt, N, nT, D, Bx, Tstim, n_lo, n_hi, t_lo, t_hi)
+        assert np.allclose(ll_f, ll_t, rtol=1e-11, atol=1e-12), case
+        assert H.rel_err(g_f, g_t) < 1e-10, case
+        dev.close()
+        done += 1
+
+
 def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
     """spatiotemporal_glm with a wide stimulus (separable device path at the frame rate): the lock-step optimizer runs on
     the HIP row kernels with neuron LISTS (pgl_ll_grad_list_dev through the frame-rate stimulus kernels) and gives the
