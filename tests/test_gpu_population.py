@@ -448,7 +448,7 @@ def test_separable_stimulus_matches_dense_and_oracle():
 
 def test_separable_stimulus_frame_rate_kernels():
     """The frame-rate form of the separable stimulus (k_sepf_fwd / k_sepf_bwd / k_sepf_finish + the MFMA GEMMs, impulse
-    columns on resident tiles through the slab-input form of k_fused7) against the tap-rate kernels of the same handle
+    columns on resident tiles through the slab-input forms of k_fused7 / k_fused5) against the tap-rate kernels of the same handle
     (dev option 94) and against the oracle on the dense features (bkgd.py:214-227, 303-340; basis.py:238-273): one to
     four post tiles, q = 100 / 50 / 150 bins per frame (5, 8 and 4 frame values per bin), one to three temporal bases,
     recordings that end before / behind the last frame, time ranges that cut frames."""
@@ -459,7 +459,9 @@ def test_separable_stimulus_frame_rate_kernels():
     cases = ((6, 3000, 24, 0.1, 25, 3, None),        # frames end at bin 2400: clamped tail
              (40, 4000, 32, 0.05, 90, 2, 7),         # q = 50 -> 8 frame values; non-identity spatial basis; frames outlast the bins
              (64, 2512, 16, 0.15, 17, 1, None),      # q = 150 -> 4 frame values, recording not a multiple of the frame
-             (20, 1600, 8, 0.1, 16, 3, None))
+             (20, 1600, 8, 0.1, 16, 3, None),
+             (100, 1808, 12, 0.1, 18, 3, None),      # seven post tiles: the two-pass kernel with the slab-input pass 1
+             (128, 1600, 6, 0.05, 40, 2, 4))
     for N, nT, D, dt_stim, Tstim, Bt, Bx_ in cases:
         Bx = D if Bx_ is None else Bx_
         ibt = np.ascontiguousarray(ibt3[:, :Bt])
@@ -470,7 +472,7 @@ def test_separable_stimulus_frame_rate_kernels():
         sep = p.device()
         sep.set_stimulus_separable(stim, dt_stim, ibt, ibx)
         th_s = np.concatenate((p.theta[:, :1], w_t, w_x, p.theta[:, 1:]), axis=1)
-        assert sep.info()['stim_path'] == 2 and sep.info()['kernel_version'] == 7
+        assert sep.info()['stim_path'] == 2 and sep.info()['kernel_version'] == (7 if N <= 64 else 5)
         ll_f, g_f = sep.ll_grad(th_s, p.Weff)
         ll_only, _ = sep.ll_grad(th_s, p.Weff, want_grad=False)
         assert np.allclose(ll_only, ll_f, rtol=1e-13)
@@ -586,7 +588,7 @@ def test_separable_stimulus_frame_rate_randomised_shapes():
         if -(-Rt // q) + 2 > 8:
             continue
         Bt = int(rng.randint(1, 5))
-        N = int(rng.choice([1, 5, 16, 17, 33, 64]))
+        N = int(rng.choice([1, 5, 16, 17, 33, 64, 80, 128]))
         nT = int(rng.randint(20, 190)) * 16 + int(rng.randint(0, 16))
         D = int(rng.randint(2, 24))
         Bx = D if rng.rand() < 0.5 else int(rng.randint(1, 12))
@@ -612,6 +614,8 @@ def test_separable_stimulus_frame_rate_randomised_shapes():
         case = (Rt, q, Bt, N, nT, D, Bx, Tstim, n_lo, n_hi, t_lo, t_hi)
         assert np.allclose(ll_f, ll_t, rtol=1e-11, atol=1e-12), case
         assert H.rel_err(g_f, g_t) < 1e-10, case
+        assert np.all(np.isfinite(ll_f)) and np.any(g_f[:, 1:1 + Bt] != 0.0) and np.any(g_f[:, 1 + Bt:1 + Bt + Bx] != 0.0), case
+        print("frame-rate vs tap-rate, case", case, "max rel grad diff %.1e" % H.rel_err(g_f, g_t))
         dev.close()
         done += 1
 

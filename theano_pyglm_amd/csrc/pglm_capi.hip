@@ -508,10 +508,10 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
 }
 
 // passes: 1, 2, or 0 = both back to back
-template <int KTL, int KTH>
+template <int KTL, int KTH, int XIN = 0>
 static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
-    auto k1 = k_fused5<KTL, KTH, 1>;
+    auto k1 = k_fused5<KTL, KTH, 1, XIN>;
     auto k2 = k_fused5<KTL, KTH, 2>;
     const size_t lds2 = (size_t)2 * pgl_img_bytes(KTH) + 256;
     hipError_t e = ensure_dyn_lds(k1, pl.lds);
@@ -541,6 +541,20 @@ static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream
     case 12 << 8 | 14: return launch_fused5_t<12, 14>(pl, fp, s, pass);
     case 14 << 8 | 18: return launch_fused5_t<14, 18>(pl, fp, s, pass);
     case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L>(pl, fp, s, pass);
+    }
+    return hipErrorInvalidValue;
+}
+
+// slab-input form of pass 1 (separable stimulus at the frame rate, 65 .. 128 neurons: at least 5 post tiles of >= 2 bases)
+static hipError_t launch_fused5_xin(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass = 0)
+{
+    switch (pl.ktl << 8 | pl.kth) {
+    case 5 << 8 | 5: return launch_fused5_t<5, 5, 1>(pl, fp, s, pass);
+    case 7 << 8 | 7: return launch_fused5_t<7, 7, 1>(pl, fp, s, pass);
+    case 9 << 8 | 11: return launch_fused5_t<9, 11, 1>(pl, fp, s, pass);
+    case 12 << 8 | 14: return launch_fused5_t<12, 14, 1>(pl, fp, s, pass);
+    case 14 << 8 | 18: return launch_fused5_t<14, 18, 1>(pl, fp, s, pass);
+    case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L, 1>(pl, fp, s, pass);
     }
     return hipErrorInvalidValue;
 }
@@ -1474,7 +1488,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     if (sepf) {
         int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
         if (rc) return rc;
-        sepf = plans[0].version == 7 && plans[0].nw7 == 4;
+        // up to four post tiles: k_fused7 (slab in / residual out); five to eight: the two-pass kernel (slab in)
+        sepf = (plans[0].version == 7 && plans[0].nw7 == 4) || (plans[0].version == 5 && plans[0].ktl >= 5);
     }
     for (size_t i = 0; i < slices.size() && !sepf; ++i) {
         int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1 && !h->sep);
@@ -1505,7 +1520,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         int rc = direct ? PGL_OK : launch_prep(h, pl, slices[0], n_lo, d_theta, d_Weff);
         if (rc) return rc;
         ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
-        rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
+        rc = (pl.version == 5) ? ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles)
+                               : ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
         if (rc) return rc;
         if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepfParams sp;
@@ -1517,7 +1533,13 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             fp.theta = d_theta;
             fp.Weff = d_Weff;
         }
-        hipError_t e = launch_fused7_xio(pl, fp, h->stream);
+        hipError_t e = hipSuccess;
+        if (pl.version == 5) {                   // pass 1 (slab in, residuals out) and, for the gradient, pass 2
+            e = launch_fused5_xin(pl, fp, h->stream, 1);
+            if (e == hipSuccess && d_grad) e = launch_fused5_xin(pl, fp, h->stream, 2);
+        } else {
+            e = launch_fused7_xio(pl, fp, h->stream);
+        }
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
         if (d_grad) {
             rc = sepf_backward(h, sp, d_grad);
@@ -1836,7 +1858,7 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     if (h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32) {
         rc = make_plan(h, n_lo, n_hi, slices[0], pl, true, true);
         if (rc) return rc;
-        if (pl.version == 7 && pl.nw7 == 4) stim_path = 2;
+        if ((pl.version == 7 && pl.nw7 == 4) || (pl.version == 5 && pl.ktl >= 5)) stim_path = 2;
     }
     if (stim_path != 2) rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1 && !h->sep);
     if (rc) return rc;

@@ -1701,7 +1701,9 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 //     the two epilogues of a SIMD run side by side between two barriers, four elements per lane in
 //     a fixed instruction order (pgl_rate4).
 // ---------------------------------------------------------------------------
-template <int KTL, int KTH, int PASS>
+// XIN = 1 (pass 1): the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] -- the stimulus current of a
+// separable stimulus (k_sepf_fwd) -- which pass 1 then overwrites with the residuals as always
+template <int KTL, int KTH, int PASS, int XIN = 0>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
     constexpr int TT = 16, NW = 8;
@@ -1888,6 +1890,12 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             }
             PGL_PROF_MARK(0);
             const bool do_bwd = active && p.want_grad && !PGL_DBG(16);
+            double xin[XIN ? 4 : 1];
+            if constexpr (XIN != 0) {                     // requested in front of the barrier: its wait hides the latency
+                const double* xs_ = rslab + (size_t)(tile - p.tile0) * rstride;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xin[r] = xs_[r * 64];
+            }
             // every wave is done with H_i (buf1): the next tile's DMA may overwrite it.  The barrier also lines
             // the waves up for the epilogue.
             __syncthreads();
@@ -1901,6 +1909,10 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     double xs[4], term4 = 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
+                    if constexpr (XIN != 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xs[r] += xin[r];
+                    }
                     const double* cg = PGL_C;
                     asm volatile("" : "+s"(cg));           // keeps the scalar loads inside the tile loop
                     done = pgl_rate4(xs, scb, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, term4, rr PGL_PROF_PASS);
@@ -1920,6 +1932,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                         for (int e = 0; e < ENE; ++e) {
                             const int r = ENE * h2 + e;
                             xe[e] = bias_l + (acc0[r] + acc1[r]);
+                            if constexpr (XIN != 0) xe[e] += xin[r];
                             se[e] = (double)scb[r];
                             const long long tg = (long long)t0 + grp + 4 * r;
                             vte[e] = valid_n && (tg < p.t_hi);
