@@ -498,6 +498,21 @@ def test_separable_stimulus_frame_rate_kernels():
             a, b = sep.ll_grad(th_s, p.Weff)
             acc_l, acc_g = acc_l + a, acc_g + b
         assert np.allclose(acc_l, ll_f, rtol=1e-11) and H.rel_err(acc_g, g_f) < 1e-10
+        if N in (40, 100):
+            # a neuron LIST (pgl_ll_grad_list_dev) through the frame-rate path == the rows of the range call
+            import torch
+            idx = np.array([N - 1, 3, N // 2, 17, 0] + list(range(20, 20 + (70 if N == 100 else 10))), dtype=np.int32)
+            d_idx = torch.from_numpy(idx).cuda()
+            d_th = torch.from_numpy(np.ascontiguousarray(th_s[idx])).cuda()
+            d_W = torch.from_numpy(np.ascontiguousarray(p.Weff)).cuda()
+            d_ll = torch.zeros(len(idx), dtype=torch.float64, device='cuda')
+            d_g = torch.zeros((len(idx), th_s.shape[1]), dtype=torch.float64, device='cuda')
+            torch.cuda.synchronize()
+            sep.set_time_range(0, nT)
+            sep.ll_grad_list_dev(d_idx.data_ptr(), len(idx), d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+            sep.sync()
+            assert np.allclose(d_ll.cpu().numpy(), ll_f[idx], rtol=1e-12), N
+            assert np.max(np.abs(d_g.cpu().numpy() - g_f[idx])) < 1e-10 * np.max(np.abs(g_f)), N
         sep.set_time_range(0, nT - 37)
         a37, b37 = sep.ll_grad(th_s, p.Weff)
         # the tap-rate kernels on the same handle
