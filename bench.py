@@ -789,11 +789,11 @@ def main():
         if shard_neurons is not None:
             out["sharding_neurons"] = shard_neurons
         if not multi and N == 128 and nT == 600000 and not args.f32_features:
-            tr = pmc_traffic(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
+            tr = pmc_traffic(['void k_fused5<18, 22, 1', 'void k_fused5<18, 22, 2'])
             if tr is not None:
                 out["roofline"]["traffic"] = tr[1]
                 out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
-            mb = pmc_mfma_busy(['void k_fused5<18, 22, 1>', 'void k_fused5<18, 22, 2>'])
+            mb = pmc_mfma_busy(['void k_fused5<18, 22, 1', 'void k_fused5<18, 22, 2'])
             if mb is not None:
                 out["roofline"]["mfma_busy_pmc"] = mb
         if not multi and not args.no_map and not args.f32_features:
