@@ -617,7 +617,7 @@ def test_batched_gibbs_shared_presynaptic_neuron_path():
 def test_batched_gibbs_sub_block_loop_and_event_bursts():
     """k_gibbs_rate_cols: several 256-bin sub-blocks per workgroup (forced through the debug option, as the
     full-size launches have them) with a ragged tail, and presynaptic bursts that overflow the LDS event
-    staging (> 24 events per window -> the window tables are walked in global memory)."""
+    staging (> 20 events per window -> the window tables are walked in global memory)."""
     from theano_pyglm_amd import _lib
     N = 9
     for rate, nT in ((20.0, 256 * 7 + 100), (160.0, 256 * 5 + 3)):

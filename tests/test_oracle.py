@@ -241,3 +241,29 @@ def test_blocked_c_baseline_matches_reference_dataflow():
         ll, _ = CO.ll_grad_blocked(p.S, fS, p.theta, p.Weff, kind, p.dt, fstim=p.fstim, want_grad=False)
         assert np.allclose(ll, ll0, rtol=1e-12)
     assert CO.set_data_copy_seconds(fS, p.S.astype(float)) > 0
+
+
+def test_softplus_tail_table_of_the_gibbs_kernel_matches_60_digit_values():
+    """The {L0, s} rows compiled into csrc/pglm_kernels.hip.h (PGL_SPT, read by k_gibbs_rate_cols for the band
+    |x| < 12 of the softplus, glm.py:43-52) are the correctly rounded 60-digit values, and the table algorithm
+    (tools/ubench/softplus_tail_table.py, the device code's prototype) reproduces log1p(exp(-a)) to 2e-16 absolute /
+    5e-16 relative over the whole band."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('spt', os.path.join(root, 'tools', 'ubench', 'softplus_tail_table.py'))
+    spt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(spt)
+    src = open(os.path.join(root, 'theano_pyglm_amd', 'csrc', 'pglm_kernels.hip.h')).read()
+    body = src[src.index('PGL_SPT[97][2] = {'):]
+    body = body[:body.index('};')]
+    rows = re.findall(r'\{(0x[0-9a-f.]+p[+-]?\d+), (0x[0-9a-f.]+p[+-]?\d+)\}', body)
+    assert len(rows) == 97
+    T = np.array([[float.fromhex(a), float.fromhex(b)] for a, b in rows])
+    assert np.array_equal(T, spt.table())
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.uniform(0, 12.0000005, 4000), np.arange(97) / 8.0, np.arange(96) / 8.0 + 0.0625])
+    ref = spt.reference(a)
+    err = np.abs(spt.tail(a, T) - ref)
+    assert err.max() < 2e-16 and (err / ref).max() < 5e-16

@@ -2164,7 +2164,7 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
     if (K <= 0 || K > PGL_KMAX || !ll_out) return fail(PGL_ERR_ARG, "K must be in 1..16");
     HIPCHK(hipSetDevice(h->device));
     GibbsColsParams gp;
-    if (h->nlin == PGL_NLIN_EXPLINEAR && h->opt_gibbs != 1) {
+    if (h->nlin == PGL_NLIN_EXPLINEAR && h->opt_gibbs != 1 && h->Rk + PGL_GRB + 32 < 65535) {   // (16-bit event counts per window)
         // regime-split path: rate terms by k_gibbs_rate_cols (single precision for the log1p term where
         // |x| >= 12, compacted f64 elsewhere), spike terms from the event lists
         int max_ev = 0;
@@ -2181,32 +2181,22 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
         gp.hs_region = gp.CP * h->Rk;
         if (same_pre) gp.hs_region = std::max(gp.hs_region, h->B * (PGL_GRB + 2) + gp.CP * 8);
         const size_t lds = ((size_t)gp.hs_region + (size_t)gp.CP * (PGL_GRB + 2) + (size_t)gp.CP * PGL_KMAX +
-                            (size_t)4 * PGL_GQ + (size_t)128 + (size_t)gp.CP) * 8 +     // (band queue, log1p table, max |w|)
-                           (size_t)gp.CP * PGL_GECAP * 8 + (size_t)2 * gp.CP * PGL_GNL * 4 + 16;
+                            (size_t)4 * PGL_GQ + (size_t)PGL_SPT_N + (size_t)gp.CP) * 8 +     // (band queue, softplus-tail table, max |w|)
+                           (size_t)gp.CP * PGL_GECAP_R * 8 + (size_t)gp.CP * PGL_GNL * 6 + 16;
         auto rate_kernel = k_gibbs_rate_cols;
         {
             hipError_t e = ensure_dyn_lds(rate_kernel, lds);
             if (e != hipSuccess) return fail(PGL_ERR_HIP, hipGetErrorString(e));
         }
-        // sub-blocks per workgroup: the grid should fill a whole number of rounds of the CU slots the kernel really gets
-        // (occupancy query: four workgroups per CU at <= 40 KB of LDS and 128 VGPRs, three above) -- e.g. 3 136
-        // workgroups on 768 slots run 5 rounds for 4.08 rounds of work.  Among the loop lengths that still amortise the
-        // per-workgroup staging (>= PGL_GNL / 4) take the best-filled one.
+        // sub-blocks per workgroup: short loops.  The columns differ in how many of their elements fall into the f64
+        // band, so workgroups differ in run time and the dispatcher's dynamic placement has to even that out: at C4
+        // (37 504 sub-block units on 1 024 slots -- occupancy query: four workgroups per CU at <= 40 KB of LDS and 128
+        // VGPRs) loops of 3..10 sub-blocks run within 1 % of each other (1.14 ms per launch), 13 = three well-filled
+        // rounds 1.19, 16 1.25, 37 = ONE round filled to 99 % 1.23 ms (tools/r4/gibbs_nloop_scan.py).  So: at least six
+        // rounds of workgroups, loops of at most eight sub-blocks (the per-workgroup setup is amortised from ~4).
         {
             const long long slots = (long long)gibbs_rate_wg_per_cu(lds) * h->numCU;
-            int best = 1;
-            double best_fill = 0.0;
-            for (int nl = (nsub * ygroups <= slots) ? 1 : PGL_GNL; nl >= 1; --nl) {     // (fewer units than slots: one each)
-                const long long wgs = ((nsub + nl - 1) / nl) * ygroups;
-                const long long rounds = (wgs + slots - 1) / slots;
-                const double fill = (double)(nsub * ygroups) / (double)(rounds * slots * nl);
-                if (fill > best_fill + 0.02 || (nl >= PGL_GNL / 4 && fill > best_fill)) {
-                    best_fill = fill;
-                    best = nl;
-                }
-                if (nl <= PGL_GNL / 4 && best_fill > 0.0 && wgs >= slots) break;
-            }
-            gp.nloop = best;
+            gp.nloop = (int)std::max(1LL, std::min(8LL, nsub * ygroups / (6 * slots)));
         }
         if ((h->opt_dbg >> 8) & 0xf) gp.nloop = std::min(PGL_GNL, (h->opt_dbg >> 8) & 0xf);      // tests: force the sub-block loop
         const int nblk = (int)((nsub + gp.nloop - 1) / gp.nloop);

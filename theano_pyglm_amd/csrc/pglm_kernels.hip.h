@@ -3400,7 +3400,8 @@ __global__ __launch_bounds__(256) void k_gibbs_ll_cols(const GibbsColsParams p)
 //                               band-queue entries per wave (the band elements of one weight: <= PGL_GRB)
 // Occupancy of k_gibbs_rate_cols (tools/ubench/occ_gibbs_ubench.hip, hipOccupancyMaxActiveBlocksPerMultiprocessor): four
 // workgroups per CU up to 40 KB of LDS and 128 VGPRs, three up to 53 KB -- and three are 15-20 % slower.  The kernel sits
-// at 40.9 KB / ~115 VGPRs on purpose.  Measured round 3 and dropped because they cross that step or pay more than they
+// at 40 944 of 40 960 bytes at the C4 shape on purpose (which is why the staged-event cap is 20 and the event counts of
+// the windows are 16-bit: the softplus-tail table needs 1.5 KB).  Measured round 3 and dropped because they cross that step or pay more than they
 // save: 384-bin sub-blocks (six segments per weight: better filled f64 passes, 46-54 KB) 1.55 ms against 1.40; per-lane
 // accumulators for all weights in registers through the VGPR index register (164 VGPRs) 1.53 ms; a band queue whose
 // leftovers travel on to the next weights (ring of 320 / 512 entries, three lane-partial vectors in flight, a lane adds
@@ -3456,6 +3457,136 @@ __device__ __forceinline__ double pgl_log1p_tab(const double t, const double* __
     return fma(u, q, te[2]);
 }
 
+// log1p(exp(-a)) for a in [0, 12] in ONE table step (the band elements of k_gibbs_rate_cols): a0 = j / 8 with
+// j = rint(8 a), v = a0 - a (|v| <= 1/16, exact); exp(-a) = E0 (1 + m) with E0 = exp(-a0), m = expm1(v); then
+// log1p(E0 (1 + m)) = L0 + log1p(s m) with L0 = log1p(E0), s = E0 / (1 + E0) <= 1/2 from the table ({L0, s} rounded
+// from 60-digit values, 97 intervals, 1.5 KB of LDS).  expm1 to v^8 / 8! (next term 4e-17), log1p(w) to w^10 / 10
+// (|w| <= 0.0323: next term 4e-18): 26 instructions and one 16-byte LDS gather instead of exp (22) + the log1p table
+// (17); absolute error 1.1e-16, relative 2.4e-16 over the whole band (tools/ubench/softplus_tail_table.py) -- the two-step
+// form lost relative accuracy at the small end (1.3e-12).
+__constant__ double PGL_SPT[97][2] = {
+    {0x1.62e42fefa39efp-1, 0x1.0000000000000p-1},
+    {0x1.43e4055056374p-1, 0x1.e00aa6681fcf3p-2},
+    {0x1.26e18819b6b47p-1, 0x1.c054cda8768f9p-2},
+    {0x1.0bd6cffe83c7ap-1, 0x1.a11c01bf10222p-2},
+    {0x1.e5746fdb5c064p-2, 0x1.829a0565978dfp-2},
+    {0x1.b6fd4f83e1f61p-2, 0x1.65033af8acd79p-2},
+    {0x1.8c27e9bc22ee1p-2, 0x1.4885610b9b828p-2},
+    {0x1.64cea7ff8a616p-2, 0x1.2d46b08dbbfe4p-2},
+    {0x1.40c7abfbec124p-2, 0x1.136561454ba86p-2},
+    {0x1.1fe5d241cf50ap-2, 0x1.f5ef21a125693p-3},
+    {0x1.01f9b27528a73p-2, 0x1.c81702a88e0d5p-3},
+    {0x1.cda525f5dea88p-3, 0x1.9d50402c11d4ap-3},
+    {0x1.9c7e908f5420fp-3, 0x1.759b8355a1bb0p-3},
+    {0x1.701df494e71dep-3, 0x1.50ee01de5accfp-3},
+    {0x1.4823997149a9fp-3, 0x1.2f335e8e7bfd6p-3},
+    {0x1.2432d212f7c19p-3, 0x1.104f8e397f508p-3},
+    {0x1.03f2d54301d49p-3, 0x1.e84152bac31afp-4},
+    {0x1.ce1ebbd958699p-4, 0x1.b501323c9923ap-4},
+    {0x1.9a72315646266p-4, 0x1.868d2916eca5bp-4},
+    {0x1.6c4bc9f89e092p-4, 0x1.5c90d0f39da16p-4},
+    {0x1.4321e1cc6d13fp-4, 0x1.36b7112534847p-4},
+    {0x1.1e756ba481cabp-4, 0x1.14abd6d65d0fap-4},
+    {0x1.fba37405c85acp-5, 0x1.ec3ad6ad8dc42p-5},
+    {0x1.c1984593bfc32p-5, 0x1.b57ae65f9ba04p-5},
+    {0x1.8e070fc045701p-5, 0x1.848343c905445p-5},
+    {0x1.603f9ae18164ap-5, 0x1.58c85cdebca7bp-5},
+    {0x1.37a289e968854p-5, 0x1.31c8280cf1c3dp-5},
+    {0x1.13a025a280713p-5, 0x1.0f0a536457387p-5},
+    {0x1.e76e4c617c898p-6, 0x1.e040681ccad94p-6},
+    {0x1.aee7038d2fdb9p-6, 0x1.a9490c1054030p-6},
+    {0x1.7cda8b50a22e0p-6, 0x1.78761313f225ap-6},
+    {0x1.508efa245836cp-6, 0x1.4d20122a136cep-6},
+    {0x1.295e50b53b654p-6, 0x1.26afa1e43c2c3p-6},
+    {0x1.06b48b5ec3195p-6, 0x1.049c3e0cc6678p-6},
+    {0x1.d01bb028d8df0p-7, 0x1.ccd6411b606f9p-7},
+    {0x1.99e9e19c9117ep-7, 0x1.975c3eecc3be2p-7},
+    {0x1.6a033368dd9b7p-7, 0x1.680527a405c3bp-7},
+    {0x1.3fae83582545bp-7, 0x1.3e209a7daf6ebp-7},
+    {0x1.1a478703e6584p-7, 0x1.191129aaba495p-7},
+    {0x1.f27916b786f6ep-8, 0x1.f09503707a24ap-8},
+    {0x1.b818da245a728p-8, 0x1.b69f67d638f8ep-8},
+    {0x1.84898b1611fd6p-8, 0x1.8363476c064e7p-8},
+    {0x1.57008fe54624fp-8, 0x1.561b2d22850c0p-8},
+    {0x1.2eca948929bb8p-8, 0x1.2e17c9c24b717p-8},
+    {0x1.0b48ec7737a01p-8, 0x1.0abd946147067p-8},
+    {0x1.d7de797b8c899p-9, 0x1.d7054b1fc1257p-9},
+    {0x1.a082ce8a69e37p-9, 0x1.9fd992191da22p-9},
+    {0x1.6fa361566008dp-9, 0x1.6f1f8371cd3fap-9},
+    {0x1.447e35674b30ep-9, 0x1.4417772fa800fp-9},
+    {0x1.1e67dba01afadp-9, 0x1.1e17cf7f97005p-9},
+    {0x1.f991b2f527eb2p-10, 0x1.f914f977dedbfp-10},
+    {0x1.be36b6c47edb7p-10, 0x1.bdd58c8bf8274p-10},
+    {0x1.89d25404b4136p-10, 0x1.8986a2cac5fa9p-10},
+    {0x1.5b93b657d026fp-10, 0x1.5b58bfcb28afcp-10},
+    {0x1.32c26f737461cp-10, 0x1.3294815ced7f2p-10},
+    {0x1.0ebba110c6b3ap-10, 0x1.0e97da2dda510p-10},
+    {0x1.dddef4e20532bp-11, 0x1.dda738adf1189p-11},
+    {0x1.a5be000c4a797p-11, 0x1.a592965fa4d74p-11},
+    {0x1.743429ab643fap-11, 0x1.7412593d98a3dp-11},
+    {0x1.487b7c2fd5f63p-11, 0x1.486125cdb77fcp-11},
+    {0x1.21e534d42e269p-11, 0x1.21d0b15711bf3p-11},
+    {0x1.ffae1aa2932a2p-12, 0x1.ff8e263314416p-12},
+    {0x1.c391acc00d5e5p-12, 0x1.c378c9556743ap-12},
+    {0x1.8e84b36ba6fc4p-12, 0x1.8e715105830e4p-12},
+    {0x1.5fb2f67077130p-12, 0x1.5fa3dd7d2f7a6p-12},
+    {0x1.36612429519aep-12, 0x1.365561fa17242p-12},
+    {0x1.11e9e67fdfe4dp-12, 0x1.11e0be0e88435p-12},
+    {0x1.e3769e7f0229fp-13, 0x1.e3685aa39565bp-13},
+    {0x1.aaa92324cf1c1p-13, 0x1.aa9e06f8cd118p-13},
+    {0x1.7887ff5702705p-13, 0x1.787f5839d974fp-13},
+    {0x1.4c4a895394428p-13, 0x1.4c43cc2540409p-13},
+    {0x1.253fa75ada4a2p-13, 0x1.253a67bfcef61p-13},
+    {0x1.02cb0bcfccbe5p-13, 0x1.02c6f5633e446p-13},
+    {0x1.c8c588a4de48cp-14, 0x1.c8bf2ab3658e5p-14},
+    {0x1.931a243f5bc3cp-14, 0x1.93152ed323578p-14},
+    {0x1.63bd0646eb132p-14, 0x1.63b929a27ce33p-14},
+    {0x1.39f088538f3eap-14, 0x1.39ed865c5b812p-14},
+    {0x1.150d4afbd247ap-14, 0x1.150af353a9a85p-14},
+    {0x1.e8ff303b747fbp-15, 0x1.e8fb8a3233ab3p-15},
+    {0x1.af8a2784ce55bp-15, 0x1.af8750158434cp-15},
+    {0x1.7cd564c9e0d19p-15, 0x1.7cd32e41dd960p-15},
+    {0x1.5015d8f26d897p-15, 0x1.50141fba945a1p-15},
+    {0x1.28985006982c0p-15, 0x1.2896f8670de67p-15},
+    {0x1.05bea3cf0a7cdp-15, 0x1.05bd983178eb2p-15},
+    {0x1.cdfa8566527e8p-16, 0x1.cdf8e48f306f6p-16},
+    {0x1.97b201e459b7fp-16, 0x1.97b0bd4147285p-16},
+    {0x1.67ca56f970021p-16, 0x1.67c95a2556856p-16},
+    {0x1.3d83a97525d9ap-16, 0x1.3d82e48dcc901p-16},
+    {0x1.1834a8df20647p-16, 0x1.18340f85ba390p-16},
+    {0x1.ee8fd2fb90d85p-17, 0x1.ee8ee42004fc9p-17},
+    {0x1.b4731c0236f1fp-17, 0x1.b47261fc59032p-17},
+    {0x1.812a6eee7f2b6p-17, 0x1.8129de0e79531p-17},
+    {0x1.53e86693130f7p-17, 0x1.53e7f5bed75e7p-17},
+    {0x1.2bf7bff17c89dp-17, 0x1.2bf76812632a7p-17},
+    {0x1.08b88454ae341p-17, 0x1.08b83fe574842p-17},
+    {0x1.d33b116773aabp-18, 0x1.d33aa6cf71fcfp-18},
+    {0x1.9c5470b033d21p-18, 0x1.9c541dac42246p-18},
+};
+// (series coefficients by scalar loads: as literals they sit in loop-invariant VGPRs and every Horner step becomes
+//  a 64-bit move + v_fmac)
+__constant__ double PGL_SPC[16] = {1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0,
+                                   -0.1, 1.0 / 9.0, -0.125, 1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, 0.125, 0.0};
+template <typename CP>
+__device__ __forceinline__ double pgl_softplus_tail_tab(const double a, const double* __restrict__ TB, const CP C)
+{
+    const double jd = rint(a * 8.0);
+    const double v = fma(jd, C[14], -a);
+    const double* te = TB + 2 * (int)jd;
+    double q = fma(v, C[0], C[1]);
+#pragma unroll
+    for (int i = 2; i <= 5; ++i) q = fma(v, q, C[i]);
+    q = fma(v, q, 0.5);
+    q = fma(v, q, 1.0);
+    const double w = (te[1] * v) * q;
+    double pl = fma(w, C[6], C[7]);
+#pragma unroll
+    for (int i = 8; i <= 13; ++i) pl = fma(w, pl, C[i]);
+    pl = fma(w, pl, -0.5);
+    pl = fma(w, pl, 1.0);
+    return fma(w, pl, te[0]);
+}
+
 // h[c][d] = sum_b phi[b][d] * beta[n_post][n_pre][b]: the impulse response of every listed pair, once per launch
 __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams p)
 {
@@ -3469,6 +3600,12 @@ __global__ __launch_bounds__(256) void k_gibbs_cols_setup(const GibbsColsParams 
 }
 
 #define PGL_GNL 16            // at most this many sub-blocks per workgroup
+#define PGL_GECAP_R 20         // staged presynaptic events per column and sub-block (~9 at 20 Hz; more: read from HBM)
+#ifdef PGL_SPT_GLOBAL
+#define PGL_SPT_N 2
+#else
+#define PGL_SPT_N 196         // doubles of the softplus-tail table in LDS (97 x 2, padded)
+#endif
 
 // Pairwise merges of lane-partial vectors (the reduction tree of k_gibbs_rate_cols).  merge32(a, b): lanes 0..31
 // = a[l] + a[l + 32], lanes 32..63 = b[l - 32] + b[l] (v_permlane32_swap: the upper half of the first register
@@ -3561,12 +3698,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     double* X0 = HS + p.hs_region;                                  // [CP][XS] bias + I_stim + I_net of the sub-block
     double* Wl = X0 + CP * XS;                                      // [CP][PGL_KMAX]
     double* Qx = Wl + CP * PGL_KMAX;                                // [4][PGL_GQ]
-    double* TB = Qx + 4 * PGL_GQ;                                   // [32][4] log1p table (pgl_log1p_tab)
+    double* TB = Qx + 4 * PGL_GQ;                                   // [97][2] softplus-tail table (pgl_softplus_tail_tab)
     double* PS = X0;                                                // [CP * NSPLIT][PGL_KMAX] block results: X0 is dead by then
-    double* WM = TB + 128;                                          // [CP] largest |candidate weight| of the column
-    int2* evS = reinterpret_cast<int2*>(WM + CP);                   // [CP][PGL_GECAP]
-    int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP); // [CP][PGL_GNL] first event of the sub-block's window
-    int* WH = WL + CP * PGL_GNL;                                    // [CP][PGL_GNL] one past its last event
+    double* WM = TB + PGL_SPT_N;                                    // [CP] largest |candidate weight| of the column
+    int2* evS = reinterpret_cast<int2*>(WM + CP);                   // [CP][PGL_GECAP_R]
+    int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP_R); // [CP][PGL_GNL] first event of the sub-block's window
+    unsigned short* WN = reinterpret_cast<unsigned short*>(WL + CP * PGL_GNL);   // [CP][PGL_GNL] events in the window (saturating)
     const int tid = threadIdx.x;
     const long long tw0 = p.t_lo + (long long)blockIdx.x * RB * p.nloop;
     // ---- once per workgroup: impulse responses, candidate weights, event windows of every sub-block ----
@@ -3587,7 +3724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int cc = blockIdx.y * CP + i / PGL_KMAX, k = i % PGL_KMAX;
         Wl[i] = (cc < p.ncols && k < K) ? p.w[(size_t)cc * K + k] : 0.0;
     }
-    if (tid < 128) TB[tid] = (&PGL_L1PT[0][0])[tid];
+    if (tid < 194 && tid < PGL_SPT_N) TB[tid] = (&PGL_SPT[0][0])[tid];
     for (int i = tid; i < CP * PGL_GNL; i += 256) {
         const int ci = i / PGL_GNL, sb = i % PGL_GNL;
         const int cc = blockIdx.y * CP + ci;
@@ -3601,7 +3738,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             hi = p.whi[(size_t)((tb1 - 1) >> 4) * p.N + npc];
         }
         WL[i] = lo;
-        WH[i] = hi;
+        WN[i] = (unsigned short)((hi - lo < 65535) ? hi - lo : 65535);
     }
     // staging role: column ca, bins ra + j*RPB (j < NJ): eight post neurons of one bin share a 64-byte line
     const int ca = tid % CP, ra = tid / CP;
@@ -3649,13 +3786,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         } else {
-            const int lo = WL[c * PGL_GNL + sb], cnt = WH[c * PGL_GNL + sb] - lo;
-            const bool staged = cnt <= PGL_GECAP;
+            const int lo = WL[c * PGL_GNL + sb], cnt = WN[c * PGL_GNL + sb];
+            const bool staged = cnt <= PGL_GECAP_R;
             const double* hs = HS + c * R;
             const int tr = (int)tb0 + tseg - 1;                     // d = tr + 64*sg - e.x
             if (!PGL_DBG(1)) {
                 for (int q = 0; q < cnt; ++q) {
-                    const int2 e = staged ? evS[c * PGL_GECAP + q] : p.spk[lo + q];
+                    const int2 e = staged ? evS[c * PGL_GECAP_R + q] : p.spk[lo + q];
                     const double ecnt = (double)e.y;
 #pragma unroll
                     for (int sg = 0; sg < NSEG; ++sg) {
@@ -3682,7 +3819,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             bad = bad || !(fma(wmax, fabs(icr[sg]), fabs(x0r[sg])) < 699.0);
         }
         // a wave with such a lane sends every element of the item through the f64 path
-        const bool careful = __ballot(bad) != 0ull;
+        const bool careful = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        const unsigned long long all_lanes = __builtin_amdgcn_ballot_w64(true);
         double pend1 = 0.0, pend2 = 0.0, pend3 = 0.0, pend4 = 0.0;
         auto push = [&](const double tot, const int k) {            // k is wave-uniform: scalar branches
             if (!(k & 1)) { pend1 = tot; return; }
@@ -3705,6 +3843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             double x[NSEG];
             bool bl[NSEG];
             float e[NSEG];
+            unsigned long long bm[NSEG], bany = 0ull;               // band lanes of every segment (scalar masks)
 #pragma unroll
             for (int sg = 0; sg < NSEG; ++sg) x[sg] = fma(wk, icr[sg], x0r[sg]);
 #pragma unroll
@@ -3713,6 +3852,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float af = fabsf((float)x[sg]);
                 const bool f = (af >= PGL_GFAST) && !careful;
                 bl[sg] = !f;
+                // (the ballot of the bare comparison IS its SGPR result; a ballot of bl costs a v_cndmask + v_cmp)
+                const unsigned long long mc = __builtin_amdgcn_ballot_w64(!(af >= PGL_GFAST));
+                bm[sg] = careful ? all_lanes : mc;
+                bany |= bm[sg];
                 const float ee = PGL_DBG(32) ? af : __builtin_amdgcn_exp2f(af * -1.44269504088896340736f);
                 e[sg] = f ? ee : 0.0f;
             }
@@ -3726,15 +3869,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             // band elements of this weight: queued per wave, evaluated in f64 on full waves; they contribute
             // lam - max(x, 0) (the max term is already in accl)
-            bool anyb = false;
-#pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) anyb = anyb || bl[sg];
-            if (__ballot(anyb) != 0ull && !PGL_DBG(16)) {
+            if (bany != 0ull && !PGL_DBG(16)) {
                 int qn = 0;
                 double accq = 0.0;
 #pragma unroll
                 for (int sg = 0; sg < NSEG; ++sg) {
-                    const unsigned long long m = __ballot(bl[sg]);
+                    const unsigned long long m = bm[sg];
                     if (m != 0ull) {
                         const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -3745,13 +3885,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_wave_barrier();
                 for (int base = 0; base < qn; base += 64) {         // one call site: the f64 code exists once
                     const bool v = base + lane < qn;
-                    const double xq = v ? Qxw[base + lane] : 20.0;
+                    const double xq = v ? Qxw[base + lane] : 0.0;
                     double d;
                     if (!careful) {
-                        // band proper: |x| < 12 is known -- exp in f64, log1p through the table
-                        d = pgl_log1p_tab(pgl_exp(-fabs(xq), PGL_C), TB);
+                        // band proper: |x| < 12 is known (single-precision test: <= 12 + 1e-6, table index <= 96)
+#ifdef PGL_SPT_GLOBAL
+                        d = pgl_softplus_tail_tab(fabs(xq), &PGL_SPT[0][0], (pgl_k_cdp)PGL_SPC);
+#else
+                        d = pgl_softplus_tail_tab(fabs(xq), TB, (pgl_k_cdp)PGL_SPC);
+#endif
                     } else {
-                        const double lam = pgl_lambda_only(xq, 1, PGL_C);
+                        const double* cg = PGL_C;
+                        asm volatile("" : "+s"(cg));       // rare path: its scalar loads stay in here
+                        const double lam = pgl_lambda_only(xq, 1, cg);
                         // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700
                         // (incl. +inf): lam = x, nothing beyond the max term
                         d = (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
@@ -3782,10 +3928,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 FS[b * XS + tt] = (tt < nb && !PGL_DBG(4)) ? p.fs[(size_t)b * p.fs_stride + (tb0 - p.t_lo) + tt] : 0.0;
             }
         } else {
-            for (int i = tid; i < CP * PGL_GECAP; i += 256) {
-                const int ci = i / PGL_GECAP, j = i % PGL_GECAP;
-                const int lo = WL[ci * PGL_GNL + sb], cnt = WH[ci * PGL_GNL + sb] - lo;
-                if (cnt <= PGL_GECAP && j < cnt && !PGL_DBG(4)) evS[i] = p.spk[lo + j];
+            for (int i = tid; i < CP * PGL_GECAP_R; i += 256) {
+                const int ci = i / PGL_GECAP_R, j = i % PGL_GECAP_R;
+                const int lo = WL[ci * PGL_GNL + sb], cnt = WN[ci * PGL_GNL + sb];
+                if (cnt <= PGL_GECAP_R && j < cnt && !PGL_DBG(4)) evS[i] = p.spk[lo + j];
             }
         }
         if (ra < RPB) {
