@@ -211,7 +211,8 @@ def mcmc_inner_ll(S, N, dt):
             "finite_fraction": float(np.isfinite(ll).mean()),
             "sweep_s": sweeps[1], "first_sweep_s": sweeps[0], "pairs_per_sweep": N * N,
             "ars_launches_last_sweep": upd.n_ars_evals,
-            "kernels": "k_gibbs_rate_cols (max(x,0) in f64 + log1p(exp(-|x|)) in f32 where |x| >= 12, compacted f64 band) + "
+            "kernels": "k_gibbs_rate_cols (max(x,0) in f64 + log1p(exp(-|x|)) in f32 where |x| >= 12, compacted f64 band "
+                       "through a one-step table) + "
                        "k_gibbs_spike_cols"}
 
 

@@ -47,6 +47,7 @@ python3 tools/gibbs_kernel_only.py 2>&1 | tail -5 | tee $R/r04_gibbs_launch.txt
 python3 tools/gibbs_x_hist.py 2>&1 | tail -11 > $R/r04_gibbs_x_hist.txt
 PYGLM_HIP_LIB=$L/libpyglm_hip_ablate.so python3 tools/gibbs_ablate.py 2>&1 | grep "^dbg" | tee $R/r04_gibbs_ablation.txt
 python3 tools/gibbs_sweep_profile.py 2>&1 | tail -7 | tee $R/r04_gibbs_sweep.txt
+python3 tools/r4/gibbs_nloop_scan.py 2>&1 | grep nloop > $R/r04_gibbs_nloop_scan.txt
 ./tools/ubench/occ_gibbs_ubench 2>&1 | grep "workgroups\|shared" | tee $R/r04_gibbs_occupancy.txt
 echo "== VALU issue costs (tools/ubench/valu_rates_ubench.hip)"
 ./tools/ubench/valu_rates_ubench 2>&1 | grep "waves/WG 16" | tee $R/r04_valu_issue_costs.txt
