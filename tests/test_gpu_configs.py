@@ -794,3 +794,60 @@ def test_map_lockstep_dirichlet_impulses():
         # only sees g / sum|g| -- the MAP of this model is not attained and both optimizers stop on the way there;
         # the reference fits it by Gibbs sampling, test/synth_mcmc.py)
     popn.release_data()
+
+
+def test_long_recording_offsets_beyond_2_31_elements():
+    """Maximum sizes: a recording 7.5 times the length of C3 (N = 128, nT = 4 500 000: 23.6 GB of resident feature
+    tiles = 2.9e9 f64 elements, so element offsets leave the 32-bit range; `tools/r4/long_recording.py` ran the same
+    checks at 24 000 000 bins = 126 GB).  No oracle follows the whole of it in reasonable time, so: the first and the
+    LAST 300 000 bins through pgl_set_time_range are bit-identical to fresh handles built from those bins (plus their
+    history), the time ranges add up to the whole, and the numpy oracle agrees on 2 048 bins near the end."""
+    N, nT, L, H0 = 128, 4500000, 300000, 208
+    ib = H.std_ibasis()
+    R, B = ib.shape
+    P = 1 + N * B
+    rng = np.random.default_rng(77)
+    S = np.empty((nT, N), dtype=np.uint8)
+    for i in range(0, nT, 500000):
+        S[i:i + 500000] = np.minimum(rng.poisson(0.02, size=(500000, N)), 10)
+    theta = np.zeros((N, P))
+    theta[:, 0] = 20.0 + 0.1 * rng.standard_normal(N)
+    theta[:, 1:] = 0.5 * rng.standard_normal((N, N * B))
+    Weff = np.ones((N, N))
+
+    def handle(Sx):
+        d = _lib.DeviceGlm(N, Sx.shape[0], B, R, 'explinear', 0.001)
+        d.set_spikes(Sx)
+        d.set_basis(ib)
+        return d
+
+    big = handle(S)
+    ll, g = big.ll_grad(theta, Weff)
+    assert big.info()['kernel_version'] == 5 and np.all(np.isfinite(ll)) and np.all(np.isfinite(g))
+    ll_s, g_s = np.zeros(N), np.zeros((N, P))
+    for i in range(0, nT, 900000):
+        big.set_time_range(i, i + 900000)
+        a, b = big.ll_grad(theta, Weff)
+        ll_s += a
+        g_s += b
+    assert np.allclose(ll_s, ll, rtol=1e-13) and H.rel_err(g_s, g) < 1e-13
+    for lo in (0, nT - L):
+        big.set_time_range(lo, lo + L)
+        a, b = big.ll_grad(theta, Weff)
+        h0 = min(H0, lo)
+        small = handle(S[lo - h0:lo + L])
+        small.set_time_range(h0, h0 + L)
+        a1, b1 = small.ll_grad(theta, Weff)
+        small.close()
+        assert np.array_equal(a, a1) and np.array_equal(b, b1)
+    t_hi = nT - 992
+    t_lo = t_hi - 2048
+    big.set_time_range(t_lo, t_hi)
+    a, b = big.ll_grad(theta, Weff)
+    big.close()
+    Ssub = S[t_lo - R:t_hi].astype(float)
+    fS = O.convolve_with_basis(Ssub, ib)[R:]
+    for n in (0, 77, 127):
+        l0, gb, _, gw = O.glm_ll_grad(n, Ssub[R:], fS, theta[n, 1:].reshape(N, B), Weff[:, n], theta[n, 0], 0.001, 'explinear')
+        assert np.isclose(a[n], l0, rtol=LL_RTOL)
+        assert H.rel_err(b[n], np.concatenate(([gb], gw.ravel()))) < G_RTOL

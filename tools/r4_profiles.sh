@@ -72,6 +72,8 @@ echo "== bench.py --gpus 2 starting its own ranks (one GPU, gloo): time-sharded 
 python3 bench.py --gpus 2 --debug-single-device --steps 10 --warmup 3 2>/dev/null | tail -1 | tee $R/r04_self_launch_two_ranks.json | cut -c1-400
 echo "== hipGraph replay against stream launches"
 python3 tools/r4/graph_step.py 2>&1 | grep "^N=" | tee $R/r04_graph_replay.txt
+echo "== a recording 40 times the length of C3 (126 GB of resident tiles)"
+python3 tools/r4/long_recording.py 24000000 2>&1 | grep -v amdgpu.ids | tail -9 | tee $R/r04_long_recording.txt
 echo "== bench.py multi-rank path on RCCL, one rank"
 for sh in time neurons; do python3 bench.py --rccl-selftest --shard $sh --steps 20 --warmup 3 2>/dev/null | tail -1; done | tee $R/r04_rccl_selftest.jsonl | cut -c1-300
 echo "== GPU test suite"
