@@ -407,14 +407,15 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     }
 
 
-def self_launch(n):
+def self_launch(n, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, env
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's record.  Runs before torch / HIP are imported: the
     parent never initialises a GPU, the children are plain Popen processes (no exec from a GPU process)."""
     import socket
     import subprocess
-    import __graft_entry__ as ge
-    ge.build_hip()                                  # once, here: the ranks find the library fresh
+    if script is None:
+        import __graft_entry__ as ge
+        ge.build_hip()                              # once, here: the ranks find the library fresh
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -422,19 +423,37 @@ def self_launch(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0] or ''
+    # rank 0's stdout is drained by a thread; the parent watches the ranks: one that fails takes the others down (its
+    # own children, by PID) instead of leaving them in a collective until the communicator times out
+    import threading
+    import time as _time
+    chunks, killed = [], set()
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    while any(pr.poll() is None for pr in procs):
+        if any(pr.poll() not in (None, 0) for pr in procs):
+            _time.sleep(2.0)                        # (ranks that fail together, e.g. no GPU each, report their own codes)
+            for i, pr in enumerate(procs):
+                if pr.poll() is None:
+                    pr.kill()
+                    killed.add(i)
+            break
+        _time.sleep(0.2)
     codes = [pr.wait() for pr in procs]
+    rd.join(timeout=10.0)
+    out0 = ''.join(c or '' for c in chunks)
     lines = [ln for ln in out0.splitlines() if ln.strip()]
-    for ln in lines[:-1]:
+    rec = lines[-1:] if codes[0] == 0 else []       # a rank 0 that did not finish has no record
+    for ln in lines[:len(lines) - len(rec)]:
         sys.stderr.write(ln + '\n')                 # anything rank 0 printed before its record (library banners)
-    if lines:
-        print(lines[-1], flush=True)
-    bad = [c for c in codes if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
-        return 3 if 3 in bad else bad[0]
+    if rec:
+        print(rec[0], flush=True)
+    bad = [c for i, c in enumerate(codes) if c != 0 and i not in killed]      # the ranks that failed by themselves
+    if bad or killed:
+        sys.stderr.write("bench.py: rank exit codes %s%s\n" % (codes, (" (ended by the parent: ranks %s)" % sorted(killed)) if killed else ""))
+        return 3 if 3 in bad else (bad[0] if bad else 1)
     return 0
 
 

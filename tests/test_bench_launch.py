@@ -33,3 +33,26 @@ def test_bench_without_gpus_fails_loudly_in_every_launch_form():
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0'], cwd=ROOT, env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and 'rank 1 needs GPU 1' in r.stderr
+
+
+def test_self_launch_takes_the_other_ranks_down_when_one_fails(tmp_path):
+    """One rank dies (exit code 5) while the others would sit in a collective: the parent ends them (its own children,
+    by PID) within seconds and reports the failing code; a clean run relays rank 0's last line."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if mode == 'fail' and r == 1:\n"
+        "    sys.exit(5)\n"
+        "if mode == 'fail':\n"
+        "    time.sleep(120)\n"
+        "print('banner of rank %d' % r)\n"
+        "print('{\"record\": %d}' % r)\n")
+    t0 = time.time()
+    assert bench.self_launch(3, script=str(script), argv=['fail']) == 5
+    assert time.time() - t0 < 30.0
+    assert bench.self_launch(3, script=str(script), argv=['ok']) == 0
