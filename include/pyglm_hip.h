@@ -127,8 +127,10 @@ int pgl_get_stim_features(pgl_handle h, double* fstim_out);
  * bins with Rt = 300 qualify) the evaluation runs at the FRAME rate: the interpolated projection is piecewise
  * linear over q-bin frames, so the Rt taps of a bin collapse to <= 8 frame values through a coefficient table
  * built here (k_sepf_fwd / k_sepf_bwd), and the impulse columns run on resident feature tiles -- for neuron ranges
- * and neuron lists of up to 128 neurons; other ratios and populations of more than 128 neurons keep the tap-rate
- * kernels (same results to 1e-12; pgl_info[12] tells which). */
+ * and neuron lists of up to 128 neurons (up to 64 neurons, <= 3 temporal bases, <= 5 frame values and q >= 16 the
+ * stimulus current is five more k-steps of the fused kernel's forward contraction instead of a kernel of its own);
+ * other ratios and populations of more than 128 neurons keep the tap-rate kernels (same results to 1e-12;
+ * pgl_info[12] tells which). */
 int pgl_set_stimulus_separable(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim,
                                const double* basis_x, int Bx, const double* basis_t, int Rt, int Bt);
 

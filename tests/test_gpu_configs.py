@@ -201,6 +201,13 @@ def test_c5_stress_full_size_separable():
     lm, _ = dev.ll_grad(th - eps * drc, p.Weff, want_grad=False)
     an = np.sum(g * drc, axis=1)
     assert np.max(np.abs((lp - lm) / (2 * eps) - an)) < 1e-5 * np.max(np.abs(an))
+    # the stimulus current through the slab (k_sepf_fwd) instead of five k-steps of the fused kernel's forward
+    # contraction: the same numbers to rounding, and NOT bit-identical (i.e. the default really is the fused forward)
+    dev.set_option(94, 3)
+    assert dev.info()['stim_path'] == 2
+    ll_b, g_b = dev.ll_grad(th, p.Weff)
+    dev.set_option(94, 0)
+    assert np.allclose(ll, ll_b, rtol=1e-12) and H.rel_err(g, g_b) < 1e-11 and not np.array_equal(g, g_b)
     # the tap-rate kernels (300 taps per bin, 3-phase path) on the whole recording
     dev.set_option(94, 2)
     assert dev.info()['stim_path'] == 1

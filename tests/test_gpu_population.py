@@ -515,6 +515,10 @@ def test_separable_stimulus_frame_rate_kernels():
             assert np.max(np.abs(d_g.cpu().numpy() - g_f[idx])) < 1e-10 * np.max(np.abs(g_f)), N
         sep.set_time_range(0, nT - 37)
         a37, b37 = sep.ll_grad(th_s, p.Weff)
+        # the stimulus current through the slab (option 94 = 3) instead of inside the forward contraction (<= 64 neurons)
+        sep.set_option(94, 3)
+        a37b, b37b = sep.ll_grad(th_s, p.Weff)
+        assert np.allclose(a37, a37b, rtol=1e-12) and H.rel_err(b37, b37b) < 1e-11
         # the tap-rate kernels on the same handle
         sep.set_option(94, 2)
         assert sep.info()['stim_path'] == 1
@@ -596,7 +600,7 @@ def test_separable_stimulus_frame_rate_randomised_shapes():
     than the recording, random neuron ranges and time ranges."""
     from tests import helpers as H
     rng = np.random.RandomState(2024)
-    done = 0
+    done = fused = 0
     while done < 14:
         Rt = int(rng.choice([20, 47, 100, 233, 300]))
         q = int(rng.randint(max(2, -(-Rt // 6)), 151))
@@ -623,16 +627,23 @@ def test_separable_stimulus_frame_rate_randomised_shapes():
         t_hi = int(rng.randint(t_lo + 1, nT + 1))
         dev.set_time_range(t_lo, t_hi)
         ll_f, g_f = dev.ll_grad(th[n_lo:n_hi], p.Weff, n_lo, n_hi)
+        case = (Rt, q, Bt, N, nT, D, Bx, Tstim, n_lo, n_hi, t_lo, t_hi)
+        # option 94 = 3: the stimulus current through the slab; where the default put it into the forward contraction
+        # (<= 64 listed neurons, <= 3 temporal bases, <= 5 frame values, frames of >= 16 bins) the bits differ
+        dev.set_option(94, 3)
+        ll_b, g_b = dev.ll_grad(th[n_lo:n_hi], p.Weff, n_lo, n_hi)
+        assert np.allclose(ll_f, ll_b, rtol=1e-11, atol=1e-12) and H.rel_err(g_f, g_b) < 1e-10, case
+        fused += int(not np.array_equal(g_f, g_b))
         dev.set_option(94, 2)
         assert dev.info()['stim_path'] == 1
         ll_t, g_t = dev.ll_grad(th[n_lo:n_hi], p.Weff, n_lo, n_hi)
-        case = (Rt, q, Bt, N, nT, D, Bx, Tstim, n_lo, n_hi, t_lo, t_hi)
         assert np.allclose(ll_f, ll_t, rtol=1e-11, atol=1e-12), case
         assert H.rel_err(g_f, g_t) < 1e-10, case
         assert np.all(np.isfinite(ll_f)) and np.any(g_f[:, 1:1 + Bt] != 0.0) and np.any(g_f[:, 1 + Bt:1 + Bt + Bx] != 0.0), case
         print("frame-rate vs tap-rate, case", case, "max rel grad diff %.1e" % H.rel_err(g_f, g_t))
         dev.close()
         done += 1
+    assert fused >= 3, fused
 
 
 def test_lockstep_map_separable_stimulus_row_kernels_and_lists():

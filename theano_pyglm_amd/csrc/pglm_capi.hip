@@ -76,8 +76,10 @@ struct pgl_context {
     // values per bin): coefficient table C[q (M + 1)][sepJ][sepBTp], see k_sepf_fwd
     bool sepf = false;
     int sepq = 0, sepM = 0, sepJ = 0, sepBTp = 0;
-    DevBuf sepC, YfT, Hb, wpart, QvT;
-    int opt_sepf = 0;                    // dev option 94: 2 = never take the frame-rate path
+    int sepNH = 0, sepGs = 0;            // A-fragment table of the fused forward (k_fused7<.., 2>): head tiles, log2 gcd(q, 16)
+    bool sepA_ok = false;
+    DevBuf sepC, sepA, YfT, Hb, wpart, QvT;
+    int opt_sepf = 0;                    // dev option 94: 2 = never take the frame-rate path, 3 = stimulus current through the slab (k_sepf_fwd)
     const int* cur_pidx = nullptr;       // post-neuron list of the evaluation being enqueued (device)
     int gibbs_npost = -1;
     double gibbs_bias = 0;
@@ -677,9 +679,24 @@ static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStre
 }
 
 // slab-input form (separable stimulus at the frame rate): 4-wave workgroups only
-static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipStream_t s)
+static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipStream_t s, int xio = 1)
 {
     if (pl.nw7 != 4) return hipErrorInvalidValue;
+    if (xio == 2) {                              // stimulus current inside the forward contraction
+        switch (pl.KT) {
+        case 1: return launch_fused7_t<1, 4, 2>(pl, fp, s);
+        case 2: return launch_fused7_t<2, 4, 2>(pl, fp, s);
+        case 3: return launch_fused7_t<3, 4, 2>(pl, fp, s);
+        case 5: return launch_fused7_t<5, 4, 2>(pl, fp, s);
+        case 7: return launch_fused7_t<7, 4, 2>(pl, fp, s);
+        case 10: return launch_fused7_t<10, 4, 2>(pl, fp, s);
+        case 12: return launch_fused7_t<12, 4, 2>(pl, fp, s);
+        case 13: return launch_fused7_t<13, 4, 2>(pl, fp, s);
+        case 16: return launch_fused7_t<16, 4, 2>(pl, fp, s);
+        case 20: return launch_fused7_t<20, 4, 2>(pl, fp, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.KT) {
     case 1: return launch_fused7_t<1, 4, 1>(pl, fp, s);
     case 2: return launch_fused7_t<2, 4, 1>(pl, fp, s);
@@ -812,7 +829,7 @@ int pgl_destroy(pgl_handle h)
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
-                      &h->spart, &h->sepC, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
+                      &h->spart, &h->sepC, &h->sepA, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
@@ -1097,6 +1114,44 @@ static int build_frame_table(pgl_handle h, const double* basis_t, int Rt, int Bt
     }
     ENSURE(h->sepC, C.size() * 8);
     HIPCHK(hipMemcpyAsync(h->sepC.p, C.data(), C.size() * 8, hipMemcpyHostToDevice, h->stream));
+    // A fragments of the fused forward (k_fused7<.., XIO = 2>): for a 16-bin tile that starts at bin t0 (frame F0, base =
+    // max(F0 - M, 0)) the coefficient of bin t0 + i on column (j', bt) of [w_t (x) z][base + j'] is
+    // C[row(t0 + i)][j' - (base(F_i) - base)][bt]; it depends on t0 only through t0 mod q once F0 >= M (phases of
+    // gcd(q, 16) bins), the tiles before that get their own entries.  MFMA A layout: lane l holds row l & 15, column
+    // 4 s + (l >> 4) of k-step s.  (J + 1) Bt <= 18 columns = five k-steps; q >= 16 so that a tile spans two frames at most.
+    h->sepA_ok = false;
+    if (Jp == 5 && BTp == 3 && q >= 16 && (J + 1) * Bt <= 18) {
+        int gs = 0;
+        while (gs < 4 && (q % (2 << gs)) == 0) ++gs;                   // gcd(q, 16) = 1 << gs
+        const long long g = 1ll << gs, NH = (q * M + 15) / 16, NP = q / g;
+        std::vector<double> A((size_t)(NH + NP) * 5 * 64, 0.0);
+        for (long long e = 0; e < NH + NP; ++e) {
+            // a representative first bin: the tile itself in the head, else the first tile behind the head with this phase
+            long long t0 = 16 * e;
+            if (e >= NH) {
+                const long long o0 = (e - NH) * g;
+                t0 = -1;
+                for (long long c = NH; c < NH + 2 * q; ++c)
+                    if ((16 * c) % q == o0) { t0 = 16 * c; break; }
+                if (t0 < 0) continue;                                   // (phase never occurs)
+            }
+            const long long F0 = t0 / q, base0 = std::max<long long>(F0 - M, 0);
+            for (int i = 0; i < 16; ++i) {
+                const long long t = t0 + i, F = t / q, o = t - F * q, dlt = std::max<long long>(F - M, 0) - base0;
+                const double* crow = C.data() + (size_t)((std::min(F, M)) * q + o) * Jp * BTp;
+                for (long long j = 0; j < J; ++j)
+                    for (int bt = 0; bt < Bt; ++bt) {
+                        const long long k = (j + dlt) * 3 + bt;          // column (j', bt), j' = j + dlt <= J
+                        A[((size_t)e * 5 + k / 4) * 64 + (k % 4) * 16 + i] = crow[j * BTp + bt];
+                    }
+            }
+        }
+        ENSURE(h->sepA, A.size() * 8);
+        HIPCHK(hipMemcpyAsync(h->sepA.p, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->sepNH = (int)NH; h->sepGs = gs;
+        h->sepA_ok = true;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->sepq = (int)q; h->sepM = (int)M; h->sepJ = Jp; h->sepBTp = BTp;
     h->sepf = true;
@@ -1225,7 +1280,7 @@ static int launch_sepf_any(pgl_handle h, int which, const SepfParams& sp)
 
 // separable stimulus at the frame rate, forward: the slab Xbuf[tile - tile0][post tile][r][lane] = I_stim of the
 // npost rows of d_theta on the plan's tile range
-static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, SepfParams& sp)
+static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, SepfParams& sp, bool fused_fwd)
 {
     const int P = 1 + h->Dstim + h->Kimp, ldy = pl.nPT * 16;
     ENSURE(h->YfT, (size_t)h->sepT * ldy * 8);
@@ -1248,6 +1303,7 @@ static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, Sep
     sp.tile0 = pl.tile0; sp.nTiles = pl.nTiles; sp.Tstim = h->sepT;
     const long long tb = (long long)pl.tile0 * 16, te = tb + (long long)pl.nTiles * 16;
     sp.F0 = tb / h->sepq; sp.F1 = (te - 1) / h->sepq;
+    if (fused_fwd) return PGL_OK;               // the stimulus current is five k-steps of the fused kernel (k_fused7<.., 2>)
     return launch_sepf_any(h, 0, sp);
 }
 
@@ -1360,6 +1416,8 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.Dstim = sl.Ds; fp.Kimp = sl.Ns * h->B; fp.Ktot = fp.Kimp + sl.Ds; fp.dt = h->dt;
     fp.Nall = h->N; fp.np0 = sl.np0; fp.DsAll = h->Dstim; fp.ds0 = sl.ds0;
     fp.mode = mode; fp.Xbuf = (double*)h->Xbuf.p; fp.xstride = pl.nPT * 16;
+    fp.sepA = nullptr; fp.sepZ = nullptr; fp.sepTheta = nullptr; fp.sepT = 0;
+    fp.sepLdy = fp.sepQ = fp.sepM = fp.sepNH = fp.sepG = fp.sepBt = 0;
     fp.spk = (const int2*)h->spk.p; fp.wlo = (const int*)h->wlo.p; fp.whi = (const int*)h->whi.p;
     fp.S = (const uint8_t*)h->S.p; fp.fstim = (const double*)h->fstim.p; fp.phi = (const double*)h->phi.p;
     fp.Wfrag = (const double*)h->Wfrag.p; fp.bias = (const double*)h->bias.p;
@@ -1525,7 +1583,9 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         if (rc) return rc;
         if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepfParams sp;
-        rc = sepf_forward(h, pl, d_theta, sp);
+        // up to four post tiles with the (5, 3) table: the stimulus current rides in the forward contraction
+        const bool fused_fwd = pl.version == 7 && h->sepA_ok && h->opt_sepf != 3;
+        rc = sepf_forward(h, pl, d_theta, sp, fused_fwd);
         if (rc) return rc;
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
@@ -1533,12 +1593,17 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             fp.theta = d_theta;
             fp.Weff = d_Weff;
         }
+        if (fused_fwd) {
+            fp.sepA = (const double*)h->sepA.p; fp.sepZ = sp.YfT; fp.sepTheta = d_theta; fp.sepT = h->sepT;
+            fp.sepLdy = sp.ldy; fp.sepQ = h->sepq; fp.sepM = h->sepM; fp.sepNH = h->sepNH; fp.sepG = h->sepGs;
+            fp.sepBt = h->sepBt;
+        }
         hipError_t e = hipSuccess;
         if (pl.version == 5) {                   // pass 1 (slab in, residuals out) and, for the gradient, pass 2
             e = launch_fused5_xin(pl, fp, h->stream, 1);
             if (e == hipSuccess && d_grad) e = launch_fused5_xin(pl, fp, h->stream, 2);
         } else {
-            e = launch_fused7_xio(pl, fp, h->stream);
+            e = launch_fused7_xio(pl, fp, h->stream, fused_fwd ? 2 : 1);
         }
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
         if (d_grad) {

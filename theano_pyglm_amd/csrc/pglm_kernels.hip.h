@@ -142,6 +142,14 @@ struct FusedParams {
     const double* __restrict__ Weff;
     int P;
     int epi64;                           // 2: all-f64 rate epilogue (PGL_OPT_EPI_F64), 0: default (see pgl_rate4)
+    // separable stimulus at the frame rate INSIDE the forward contraction (k_fused7<.., XIO = 2>): the stimulus current
+    // of a tile is five more k-steps, A = coefficient rows of the tile's 16 bins (sepA, by tile phase), B = w_t (x) z
+    const double* __restrict__ sepA;     // [sepNH + q / gcd(q, 16)][5][64] A fragments (build_frame_table)
+    const double* __restrict__ sepZ;     // [Tstim][sepLdy] frame-rate projections z_n of the listed rows (YfT)
+    const double* __restrict__ sepTheta; // (npost, P): w_t = columns 1 .. 3
+    long long sepT;                      // stimulus frames
+    int sepLdy, sepQ, sepM, sepNH, sepG; // NH head tiles with their own A fragments, gcd(q, 16) = 1 << sepG
+    int sepBt;                           // temporal bases in use (<= 3)
 };
 
 // The Wmat B fragments (k-steps ks0 .. ks0 + NS - 1, lane group grp) of local post neuron nloc, as k_prep_w would
@@ -2414,6 +2422,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
 // ---------------------------------------------------------------------------
 // XIO = 1: the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] (the stimulus current of a separable
 // stimulus, k_sepf_fwd) and the residuals r = d ll / d x are written back to the same slab (for k_sepf_bwd)
+// XIO = 2: the stimulus current is part of the forward contraction instead (no k_sepf_fwd launch, no slab read): with
+// F0 the frame of the tile's first bin and base = max(F0 - M, 0), bin i of the tile (frame F0 or F0 + 1) has
+//   I_stim[i][n] = sum_{j' <= J, bt} A[i][(j', bt)] * w_t[n][bt] z_n[min(base + j', Tstim - 1)],
+//   A[i][(j', bt)] = C[row(t0 + i)][j' - (base(F_i) - base)][bt]
+// -- (J + 1) Bt = 18 columns = five k-steps whose A fragments depend on the tile only through t0 mod q (head tiles
+// apart) and come from a table (p.sepA), the B fragments are five gathers of z and a multiply; residuals out as XIO = 1
 template <int KT, int NWV, int XIO = 0>
 __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
 {
@@ -2475,9 +2489,22 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         }
     }
     unsigned scb[4] = {0u, 0u, 0u, 0u}, scn[4] = {0u, 0u, 0u, 0u};
-    double xib[XIO ? 4 : 1], xin[XIO ? 4 : 1];
+    double xib[XIO == 1 ? 4 : 1], xin[XIO == 1 ? 4 : 1];
     double* const xslab = XIO ? p.Xbuf + (size_t)(active ? pt : 0) * 256 + lane : nullptr;
     const size_t xstride = (size_t)p.nPT * 256;
+    // XIO = 2: the lane's five B entries are (j', bt) = divmod(4 s + grp, 3) of its neuron
+    constexpr int SF = (XIO == 2) ? 5 : 1;
+    double sfa[SF], sfz[SF], sfw[SF];
+    int sfj[SF], sepF = 0, sepO = 0;
+    if constexpr (XIO == 2) {
+#pragma unroll
+        for (int s = 0; s < SF; ++s) {
+            const int k = 4 * s + grp;
+            sfj[s] = k / 3;
+            sfw[s] = (valid_n && k < 18 && k - 3 * (k / 3) < p.sepBt) ? p.sepTheta[(size_t)nloc * p.P + 1 + (k - 3 * (k / 3))] : 0.0;
+            sfa[s] = sfz[s] = 0.0;
+        }
+    }
     auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2485,10 +2512,38 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             const long long tc = (tg < p.nT) ? tg : (p.nT - 1);
             dst[r] = p.S[tc * p.Nall + nglob];
         }
-        if constexpr (XIO != 0) {
+        if constexpr (XIO == 1) {
             const double* xs_ = xslab + (size_t)(tile - p.tile0) * xstride;
 #pragma unroll
             for (int r = 0; r < 4; ++r) xin[r] = xs_[r * 64];
+        }
+    };
+    // XIO = 2: A fragments and z of a tile are requested when the tile starts and used behind its K loop
+    auto load_stim = [&](const int tile) {
+        if constexpr (XIO == 2) {
+            // frame and offset of the tile's first bin: one division per chunk, then increments (q >= 16)
+            if (tile == tile_beg) {
+                const int tb = tile * TT;
+                sepF = tb / p.sepQ;
+                sepO = tb - sepF * p.sepQ;
+            } else {
+                sepO += TT;
+                if (sepO >= p.sepQ) {
+                    sepO -= p.sepQ;
+                    ++sepF;
+                }
+            }
+            const int ph = (tile < p.sepNH) ? tile : p.sepNH + (sepO >> p.sepG);
+            const long long base = (sepF > p.sepM) ? sepF - p.sepM : 0;
+            const double* ap = p.sepA + (size_t)ph * (SF * 64) + lane;
+            const double* zp = p.sepZ + (valid_n ? nloc : 0);
+#pragma unroll
+            for (int s = 0; s < SF; ++s) {
+                long long f = base + sfj[s];
+                f = (f < p.sepT) ? f : p.sepT - 1;
+                sfa[s] = ap[s * 64];
+                sfz[s] = zp[(size_t)f * p.sepLdy];
+            }
         }
     };
     if (tile_beg < tile_end) {
@@ -2507,10 +2562,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         PGL_PROF_MARK(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) scb[r] = scn[r];
-        if constexpr (XIO != 0) {
+        if constexpr (XIO == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xib[r] = xin[r];
         }
+        load_stim(tile);
         // the image of the next tile: PWV pieces of 1 KiB per wave, issued between the MFMAs (PGL_DMA_IL) of the
         // forward loop when the Wmat fragments live in registers -- with the streamed Wmat ring a DMA in flight
         // would sit in front of the ring loads in the in-order vmcnt queue -- else of the backward loop; waves
@@ -2593,6 +2649,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 }
             }
         }
+        if constexpr (XIO == 2) {                         // the stimulus current: five more k-steps
+#pragma unroll
+            for (int s = 0; s < SF; ++s) {
+                if (s & 1)
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s] * sfw[s], acc1, 0, 0, 0);
+                else
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s] * sfw[s], acc0, 0, 0, 0);
+            }
+        }
         PGL_PROF_MARK(3);
         // ---- epilogue on the accumulator registers ----
         if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(PGL_EPI_PRIO);
@@ -2603,7 +2668,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 double xs[4], term4 = 0.0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
-                if constexpr (XIO != 0) {
+                if constexpr (XIO == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xs[r] += xib[r];
                 }
@@ -2628,7 +2693,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * h2 + e;
                         xe[e] = bias_l + (acc0[r] + acc1[r]);
-                        if constexpr (XIO != 0) xe[e] += xib[r];
+                        if constexpr (XIO == 1) xe[e] += xib[r];
                         se[e] = (double)scb[r];
                         const long long tg = (long long)t0 + grp + 4 * r;
                         vte[e] = valid_n && (tg < p.t_hi);
