@@ -148,11 +148,14 @@ def map_wall_clock(S, N, dt):
             "neurons_converged_gtol": getattr(popn, 'last_fit_stats', {}).get('converged_gtol'),
             "neurons_stalled": getattr(popn, 'last_fit_stats', {}).get('stalled'),
             "neurons_at_maxiter": getattr(popn, 'last_fit_stats', {}).get('maxiter'),
-            "optimizer": "lock-step batched BFGS (per-neuron line-search state machines, one launch per pending trial of "
-                         "the listed neurons; bookkeeping: %s, active set read back %s launch(es) late: no host sync per "
-                         "launch), initial inverse-Hessian scaling %s, maxiter 225, gtol 1e-5, GPU-resident state on one "
-                         "stream" % (stats.get('bookkeeping', 'n/a'), stats.get('lag', 'n/a'),
-                                     's.y/y.y' if stats.get('init_scaling') else 'none (identity)')}
+            "line_search_steps": stats.get('line_search_steps'), "neuron_iterations": stats.get('neuron_iterations'),
+            "optimizer": "lock-step batched BFGS = scipy's algorithm for every neuron at once (H0 = I, More'-Thuente "
+                         "strong-Wolfe search with scipy's constants and first trial step; one fused ll+grad launch per pending "
+                         "trial step of the listed neurons; bookkeeping: %s, one read-modify-write pass over the dense inverse "
+                         "Hessians per accepted iteration; active set read back %s launch(es) late: no host sync per launch), "
+                         "initial inverse-Hessian scaling %s, maxiter 225, gtol 1e-5, GPU-resident state on one stream"
+                         % (stats.get('bookkeeping', 'n/a'), stats.get('lag', 'n/a'),
+                            's.y/y.y' if stats.get('init_scaling') else 'none (identity)')}
 
 
 def mcmc_inner_ll(S, N, dt):
@@ -228,7 +231,7 @@ def st_ibasis(key, R=300, dt=0.001):
     return ib / (R * dt)
 
 
-def stim_stress(reps=20, with_map=False):
+def stim_stress(reps=20, with_map=True):
     """Secondary block for BASELINE config 5 ("stimulus-conv kernel stressed"): SURVEY 8(d)'s stress variant --
     spatiotemporal_glm N=64, T=300 s, D_stim=1024 pixels, identity spatial basis, Bt=3, frames of 100 bins -- on the
     separable device path (frame-rate stimulus kernels + impulse columns on resident tiles), ll+grad per evaluation,
@@ -280,9 +283,10 @@ def stim_stress(reps=20, with_map=False):
     dev.set_option(_lib.OPT_TIMING, 1)
     dev.close()
     # one MAP sweep of the same model and data through the host mirror (coord_descent default: STA warm start of the stimulus
-    # weights on the device, then all 64 per-neuron BFGS fits in lock step -- HIP row kernels, neuron lists through the
-    # frame-rate stimulus kernels; the template's N(0, 0.001) impulse prior runs every fit into the reference's maxiter = 225)
-    map_s = map_first = None
+    # weights on the device, then all 64 per-neuron BFGS fits in lock step -- HIP row kernels running scipy's algorithm,
+    # neuron lists through the frame-rate stimulus kernels; the template's N(0, 0.001) impulse prior runs every fit into the
+    # reference's maxiter = 225, exactly where a sequential scipy fit of the neuron stops)
+    map_s = map_first = lp_init = lp_final = None
     map_stats = {}
     if not with_map:
         return _stim_record(locals())
@@ -299,13 +303,16 @@ def stim_stress(reps=20, with_map=False):
     x0 = popn.sample(np.random.RandomState(0))
     for g in x0['glms']:
         g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
+    lp_init = popn.compute_log_p(x0)
     t0 = time.perf_counter()
     cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
     map_first = time.perf_counter() - t0
     t0 = time.perf_counter()
-    cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
+    xm = cd.coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1)
     map_s = time.perf_counter() - t0
     map_stats = dict(getattr(popn, 'last_fit_stats', None) or {})
+    map_stats.pop('per_neuron', None)
+    lp_final = popn.compute_log_p(xm)
     popn.release_data()
     return _stim_record(locals())
 
@@ -328,7 +335,10 @@ def _stim_record(v):
             "impulse_contraction_frac_of_f64_mfma_peak": flops_imp / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
             "dense_equivalent_bytes": float(nT) * Bt * D * 8,
             "device_bytes_stimulus": 2.0 * stim.size * 8,
-            "map_sweep_s": map_s, "map_first_call_s": map_first, "map_stats": map_stats,
+            "map_sweep_s": map_s, "map_first_call_s": map_first, "map_log_p_initial": v['lp_init'],
+            "map_log_p_final": v['lp_final'], "map_launches": map_stats.get('evaluations'),
+            "map_neurons_converged_gtol": map_stats.get('converged_gtol'), "map_neurons_at_maxiter": map_stats.get('maxiter'),
+            "map_stats": map_stats,
             "map_path": "coord_descent(maxiter=1) default: pgl_sta warm start + lock-step BFGS (P = %d per neuron)" % P}
 
 
@@ -408,18 +418,32 @@ def cpu_baseline(S, ibasis, theta, Weff, dt, sample_bins):
     }
 
 
+RENDEZVOUS_EXIT = 17          # a rank could not join the process group (port taken between probe and bind)
+
+
 def self_launch(n, script=None, argv=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, env
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's record.  Runs before torch / HIP are imported: the
     parent never initialises a GPU, the children are plain Popen processes (no exec from a GPU process)."""
-    import socket
-    import subprocess
     if script is None:
         import __graft_entry__ as ge
         ge.build_hip()                              # once, here: the ranks find the library fresh
+    return _self_launch_once(n, script, argv, attempts_left=2)
+
+
+def _free_port():
+    import socket
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+def _self_launch_once(n, script, argv, attempts_left):
+    import subprocess
+    # (the port is free when probed; another process can take it before rank 0 binds it -- then the ranks fail at the
+    #  rendezvous, before any work, and the launch is repeated once on a new port)
+    port = _free_port()
+    t_start = time.time()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -454,6 +478,10 @@ def self_launch(n, script=None, argv=None):
     bad = [c for i, c in enumerate(codes) if c != 0 and i not in killed]      # the ranks that failed by themselves
     if bad or killed:
         sys.stderr.write("bench.py: rank exit codes %s%s\n" % (codes, (" (ended by the parent: ranks %s)" % sorted(killed)) if killed else ""))
+        if RENDEZVOUS_EXIT in bad and attempts_left > 1:
+            sys.stderr.write("bench.py: rendezvous on port %d failed after %.0f s; launching again on a new port\n"
+                             % (port, time.time() - t_start))
+            return _self_launch_once(n, script, argv, attempts_left - 1)
         return 3 if 3 in bad else (bad[0] if bad else 1)
     return 0
 
@@ -470,8 +498,9 @@ def main():
     ap.add_argument('--no-map', action='store_true', help='skip the secondary MAP wall-clock measurement')
     ap.add_argument('--no-mcmc', action='store_true', help='skip the secondary MCMC inner-ll measurement')
     ap.add_argument('--no-stim', action='store_true', help='skip the secondary stimulus stress-variant measurement (config 5)')
-    ap.add_argument('--stim-map', action='store_true',
-                    help='also time a MAP sweep of the stress variant (two sweeps of ~17 s: not part of the default run)')
+    ap.add_argument('--no-stim-map', action='store_true',
+                    help='skip the MAP sweep of the stress variant inside the stimulus block')
+    ap.add_argument('--stim-map', action='store_true', help='(accepted for older scripts: the sweep is part of the default run)')
     ap.add_argument('--no-ab', action='store_true',
                     help='skip the A/B loops after the timed region (in-kernel features, all-f64 epilogue): profiler '
                          'passes use it so that per-kernel averages and counters describe the headline kernel only')
@@ -516,11 +545,17 @@ def main():
     if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
-        if args.debug_single_device:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            # device_id binds the communicator to this rank's GPU up front (no guessing from the global rank, eager init)
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        import datetime
+        try:
+            if args.debug_single_device:
+                dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+            else:
+                # device_id binds the communicator to this rank's GPU up front (no guessing from the global rank, eager init)
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
+                                        timeout=datetime.timedelta(seconds=600))
+        except Exception as e:                    # port taken / store unreachable: the self-launcher retries on a new port
+            sys.stderr.write("bench.py rank %d: rendezvous failed: %s\n" % (rank, e))
+            sys.exit(RENDEZVOUS_EXIT)
 
     if multi:
         dist.barrier()                       # rank 0 has finished building
@@ -564,9 +599,7 @@ def main():
     d_out = torch.zeros(npost * (1 + P), dtype=torch.float64, device='cuda')
     d_ll = d_out[:npost]
     d_grad = d_out[npost:].view(npost, P)
-    if multi and args.shard == 'neurons':
-        sizes = [b - a for a, b in PL.all_shard_bounds(N, world)]
-        gather = [torch.zeros(s, dtype=torch.float64, device='cuda') for s in sizes]
+    pop_ll = [None]                       # --shard neurons: the gathered population ll of the last step
     torch.cuda.synchronize()
 
     # The library queues its kernels on torch's current stream -- the stream RCCL collectives are
@@ -592,14 +625,13 @@ def main():
                     dist.all_reduce(h)
                     d_out.copy_(h)
                 else:
-                    hl = [g.cpu() for g in gather]
-                    dist.all_gather(hl, d_ll.cpu())
-                    for g, hg in zip(gather, hl):
-                        g.copy_(hg)
+                    pop_ll[0] = PL.allgather_rows_t(d_ll, N)
             elif args.shard == 'time':
                 dist.all_reduce(d_out)               # population (ll, grad) on every rank
             else:
-                dist.all_gather(gather, d_ll)        # population ll on every rank (1 KB)
+                # population ll on every rank (1 KB): the product's padded all-gather (uneven shards, e.g. 100 neurons
+                # on 8 ranks, are one all_gather_into_tensor of equal-sized pieces)
+                pop_ll[0] = PL.allgather_rows_t(d_ll, N)
             if record and not args.debug_single_device:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record(bench_stream)
@@ -643,7 +675,8 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     shard_neurons = None
-    rccl_ranks = dist.get_world_size() if multi else 1
+    # ranks that exchanged over RCCL (backend nccl); a gloo run (--debug-single-device) reports 'ranks' only
+    rccl_ranks = (dist.get_world_size() if dist.get_backend() == 'nccl' else 0) if multi else 1
     if multi and args.shard == 'time' and world > 1:
         # the split north_star names, measured behind the timed region: post-synaptic neurons block-partitioned
         # (parallel_coord_descent.py:137-147), every rank on the whole recording, all-gather of the ll shards per step
@@ -652,19 +685,13 @@ def main():
         dn_theta = torch.from_numpy(theta[a:b].copy()).cuda()
         dn_ll = torch.zeros(b - a, dtype=torch.float64, device='cuda')
         dn_grad = torch.zeros((b - a, P), dtype=torch.float64, device='cuda')
-        sizes = [hi - lo for lo, hi in PL.all_shard_bounds(N, world)]
-        gat = [torch.zeros(sz, dtype=torch.float64, device='cuda') for sz in sizes]
+        gat = [None]
 
         def nstep():
             dev.ll_grad_dev(dn_theta.data_ptr(), d_Weff.data_ptr(), dn_ll.data_ptr(), dn_grad.data_ptr(), a, b)
             if args.debug_single_device:
                 dev.sync()
-                hl = [g.cpu() for g in gat]
-                dist.all_gather(hl, dn_ll.cpu())
-                for g, hg in zip(gat, hl):
-                    g.copy_(hg)
-            else:
-                dist.all_gather(gat, dn_ll)
+            gat[0] = PL.allgather_rows_t(dn_ll, N)   # padded: valid for uneven shards on nccl and gloo alike
         nsteps = max(1, min(args.steps, 20))
         for _ in range(2):
             nstep()
@@ -684,7 +711,7 @@ def main():
                   "neurons": int(b - a), "bins": int(nT), "kernel_version": int(dev.info(a, b)['kernel_version'])}
         per_rank_n = [None] * world
         dist.all_gather_object(per_rank_n, mine_n)
-        ll_gathered = np.concatenate([g.cpu().numpy() for g in gat])
+        ll_gathered = gat[0].cpu().numpy()
         shard_neurons = {"ms_per_step": 1e3 * float(tt.item()) / nsteps, "steps": nsteps,
                          "evals_per_s": nsteps / float(tt.item()), "collective": "all-gather of the per-neuron ll (%d B)" % (8 * N),
                          "per_rank": per_rank_n, "_ll": ll_gathered}
@@ -738,7 +765,7 @@ def main():
         if args.shard == 'time':
             ll_pop = ll_host                                   # all-reduced: full ll of all N neurons
         else:
-            ll_pop = np.concatenate([g.cpu().numpy() for g in gather])
+            ll_pop = pop_ll[0].cpu().numpy()
         if rank == 0:
             dev.set_time_range(0, nT)
             ll_ref, _ = dev.ll_grad(theta, Weff, 0, N, want_grad=False)
@@ -805,6 +832,7 @@ def main():
             out["roofline"]["all_f64_epilogue"] = allf64
         if per_rank is not None:
             out["per_rank"] = per_rank
+            out["ranks"] = dist.get_world_size()
             out["rccl_ranks"] = rccl_ranks
             out["collective_backend"] = dist.get_backend()
         if shard_neurons is not None:
@@ -822,7 +850,7 @@ def main():
         if not multi and not args.no_mcmc and not args.f32_features:
             out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
         if not multi and not args.no_stim and not args.f32_features:
-            out["secondary_stim"] = stim_stress(with_map=args.stim_map)
+            out["secondary_stim"] = stim_stress(with_map=not args.no_stim_map)
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, ib, theta, Weff, dt, sample_bins=min(nT, 300000))
         # RCCL prints a banner through C stdio: flush it first so that the JSON line is the last line of stdout

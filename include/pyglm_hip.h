@@ -156,34 +156,39 @@ int pgl_ll_grad_dev(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
 int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double* d_theta,
                          const double* d_Weff, double* d_ll, double* d_grad);
 int pgl_sync(pgl_handle h);
-/* Helper of the lock-step optimiser around pgl_ll_grad_list_dev (the reference restarts a failed per-neuron
- * BFGS by calling scipy again, coord_descent.py:194-199): rows m of the batch d_H (M, P, P) of inverse-Hessian
- * estimates with d_scale[m] != 0 are set to d_scale[m] * identity on the handle's stream; other rows are not
- * touched. */
-int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int M, int P);
-
-/* Bookkeeping of the lock-step optimiser (inference/batched_bfgs.py) as row kernels on the handle's stream -- the
- * reference has no counterpart, it calls scipy.optimize.minimize(method="bfgs") neuron by neuron
- * (coord_descent.py:161-204).  All optimiser state of a shard of M neurons with P parameters lives in ONE device block
- * of pgl_bfgs_state_doubles(M, P) doubles (flags and counters stored as doubles), in this order:
- *   (M,P) each: X, g, p, H g, s, y, t = H g_new;  (M,P,3) each: U, V (H += U V^T);
- *   (M) each: f, alpha, slope, rho, scale, iters, restarts, nhalf, active, frozen, acc, upd.
- *   trial:     Xt[j] = X[r] + alpha[r] p[r], r = d_rows[j] (NULL: j), j < L
- *   objective: rows of d_Xt are theta rows [bias, w_stim, w_ir]; in place ll -> f = -(ll + log prior),
- *              grad -> g = -(grad + prior gradient) with fit_glm's NaN rules (coord_descent.py:170-182);
- *              priors: bias.py:33, bkgd.py:76 (stim_sigma), priors.py:139 (kind 0) / 202 (kind 1: group lasso)
- *   accept:    Armijo test of the listed trials; accepted rows take the step, failed ones halve alpha
- *   update:    expects t = H g (caller: batched GEMV); writes U, V, H_new g, the next direction / step, the restart
- *              and convergence flags; scale[r] != 0 asks for H[r] = I after the caller's H += U V^T
- *              (pgl_identity_rows_dev). */
+/* The lock-step optimiser (inference/batched_bfgs.py) as row kernels on the handle's stream.  The reference calls
+ * scipy.optimize.minimize(method="bfgs") neuron by neuron (coord_descent.py:161-204); these run the same algorithm --
+ * BFGS from H = I, More'-Thuente strong-Wolfe line search with scipy's constants and first trial step
+ * (csrc/pglm_linesearch.h), stop on max|g| <= gtol or maxiter iterations -- for all M neurons of a shard at once, one
+ * fused ll+grad launch per trial step.  All optimiser state of a shard of M neurons with P parameters lives in ONE
+ * device block of pgl_bfgs_state_doubles(M, P) doubles (flags and counters stored as doubles), in this order:
+ *   (M,P) each: X, g, p, H g, s, y, t = H g_new, Xb, gb (best trial of the running search);
+ *   (M,P,3) each: U, V (pending H += U V^T);
+ *   (M) each: f, fprev, alpha, slope, rho, hscale, iters, restarts, active, frozen, acc, upd, stall, ident, pend, fb,
+ *             nfev;  then the line-search state, (18, M).
+ * The dense inverse Hessians d_H (M, P, ld), ld even and >= P, are the caller's buffer (uninitialised is fine).
+ *   init:       X, f, g of every row in place -> steepest-descent start, first trial step min(1, 1.01/|g|)
+ *   trial:      Xt[j] = X[r] + alpha[r] p[r], r = d_rows[j] (NULL: j), j < L
+ *   objective:  rows of d_Xt are theta rows [bias, w_stim, w_ir]; in place ll -> f = -(ll + log prior),
+ *               grad -> g = -(grad + prior gradient) with fit_glm's NaN rules (coord_descent.py:170-182);
+ *               priors: bias.py:33, bkgd.py:76 (stim_sigma), priors.py:139 (kind 0) / 202 (kind 1: group lasso)
+ *               (rows in another packing: the caller supplies f and g itself)
+ *   linesearch: one step of every listed row's search: next trial step, or the row takes the step (acc = 1), or the
+ *               search is stuck: best sufficient-decrease point if any, else stall = 1 (scipy stops with
+ *               "precision loss" there); at most max_trials steps per search (scipy: 100)
+ *   hmul:       rows with acc = 1: H += U V^T (pending update) and t = H g in one pass over H
+ *   update:     U, V, H_new g, next direction and first step, restart (once) / freeze of stalled rows, convergence;
+ *               init_scaling != 0: H <- (s.y / y.y) I before the first update after a (re)start (not scipy's). */
 long long pgl_bfgs_state_doubles(int M, int P);
+int pgl_bfgs_init_dev(pgl_handle h, double* d_state, int M, int P, double gtol);
 int pgl_bfgs_trial_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_Xt);
 int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, double* d_ll_f, double* d_grad_g,
                            int prior_kind, double mu_b, double sg_b, double stim_sigma, double mu, double sigma,
                            double lam);
-int pgl_bfgs_accept_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
-                        const double* d_f, const double* d_g);
-int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter);
+int pgl_bfgs_linesearch_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
+                            const double* d_f, const double* d_g, int max_trials);
+int pgl_bfgs_hmul_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_H, int ld);
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling);
 
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
  * fS_out (nT,N,B) row-major, float64. */

@@ -232,7 +232,8 @@ def test_bench_self_launches_its_ranks():
                         '--seconds', '60', '--neurons', '64'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
-    assert rec['n_gpus'] == 2 and rec['rccl_ranks'] == 2 and rec['steps'] == 3 and rec['value'] > 0
+    assert rec['n_gpus'] == 2 and rec['ranks'] == 2 and rec['steps'] == 3 and rec['value'] > 0
+    assert rec['rccl_ranks'] == 0 and rec['collective_backend'] == 'gloo'       # a gloo run exercises no RCCL rank
     assert len(rec['per_rank']) == 2 and sorted(p['rank'] for p in rec['per_rank']) == [0, 1]
     sn = rec['sharding_neurons']
     assert sn['ms_per_step'] > 0 and len(sn['per_rank']) == 2
@@ -244,3 +245,30 @@ def test_bench_self_launches_its_ranks():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+
+
+def test_bench_eight_ranks_uneven_neuron_shards_on_one_gpu():
+    """`python bench.py --gpus 8 --neurons 100` (eight ranks on the one GPU of the box, gloo): 100 neurons over 8 ranks
+    are shards of 12 or 13 neurons -- the neuron-sharded step gathers them through the padded all-gather of
+    parallel.allgather_rows_t -- and both sharded population lls equal the single-rank evaluation (asserted inside
+    bench.py at rtol 1e-10); then the same with --shard neurons as the headline sharding."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict((k, v) for k, v in os.environ.items()
+               if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'))
+    for extra in ([], ['--shard', 'neurons']):
+        r = subprocess.run([sys.executable, 'bench.py', '--gpus', '8', '--debug-single-device', '--steps', '2', '--warmup', '1',
+                            '--seconds', '30', '--neurons', '100'] + extra, cwd=root, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec['n_gpus'] == 8 and rec['ranks'] == 8 and rec['rccl_ranks'] == 0 and rec['value'] > 0
+        assert len(rec['per_rank']) == 8
+        if extra:
+            assert sorted(p['neurons'] for p in rec['per_rank']) == [12] * 4 + [13] * 4
+        else:
+            sn = rec['sharding_neurons']
+            assert sorted(p['neurons'] for p in sn['per_rank']) == [12] * 4 + [13] * 4
+            assert all(p['bins'] == 30000 for p in sn['per_rank'])

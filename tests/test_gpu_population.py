@@ -553,12 +553,15 @@ def test_two_data_sequences_log_p_and_lockstep_map():
     popn.release_data()
 
 
-def test_lockstep_row_kernels_equal_tensor_op_bookkeeping(std4):
-    """The lock-step optimizer's bookkeeping as HIP row kernels (pgl_bfgs_trial / objective / accept / update_dev,
-    the default for theta-row packings) against the same state machine in framework tensor ops: identical
-    iterates -- same number of iterations and evaluations, objectives equal to rounding -- for the group-lasso
-    prior (standard_glm), a Gaussian impulse prior, a BasisStimulus model (stimulus block of the prior kernel) and a
-    neuron sub-range; a NaN gradient (zero impulse group under the group lasso, priors.py:202) takes the same path."""
+def test_lockstep_row_kernels_follow_scipy_bfgs(std4):
+    """The lock-step optimizer (HIP row kernels: pgl_bfgs_init / trial / objective / linesearch / hmul / update_dev) runs the
+    algorithm scipy runs for the reference's fit_glm (coord_descent.py:161-204): BFGS from H = I with the More'-Thuente
+    strong-Wolfe search and scipy's first trial step.  Per neuron: the same number of iterations and line-search steps
+    as the sequential scipy fit of that neuron (rounding may move a stop by one iteration), objectives equal to 1e-9 --
+    for the group-lasso prior (standard_glm), a Gaussian impulse prior, a BasisStimulus model (stimulus block of the prior
+    kernel) and a neuron sub-range; a NaN gradient (zero impulse group under the group lasso, priors.py:202) takes
+    fit_glm's path (zero gradient: the fit stops where it started)."""
+    from theano_pyglm_amd.inference import coord_descent as cd
     from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
     model, popn, data = std4
     cases = [(popn, data, 0, 4), (popn, data, 1, 3)]
@@ -575,20 +578,30 @@ def test_lockstep_row_kernels_equal_tensor_op_bookkeeping(std4):
     dstim['dt_stim'] = 0.1
     pb.add_data(dstim)
     cases.append((pb, dstim, 0, 4))
+    same_nit = total = 0
     for k, (pp, dd, lo, hi) in enumerate(cases):
         x0 = pp.sample(np.random.RandomState(40 + k))
         if k == 0:
             x0['glms'][2]['imp']['w_ir'][5:10] = 0.0          # zero group: NaN prior gradient at the start
-        xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
-        fa, ita, eva = fit_glms_batched_torch(pp, xa, n_lo=lo, n_hi=hi, row_kernels=True)
+        xa = copy.deepcopy(x0)
+        fa, ita, eva = fit_glms_batched_torch(pp, xa, n_lo=lo, n_hi=hi)
         sa = dict(pp.last_fit_stats)
-        fb, itb, evb = fit_glms_batched_torch(pp, xb, n_lo=lo, n_hi=hi, row_kernels=False, lag=1)
-        sb = dict(pp.last_fit_stats)
-        assert sa.pop('bookkeeping') == 'hip row kernels' and sb.pop('bookkeeping') == 'torch tensor ops'
-        assert (ita, eva) == (itb, evb) and sa == sb, (k, sa, sb)
-        assert np.allclose(fa, fb, rtol=1e-12, atol=0), (k, fa, fb)
-        for n in range(lo, hi):
-            assert np.allclose(pp.glm.theta_row(xa['glms'][n]), pp.glm.theta_row(xb['glms'][n]), rtol=1e-9, atol=1e-12)
+        assert sa['bookkeeping'] == 'hip row kernels'
+        assert sa['converged_gtol'] + sa['stalled'] + sa['maxiter'] == hi - lo
+        prms = cd.prep_first_order_glm_inference(pp)
+        for i, n in enumerate(range(lo, hi)):
+            nv = pp.extract_vars(copy.deepcopy(x0), n)
+            res = cd.fit_glm(nv, n, prms)
+            nit, nls = sa['per_neuron']['iterations'][i], sa['per_neuron']['line_search_steps'][i]
+            assert abs(res.fun - fa[i]) <= 1e-9 * abs(res.fun), (k, n, res.fun, fa[i])
+            # scipy: nfev = the evaluation at the start + one per line-search step
+            assert abs(res.nit - nit) <= 1 and abs((res.nfev - 1) - nls) <= 2, (k, n, res.nit, nit, res.nfev, nls)
+            same_nit += int(res.nit == nit and res.nfev - 1 == nls)
+            total += 1
+            assert np.allclose(pp.glm.theta_row(xa['glms'][n]), pp.glm.theta_row(nv['glm']), rtol=1e-5, atol=1e-7)
+        if k == 0:
+            assert sa['per_neuron']['iterations'][2] == 0 and np.array_equal(xa['glms'][2]['imp']['w_ir'], x0['glms'][2]['imp']['w_ir'])
+    assert same_nit >= total - 3, (same_nit, total)            # almost always the very same count
     pg.release_data()
     pb.release_data()
 
@@ -648,8 +661,8 @@ def test_separable_stimulus_frame_rate_randomised_shapes():
 
 def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
     """spatiotemporal_glm with a wide stimulus (separable device path at the frame rate): the lock-step optimizer runs on
-    the HIP row kernels with neuron LISTS (pgl_ll_grad_list_dev through the frame-rate stimulus kernels) and gives the
-    iterates of the tensor-op bookkeeping on neuron ranges; a list call equals the range call row by row."""
+    the HIP row kernels with neuron LISTS (pgl_ll_grad_list_dev through the frame-rate stimulus kernels) and ends where
+    the sequential scipy fits (neuron ranges) end; a list call equals the range call row by row."""
     from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch, _Packing
     from theano_pyglm_amd.models import templates
     import torch
@@ -673,7 +686,7 @@ def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
     assert popn.glm.bkgd_model.separable
     h = popn._handle(popn._current)
     assert h.info()['stim_path'] == 2
-    pk = _Packing(popn, torch)
+    pk = _Packing(popn, torch, [h])
     assert pk.identity and pk.list_launch
     # a neuron list == the range call, row by row
     x = popn.sample(np.random.RandomState(44))
@@ -692,29 +705,94 @@ def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
     h.sync()
     assert np.allclose(d_ll.cpu().numpy(), ll_r[idx], rtol=1e-12)
     assert np.max(np.abs(d_g.cpu().numpy() - g_r[idx])) < 1e-10 * np.max(np.abs(g_r))
-    # row kernels (lists) against tensor-op bookkeeping
+    # row kernels with neuron lists against sequential scipy fits through the host-pointer API (neuron ranges)
+    from theano_pyglm_amd.inference import coord_descent as cd
     x0 = popn.sample(np.random.RandomState(45))
     tame(x0)
-    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
-    fa, ita, eva = fit_glms_batched_torch(popn, xa, row_kernels=True)
+    xa = copy.deepcopy(x0)
+    fa, ita, eva = fit_glms_batched_torch(popn, xa)
     sa = dict(popn.last_fit_stats)
-    fb, itb, evb = fit_glms_batched_torch(popn, xb, row_kernels=False, lag=1)
-    sb = dict(popn.last_fit_stats)
-    assert sa.pop('bookkeeping') == 'hip row kernels' and sb.pop('bookkeeping') == 'torch tensor ops'
-    assert sa['neuron_evaluations'] <= sa['evaluations'] * N               # lists: finished neurons drop out of the launches
-    # (~165 BFGS iterations: list launches sum the listed rows in another order than range launches, the two
-    #  trajectories drift apart by rounding and may stop an iteration apart -- at the same optimum)
-    assert abs(ita - itb) <= 3 and np.allclose(fa, fb, rtol=1e-8, atol=0), (sa, sb, fa, fb)
-    for n in range(N):
-        assert np.allclose(popn.glm.theta_row(xa['glms'][n]), popn.glm.theta_row(xb['glms'][n]), rtol=1e-3, atol=1e-5)
+    assert sa['bookkeeping'] == 'hip row kernels'
+    assert sa['neuron_evaluations'] < sa['evaluations'] * N                # lists: finished neurons drop out of the launches
     assert sa['converged_gtol'] + sa['stalled'] == N
+    prms = cd.prep_first_order_glm_inference(popn)
+    for n in (0, 3, 5):
+        nv = popn.extract_vars(copy.deepcopy(x0), n)
+        res = cd.fit_glm(nv, n, prms)
+        # (~100+ BFGS iterations: list launches sum the listed rows in another order than range launches, the two
+        #  trajectories drift apart by rounding and may stop a few iterations apart -- at the same optimum)
+        assert abs(res.fun - fa[n]) <= 1e-8 * abs(res.fun), (n, res.fun, fa[n], sa)
+        assert abs(res.nit - sa['per_neuron']['iterations'][n]) <= max(3, res.nit // 20), (n, res.nit, sa['per_neuron'])
+        assert np.allclose(popn.glm.theta_row(xa['glms'][n]), popn.glm.theta_row(nv['glm']), rtol=1e-3, atol=1e-5)
     popn.release_data()
 
 
-def test_all_f64_epilogue_option_and_identity_rows():
+def test_separable_stimulus_wide_population_short_lists_and_shards():
+    """spatiotemporal_glm with N * B > 320 impulse columns (N = 128, B = 3) and a separable stimulus: neuron lists and
+    neuron shards SHORTER than 49 neurons stay on the frame-rate path (the feature row is too long for k_fused7, so the
+    slab-input form of the two-pass kernel serves any number of post tiles) and equal the whole-population call row by
+    row; the lock-step MAP fit of a 28-neuron shard and the default sweep of the whole population (its launch lists shrink
+    below 49 as neurons finish) run through it."""
+    import torch
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch, _Packing
+    from theano_pyglm_amd.inference import coord_descent as cd
+    from theano_pyglm_amd.models import templates
+    N, nT, D = 128, 8000, 24
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = D
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
+    tmpl['bkgd']['sigma'] = 0.05
+    tmpl['bkgd']['separable'] = True
+    tmpl['impulse']['sigma'] = 0.5
+    rng = np.random.default_rng(77)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    stim = rng.standard_normal((nT // 100, D))
+    popn = Population(make_model(tmpl, N=N, dt=0.001))
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': stim, 'dt_stim': 0.1})
+    h = popn._handle(popn._current)
+    assert h.info()['stim_path'] == 2 and h.info(100, 128)['stim_path'] == 2 and h.info(5, 6)['stim_path'] == 2
+    pk = _Packing(popn, torch, [h])
+    assert pk.identity and pk.list_launch
+    x = popn.sample(np.random.RandomState(3))
+    for xn in x['glms']:
+        xn['bias']['bias'] = np.array([1.0])
+        xn['imp']['w_ir'] = 0.02 * np.asarray(xn['imp']['w_ir']) / 0.5
+    th = popn.theta_matrix(x)
+    W = popn.W_eff(x)
+    ll_r, g_r = h.ll_grad(th, W)
+    assert np.all(np.isfinite(ll_r))
+    # shards shorter than 49 neurons (1, 2 and 3 post tiles)
+    for lo, hi in ((100, 128), (7, 20), (60, 101)):
+        ll_s, g_s = h.ll_grad(th[lo:hi], W, lo, hi)
+        assert np.allclose(ll_s, ll_r[lo:hi], rtol=1e-11) and np.max(np.abs(g_s - g_r[lo:hi])) < 1e-9 * np.max(np.abs(g_r))
+    # neuron lists of 1 .. 48 neurons
+    for cnt in (1, 17, 48):
+        idx = np.sort(np.random.RandomState(cnt).permutation(N)[:cnt]).astype(np.int32)
+        d_idx = torch.from_numpy(idx).cuda()
+        d_th = torch.from_numpy(np.ascontiguousarray(th[idx])).cuda()
+        d_W = torch.from_numpy(np.ascontiguousarray(W)).cuda()
+        d_ll = torch.zeros(cnt, dtype=torch.float64, device='cuda')
+        d_g = torch.zeros((cnt, th.shape[1]), dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        h.ll_grad_list_dev(d_idx.data_ptr(), cnt, d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+        h.sync()
+        assert np.allclose(d_ll.cpu().numpy(), ll_r[idx], rtol=1e-11), cnt
+        assert np.max(np.abs(d_g.cpu().numpy() - g_r[idx])) < 1e-9 * np.max(np.abs(g_r)), cnt
+    # lock-step fit of a short shard, and the default sweep with shrinking lists
+    lp0, _ = popn.compute_lp_grad_packed(x)
+    xs = copy.deepcopy(x)
+    nlp_s, _, _ = fit_glms_batched_torch(popn, xs, n_lo=100, n_hi=128, maxiter=40)
+    assert np.all(nlp_s < -lp0[100:128])
+    xm = cd.coord_descent(popn, x0=copy.deepcopy(x), maxiter=1)
+    st = popn.last_fit_stats
+    assert st['bookkeeping'] == 'hip row kernels' and st['neuron_evaluations'] < st['evaluations'] * N, st
+    assert popn.compute_log_p(xm) > popn.compute_log_p(x)
+    popn.release_data()
+
+
+def test_all_f64_epilogue_option():
     """PGL_OPT_EPI_F64 (run-time switch of the single-precision exp(-x) correction): same ll and gradient to 1e-12 in
-    the regime where the correction is used (currents > 12), bit-identical outside it; pgl_identity_rows_dev touches
-    exactly the flagged rows."""
+    the regime where the correction is used (currents > 12), bit-identical outside it."""
     import torch
     from tests import helpers as Hh
     from theano_pyglm_amd import _lib
@@ -733,17 +811,53 @@ def test_all_f64_epilogue_option_and_identity_rows():
         ll_or, g_or = p.oracle_ll_grad(0, 3)
         assert np.allclose(ll1[:3], ll_or, rtol=1e-10) and Hh.rel_err(g1[:3], g_or) < 1e-9
         d.close()
+
+
+def test_bfgs_hmul_kernel_against_dense_algebra():
+    """pgl_bfgs_hmul_dev -- the one pass over the dense inverse Hessians per accepted iteration: for the listed rows with
+    acc = 1 it applies the pending rank-3 update H <- H + U V^T and returns t = H g; a row still at hscale * I is
+    materialised together with its first update and left alone without one; rows without acc (or not listed) are not
+    touched.  Odd and even P (padded leading dimension), P below and above one column sweep of a wave."""
+    import torch
+    from tests import helpers as Hh
     p = Hh.Problem(3, 200, Hh.std_ibasis(), seed=1)
     d = p.device()
-    M, P = 5, 37
-    Hm = torch.randn(M, P, P, dtype=torch.float64, device='cuda')
-    ref = Hm.clone()
-    scale = torch.tensor([0.0, 1.0, 0.0, 2.5, 0.0], dtype=torch.float64, device='cuda')
-    d.reset_identity_dev(Hm.data_ptr(), scale.data_ptr(), M, P)
-    d.sync()
-    torch.cuda.synchronize()
-    eye = torch.eye(P, dtype=torch.float64, device='cuda')
-    for m in range(M):
-        want = ref[m] if scale[m] == 0 else float(scale[m]) * eye
-        assert torch.equal(Hm[m], want)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for M, P in ((6, 37), (5, 130), (4, 641)):
+        ld = P + (P & 1)
+        n = d.bfgs_state_doubles(M, P)
+        st = torch.zeros(n, dtype=torch.float64, device='cuda')
+        MP = M * P
+        g = st[MP:2 * MP].view(M, P)
+        t = st[6 * MP:7 * MP].view(M, P)
+        U, V = st[9 * MP:12 * MP].view(M, P, 3), st[12 * MP:15 * MP].view(M, P, 3)
+        sc = st[15 * MP:].view(-1, M)
+        hscale, acc, ident, pend = sc[5], sc[10], sc[13], sc[14]
+        g.copy_(torch.randn(M, P, dtype=torch.float64, device='cuda', generator=gen))
+        U.copy_(torch.randn(M, P, 3, dtype=torch.float64, device='cuda', generator=gen))
+        V.copy_(torch.randn(M, P, 3, dtype=torch.float64, device='cuda', generator=gen))
+        t.fill_(-7.0)
+        H = torch.randn(M, P, ld, dtype=torch.float64, device='cuda', generator=gen)
+        H0 = H.clone()
+        # rows: 0 dense + pending, 1 dense no pending, 2 identity + pending, 3 identity no pending (lazy), 4.. acc = 0
+        acc.copy_(torch.tensor([1, 1, 1, 1] + [0] * (M - 4), dtype=torch.float64))
+        ident.copy_(torch.tensor([0, 0, 1, 1] + [0] * (M - 4), dtype=torch.float64))
+        pend.copy_(torch.tensor([1, 0, 1, 0] + [1] * (M - 4), dtype=torch.float64))
+        hscale.copy_(torch.tensor([1.0, 1.0, 0.37, 2.0] + [1.0] * (M - 4), dtype=torch.float64))
+        rows = torch.tensor([3, 0, 2, 1] + list(range(4, M)), dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()
+        d.bfgs_hmul_dev(st.data_ptr(), M, P, rows.data_ptr(), M, H.data_ptr(), ld)
+        d.sync()
+        eye = torch.eye(P, dtype=torch.float64, device='cuda')
+        UV = torch.bmm(U, V.transpose(1, 2))
+        want0 = H0[0, :, :P] + UV[0]
+        assert torch.allclose(H[0, :, :P], want0, rtol=1e-13, atol=1e-13)
+        assert torch.allclose(t[0], want0 @ g[0], rtol=1e-11, atol=1e-11)
+        assert torch.equal(H[1], H0[1]) and torch.allclose(t[1], H0[1, :, :P] @ g[1], rtol=1e-11, atol=1e-11)
+        want2 = 0.37 * eye + UV[2]
+        assert torch.allclose(H[2, :, :P], want2, rtol=1e-13, atol=1e-13)
+        assert torch.allclose(t[2], want2 @ g[2], rtol=1e-11, atol=1e-11)
+        assert torch.equal(H[3], H0[3]) and bool((t[3] == -7.0).all())          # lazy identity: not touched
+        for m in range(4, M):
+            assert torch.equal(H[m], H0[m]) and bool((t[m] == -7.0).all())
     d.close()

@@ -1,4 +1,4 @@
-"""World-size-2 gloo test of the neuron-sharded path (theano_pyglm_amd/parallel.py):
+"""World-size-2 and world-size-8 gloo tests of the sharded paths (theano_pyglm_amd/parallel.py):
 each rank evaluates only its shard (here with the oracle injected as the local
 evaluator -- the plumbing, not the kernel, is under test) and the all-gathered
 population ll equals the single-process value."""
@@ -58,27 +58,38 @@ def _worker(rank, world, port, N, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('N', [6, 7])
-def test_sharded_population_ll(N):
+@pytest.mark.parametrize('world,N', [(2, 6), (2, 7), (8, 128), (8, 100)])
+def test_sharded_population_ll(world, N):
+    """Both shardings on `world` gloo ranks: neuron shards (north_star's split; N = 100 on 8 ranks is uneven: 12 or 13
+    neurons per rank, padded all-gather) and time shards (all-reduce of the packed block); world = 8 with N = 128 is the
+    shape of BASELINE config 3."""
     import torch.multiprocessing as mp
+    from theano_pyglm_amd import parallel as PL
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, N, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for pr in procs:
-        pr.join(timeout=60)
+        pr.join(timeout=120)
         assert pr.exitcode == 0
     p = H.Problem(N, 700, H.std_ibasis(), seed=50, weighted=True)
     ll0, g0 = p.oracle_ll_grad()
+    assert sorted(r[0] for r in res) == list(range(world))
+    sizes = set()
     for rank, total, ll_all, calls, rows, ll_t, g_t, tcalls in res:
         assert np.allclose(ll_all, ll0, rtol=1e-13) and np.isclose(total, ll0.sum(), rtol=1e-13)
-        assert calls == [((N * rank) // 2, (N * (rank + 1)) // 2)]      # only its own shard
+        assert calls == [((N * rank) // world, (N * (rank + 1)) // world)]      # only its own shard
+        sizes.add(calls[0][1] - calls[0][0])
         assert np.array_equal(rows, p.theta)
         assert np.allclose(ll_t, ll0, rtol=1e-12) and H.rel_err(g_t, g0) < 1e-12
-        assert tcalls == [(0, 352)] if rank == 0 else tcalls == [(352, 700)]
+        assert tcalls == [PL.time_shard_bounds(700, rank, world)]
+    if (world, N) == (8, 100):
+        assert sizes == {12, 13}
+    if world == 2:
+        assert PL.time_shard_bounds(700, 0, 2) == (0, 352) and PL.time_shard_bounds(700, 1, 2) == (352, 700)
 
 
 def test_shard_bounds_cover():

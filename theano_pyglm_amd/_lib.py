@@ -31,8 +31,8 @@ SYMBOLS = [
     'pgl_gibbs_ll', 'pgl_gibbs_update', 'pgl_last_timing', 'pgl_info', 'pgl_simulate', 'pgl_sta',
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
-    'pgl_identity_rows_dev', 'pgl_bfgs_state_doubles', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
-    'pgl_bfgs_accept_dev', 'pgl_bfgs_update_dev',
+    'pgl_bfgs_state_doubles', 'pgl_bfgs_init_dev', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
+    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_update_dev',
 ]
 
 
@@ -105,14 +105,14 @@ def load():
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_list_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pgl_sync.argtypes = [vp]
-    if hasattr(lib, 'pgl_bfgs_update_dev'):
+    if hasattr(lib, 'pgl_bfgs_hmul_dev'):                     # (older dev A/B builds named by PYGLM_HIP_LIB lack it)
         lib.pgl_bfgs_state_doubles.argtypes = [C.c_int, C.c_int]
+        lib.pgl_bfgs_init_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double]
         lib.pgl_bfgs_trial_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
         lib.pgl_bfgs_objective_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int] + [C.c_double] * 6
-        lib.pgl_bfgs_accept_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]
-        lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int]
-    if hasattr(lib, 'pgl_identity_rows_dev'):                 # (older dev A/B builds named by PYGLM_HIP_LIB lack it)
-        lib.pgl_identity_rows_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+        lib.pgl_bfgs_linesearch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]
+        lib.pgl_bfgs_hmul_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
+        lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
     lib.pgl_features.argtypes = [vp, vp]
     lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
     lib.pgl_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
@@ -327,18 +327,21 @@ class DeviceGlm(object):
                                              C.c_void_p(d_grad_g), int(prior_kind), float(mu_b), float(sg_b),
                                              float(stim_sigma), float(mu), float(sigma), float(lam)))
 
-    def bfgs_accept_dev(self, d_state, M, P, d_rows, L, d_Xt, d_f, d_g):
-        _chk(self.lib.pgl_bfgs_accept_dev(self.h, C.c_void_p(d_state), int(M), int(P),
-                                          C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_Xt),
-                                          C.c_void_p(d_f), C.c_void_p(d_g)))
+    def bfgs_init_dev(self, d_state, M, P, gtol):
+        _chk(self.lib.pgl_bfgs_init_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol)))
 
-    def bfgs_update_dev(self, d_state, M, P, gtol, maxiter):
-        _chk(self.lib.pgl_bfgs_update_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol), int(maxiter)))
+    def bfgs_linesearch_dev(self, d_state, M, P, d_rows, L, d_Xt, d_f, d_g, max_trials=100):
+        _chk(self.lib.pgl_bfgs_linesearch_dev(self.h, C.c_void_p(d_state), int(M), int(P),
+                                              C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_Xt),
+                                              C.c_void_p(d_f), C.c_void_p(d_g), int(max_trials)))
 
-    def reset_identity_dev(self, d_H, d_scale, M, P):
-        """Rows m of the device batch d_H (M, P, P) with d_scale[m] != 0 (device float64) become d_scale[m] * I
-        (asynchronous)."""
-        _chk(self.lib.pgl_identity_rows_dev(self.h, C.c_void_p(d_H), C.c_void_p(d_scale), int(M), int(P)))
+    def bfgs_hmul_dev(self, d_state, M, P, d_rows, L, d_H, ld):
+        _chk(self.lib.pgl_bfgs_hmul_dev(self.h, C.c_void_p(d_state), int(M), int(P),
+                                        C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_H), int(ld)))
+
+    def bfgs_update_dev(self, d_state, M, P, gtol, maxiter, init_scaling=False):
+        _chk(self.lib.pgl_bfgs_update_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol), int(maxiter),
+                                          1 if init_scaling else 0))
 
     def sync(self):
         _chk(self.lib.pgl_sync(self.h))

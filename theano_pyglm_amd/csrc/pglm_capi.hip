@@ -224,7 +224,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (h->opt_kernel == 3) pl.version = 4;
         // two-pass kernel on resident tiles from 5 post tiles on; from 4 when the feature row is too long for
         // the resident K-split kernel (measured at K = 640: 64 neurons 2.05 ms against 2.33 ms of k_fused2)
-        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT == 4 && need > 20))))
+        // (force7 with a feature row too long for k_fused7 -- a short neuron list of a wide separable-stimulus population:
+        // the slab-input form of the two-pass kernel, whatever the number of post tiles)
+        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT == 4 && need > 20))) ||
+                 (force7 && need > 20 && (h->opt_kernel == 0 || h->opt_kernel == 7)))
             pl.version = 5;
     }
     pl.tile0 = (int)(h->t_lo / 16);
@@ -1542,7 +1545,9 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
     // separable stimulus at the frame rate: impulse columns on resident tiles (k_fused7, slab-input form), the stimulus
     // current / its gradients by k_sepf_*; needs a short feature row (<= 4 post tiles, <= 320 columns)
     // (neuron lists are fine here: the stimulus kernels work on the listed rows, the fused kernel maps rows to neurons)
-    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32;
+    // (a kernel forced by PGL_OPT_KERNEL other than 7 / 4 keeps the stimulus on the 3-phase path it asks for)
+    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
+                (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4);
     if (sepf) {
         int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
         if (rc) return rc;
@@ -1768,18 +1773,6 @@ int pgl_ll_grad_list_dev(pgl_handle h, const int* d_idx, int count, const double
     return rc;
 }
 
-int pgl_identity_rows_dev(pgl_handle h, double* d_H, const double* d_scale, int M, int P)
-{
-    if (!h || !d_H || !d_scale) return fail(PGL_ERR_ARG, "null argument");
-    if (M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad shape");
-    HIPCHK(hipSetDevice(h->device));
-    const long long PP = (long long)P * P;
-    const unsigned bx = (unsigned)std::min<long long>((PP + 256 * 8 - 1) / (256 * 8), 64);
-    hipLaunchKernelGGL(k_identity_rows, dim3(bx, (unsigned)M), dim3(256), 0, h->stream, d_H, d_scale, P);
-    HIPCHK(hipGetLastError());
-    return PGL_OK;
-}
-
 // ---- lock-step BFGS bookkeeping kernels (inference/batched_bfgs.py) ----------------------------------------------
 long long pgl_bfgs_state_doubles(int M, int P) { return (long long)pgl_bfgs_doubles(M, P); }
 
@@ -1809,23 +1802,46 @@ int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, doubl
     return PGL_OK;
 }
 
-int pgl_bfgs_accept_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
-                        const double* d_f, const double* d_g)
+int pgl_bfgs_init_dev(pgl_handle h, double* d_state, int M, int P, double gtol)
 {
-    if (!h || !d_state || !d_Xt || !d_f || !d_g || M <= 0 || P <= 0 || L <= 0 || L > M)
-        return fail(PGL_ERR_ARG, "bad argument");
+    if (!h || !d_state || M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_bfgs_accept, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows, d_Xt, d_f,
-                       d_g);
+    hipLaunchKernelGGL(k_bfgs_init, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
 
-int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter)
+int pgl_bfgs_linesearch_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
+                            const double* d_f, const double* d_g, int max_trials)
+{
+    if (!h || !d_state || !d_Xt || !d_f || !d_g || M <= 0 || P <= 0 || L <= 0 || L > M || max_trials <= 0)
+        return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_bfgs_linesearch, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows, d_Xt,
+                       d_f, d_g, max_trials);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_hmul_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_H, int ld)
+{
+    if (!h || !d_state || !d_H || M <= 0 || P <= 0 || L <= 0 || L > M) return fail(PGL_ERR_ARG, "bad argument");
+    if (ld < P || (ld & 1) || (reinterpret_cast<uintptr_t>(d_H) & 15))
+        return fail(PGL_ERR_ARG, "H: leading dimension even and >= P, base 16-byte aligned");
+    HIPCHK(hipSetDevice(h->device));
+    const unsigned bx = (unsigned)((P + 4 * PGL_HM_ROWS - 1) / (4 * PGL_HM_ROWS));
+    hipLaunchKernelGGL(k_bfgs_hmul, dim3(bx, (unsigned)L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows,
+                       d_H, ld);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling)
 {
     if (!h || !d_state || M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_bfgs_update, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol, maxiter);
+    hipLaunchKernelGGL(k_bfgs_update, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol, maxiter,
+                       init_scaling);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -1920,7 +1936,8 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     // the 3-phase path, 2 separable at the frame rate (k_sepf_*, impulse columns on resident tiles)
     int stim_path = h->sep ? 1 : 0;
     int rc = PGL_OK;
-    if (h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32) {
+    if (h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
+        (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4)) {
         rc = make_plan(h, n_lo, n_hi, slices[0], pl, true, true);
         if (rc) return rc;
         if ((pl.version == 7 && pl.nw7 == 4) || (pl.version == 5 && pl.ktl >= 5)) stim_path = 2;

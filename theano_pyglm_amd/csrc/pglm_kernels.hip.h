@@ -4930,21 +4930,6 @@ __global__ __launch_bounds__(256) void k_sta_finish(const double* __restrict__ p
 }
 
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
-// Rows m of a batch of square matrices H (M, P, P) with scale[m] != 0 become scale[m] * identity; the other rows are
-// not touched (their blocks exit at once).  Lock-step BFGS: "restart this neuron from steepest descent" / "scale the
-// initial inverse Hessian by s.y / y.y" without a pass over the whole batch and without telling the host which rows
-// (inference/batched_bfgs.py).
-__global__ __launch_bounds__(256) void k_identity_rows(double* __restrict__ H, const double* __restrict__ scale, int P)
-{
-    const int m = blockIdx.y;
-    const double d = scale[m];
-    if (d == 0.0) return;
-    const long long PP = (long long)P * P;
-    double* Hm = H + (size_t)m * PP;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < PP; i += (long long)gridDim.x * 256)
-        Hm[i] = (i / P == i % P) ? d : 0.0;
-}
-
 __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restrict__ ST,
                                long long nT, int N)
 {
@@ -4967,23 +4952,38 @@ __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------
-// Lock-step BFGS bookkeeping (inference/batched_bfgs.py): the per-neuron line-search / update state machines of
-// all M neurons of a shard as a handful of row kernels -- one workgroup per neuron row -- instead of ~110 tiny
-// framework kernels per evaluation (4 us of work and a launch gap each: a fifth of a MAP sweep at C3).  The
-// reference has no counterpart: it calls scipy.optimize.minimize(method="bfgs") per neuron (coord_descent.py:194).
-// All state lives in ONE device block of doubles (flags and counters included), laid out by pgl_bfgs_view.
+// Lock-step BFGS (inference/batched_bfgs.py): the per-neuron optimiser state machines of all M neurons of a shard as a
+// handful of row kernels -- one workgroup per neuron row -- around the fused ll+grad launch.  The reference calls
+// scipy.optimize.minimize(method="bfgs") per neuron (coord_descent.py:194-199); the row kernels run the same algorithm
+// for every neuron at once: BFGS from H = I, More'-Thuente line search for the strong Wolfe conditions
+// (pglm_linesearch.h: scipy's DCSRCH with scipy's constants and first trial step), termination on max|g| <= gtol or
+// maxiter iterations.  Where scipy gives up ("precision loss": the search reports a warning) the row takes the best
+// sufficient-decrease step of that search if there is one, else restarts once from steepest descent, then freezes.
+// All state lives in ONE device block of doubles (flags and counters included), laid out by pgl_bfgs_view; the dense
+// inverse Hessians H (M, P, ld) are the caller's buffer and are touched by k_bfgs_hmul only: ONE read-modify-write
+// pass per accepted iteration applies the pending rank-3 update H += U V^T of the previous iteration and multiplies
+// by the new gradient; a (re)started H = hscale * I is never materialised before its first update.
 // ---------------------------------------------------------------------------
+#include "pglm_linesearch.h"
+
 struct BfgsView {
     int M, P;
-    double *X, *g, *p, *Hg, *s, *y, *t;              // (M, P)
+    double *X, *g, *p, *Hg, *s, *y, *t, *Xb, *gb;    // (M, P)
     double *U, *V;                                   // (M, P, 3): H += U V^T is the BFGS update
-    double *f, *alpha, *slope, *rho, *scale, *iters, *restarts, *nhalf, *active, *frozen, *acc, *upd;   // (M)
+    double *f, *fprev, *alpha, *slope, *rho, *hscale, *iters, *restarts, *active, *frozen, *acc, *upd, *stall, *ident,
+           *pend, *fb, *nfev;                        // (M)
+    double* ls;                                      // (PGL_LS_NDOUBLES, M): line-search state, field-major
 };
-#define PGL_BFGS_NVEC 7
-#define PGL_BFGS_NSCAL 12
+#define PGL_BFGS_NVEC 9
+#define PGL_BFGS_NSCAL 17
+#define PGL_LS_FTOL 1e-4
+#define PGL_LS_GTOL 0.9
+#define PGL_LS_XTOL 1e-14
+#define PGL_LS_STPMIN 1e-100
+#define PGL_LS_STPMAX 1e100
 __host__ __device__ inline size_t pgl_bfgs_doubles(int M, int P)
 {
-    return (size_t)M * P * (PGL_BFGS_NVEC + 6) + (size_t)M * PGL_BFGS_NSCAL;
+    return (size_t)M * P * (PGL_BFGS_NVEC + 6) + (size_t)M * (PGL_BFGS_NSCAL + PGL_LS_NDOUBLES);
 }
 __host__ __device__ inline BfgsView pgl_bfgs_view(double* st, int M, int P)
 {
@@ -4991,12 +4991,28 @@ __host__ __device__ inline BfgsView pgl_bfgs_view(double* st, int M, int P)
     const size_t MP = (size_t)M * P;
     v.M = M; v.P = P;
     v.X = st; v.g = st + MP; v.p = st + 2 * MP; v.Hg = st + 3 * MP; v.s = st + 4 * MP; v.y = st + 5 * MP;
-    v.t = st + 6 * MP; v.U = st + 7 * MP; v.V = st + 10 * MP;
-    double* q = st + 13 * MP;
-    v.f = q; v.alpha = q + M; v.slope = q + 2 * M; v.rho = q + 3 * M; v.scale = q + 4 * M; v.iters = q + 5 * M;
-    v.restarts = q + 6 * M; v.nhalf = q + 7 * M; v.active = q + 8 * M; v.frozen = q + 9 * M; v.acc = q + 10 * M;
-    v.upd = q + 11 * M;
+    v.t = st + 6 * MP; v.Xb = st + 7 * MP; v.gb = st + 8 * MP; v.U = st + 9 * MP; v.V = st + 12 * MP;
+    double* q = st + 15 * MP;
+    v.f = q; v.fprev = q + M; v.alpha = q + 2 * M; v.slope = q + 3 * M; v.rho = q + 4 * M; v.hscale = q + 5 * M;
+    v.iters = q + 6 * M; v.restarts = q + 7 * M; v.active = q + 8 * M; v.frozen = q + 9 * M; v.acc = q + 10 * M;
+    v.upd = q + 11 * M; v.stall = q + 12 * M; v.ident = q + 13 * M; v.pend = q + 14 * M; v.fb = q + 15 * M;
+    v.nfev = q + 16 * M;
+    v.ls = q + (size_t)PGL_BFGS_NSCAL * M;
     return v;
+}
+#define PGL_LS_FIELDS(F) F(stp, 0) F(finit, 1) F(ginit, 2) F(gtest, 3) F(stx, 4) F(fx, 5) F(gx, 6) F(sty, 7) F(fy, 8) \
+    F(gy, 9) F(stmin, 10) F(stmax, 11) F(width, 12) F(width1, 13) F(brackt, 14) F(stage, 15) F(nfev, 16) F(moved, 17)
+__device__ __forceinline__ void pgl_ls_load(const BfgsView& v, int r, PglLs* s)
+{
+#define PGL_LS_LD(name, k) s->name = v.ls[(size_t)k * v.M + r];
+    PGL_LS_FIELDS(PGL_LS_LD)
+#undef PGL_LS_LD
+}
+__device__ __forceinline__ void pgl_ls_store(const BfgsView& v, int r, const PglLs* s)
+{
+#define PGL_LS_ST(name, k) v.ls[(size_t)k * v.M + r] = s->name;
+    PGL_LS_FIELDS(PGL_LS_ST)
+#undef PGL_LS_ST
 }
 
 // sum / max over the 256 threads of a block, result in every thread (fixed order)
@@ -5015,6 +5031,37 @@ __device__ __forceinline__ double pgl_blk_max(double v, double* red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// start of a fit: X, f, g of every row are in place; H = I (not materialised), steepest-descent direction, scipy's
+// first trial step min(1, 1.01 / |g|) (its old_old_fval = f + |g| / 2), rows with max|g| <= gtol never start
+__global__ __launch_bounds__(256) void k_bfgs_init(const BfgsView v, const double gtol)
+{
+    __shared__ double red[4];
+    const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
+    const size_t o = (size_t)r * P;
+    double gg = 0.0, gmax = 0.0;
+    for (int c = tid; c < P; c += 256) {
+        const double gc = v.g[o + c];
+        v.Hg[o + c] = gc;
+        v.p[o + c] = -gc;
+        gg = fma(gc, gc, gg);
+        gmax = fmax(gmax, fabs(gc));
+    }
+    gg = pgl_blk_sum(gg, red);
+    gmax = pgl_blk_max(gmax, red);
+    if (tid == 0) {
+        const double f = v.f[r], fprev = f + sqrt(gg) / 2.0, slope = -gg;
+        v.fprev[r] = fprev; v.slope[r] = slope; v.rho[r] = 0.0; v.hscale[r] = 1.0; v.iters[r] = 0.0; v.restarts[r] = 0.0;
+        v.frozen[r] = 0.0; v.acc[r] = 0.0; v.upd[r] = 0.0; v.stall[r] = 0.0; v.ident[r] = 1.0; v.pend[r] = 0.0;
+        v.fb[r] = f; v.nfev[r] = 0.0;
+        v.active[r] = gmax > gtol ? 1.0 : 0.0;
+        PglLs s;
+        const double a0 = pgl_ls_first_step(f, fprev, slope);
+        pgl_ls_start(&s, a0, f, slope, PGL_LS_FTOL, PGL_LS_STPMIN, PGL_LS_STPMAX);
+        pgl_ls_store(v, r, &s);
+        v.alpha[r] = a0;
+    }
 }
 
 // trial points of the listed rows: Xt[j] = X[r] + alpha[r] p[r], r = rows[j] (null: r = j)
@@ -5097,82 +5144,219 @@ __global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const doubl
         for (int c = tid; c < P; c += 256) g[c] = 0.0;
 }
 
-// Armijo test of the listed trials; accepted rows take the step (X, f, g) and leave s, y, s.y behind
-__global__ __launch_bounds__(256) void k_bfgs_accept(const BfgsView v, const int* __restrict__ rows,
-                                                     const double* __restrict__ Xt, const double* __restrict__ ft,
-                                                     const double* __restrict__ gt)
+// One line-search step of every listed row whose search is running: phi'(alpha) = g_trial . p, then the More'-Thuente
+// state machine.  Outcomes: another trial step (alpha[r]); the trial satisfies the strong Wolfe conditions and the row
+// takes it (X, f, g; s, y, rho left behind, acc = 1); or the search cannot make progress -- then the best
+// sufficient-decrease point of this search is taken if there is one (the trial itself or the saved best step, Xb / gb),
+// else stall = 1 (k_bfgs_update restarts or freezes the row).
+__global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const int* __restrict__ rows,
+                                                         const double* __restrict__ Xt, const double* __restrict__ ft,
+                                                         const double* __restrict__ gt, const int max_trials)
 {
     __shared__ double red[4];
+    __shared__ int dec[3];
     const int j = blockIdx.x, r = rows ? rows[j] : j, tid = threadIdx.x, P = v.P;
-    const bool act = v.active[r] != 0.0;
-    const bool ok = act && (ft[j] <= v.f[r] + 1e-4 * v.alpha[r] * v.slope[r]);
-    if (!ok) {
-        if (act && tid == 0) {                        // failed trial: halve the step
-            v.alpha[r] *= 0.5;
-            v.nhalf[r] += 1.0;
+    if (v.active[r] == 0.0) return;
+    const size_t o = (size_t)r * P, ot = (size_t)j * P;
+    double dp = 0.0;
+    for (int c = tid; c < P; c += 256) dp = fma(gt[ot + c], v.p[o + c], dp);
+    dp = pgl_blk_sum(dp, red);
+    if (tid == 0) {
+        // (the state machine is wave-uniform scalar code; routed through a vector register index so that its ~40 doubles
+        // live in VGPRs instead of spilling the scalar register file)
+        int rv = r;
+        asm volatile("" : "+v"(rv));
+        const int r = rv;
+        PglLs s;
+        pgl_ls_load(v, r, &s);
+        const double stp = s.stp;
+        double f = ft[j];
+        if (!(f <= 1e16)) f = 1e16;                          // +inf like NaN (fit_glm maps NaN only; scipy's search stops on inf)
+        int rc = pgl_ls_step(&s, f, dp, PGL_LS_FTOL, PGL_LS_GTOL, PGL_LS_XTOL, PGL_LS_STPMIN, PGL_LS_STPMAX);
+        if (rc == PGL_LS_EVALUATE && s.nfev >= (double)max_trials) rc = PGL_LS_WARNING;
+        int src = 0;                                         // 1: take the trial, 2: take the saved best step
+        const int moved = s.moved != 0.0;
+        if (rc == PGL_LS_CONVERGED) src = 1;
+        else if (rc == PGL_LS_WARNING) {
+            const bool okT = stp > 0.0 && f <= s.finit + stp * s.gtest && f < s.finit;
+            const bool okB = !moved && s.stx > 0.0 && v.fb[r] <= s.finit + s.stx * s.gtest && v.fb[r] < s.finit;
+            if (okT && (!okB || f <= v.fb[r])) src = 1;
+            else if (okB) src = 2;
+            if (src == 0) v.stall[r] = 1.0;
+        } else {
+            pgl_ls_store(v, r, &s);
+            v.alpha[r] = s.stp;
+            if (moved) v.fb[r] = f;
         }
+        v.nfev[r] += 1.0;
+        dec[0] = rc; dec[1] = src; dec[2] = moved;
+    }
+    __syncthreads();
+    const int rc = dec[0], src = dec[1];
+    if (rc == PGL_LS_EVALUATE) {
+        if (dec[2])                                          // the trial is the best step so far: keep its point and gradient
+            for (int c = tid; c < P; c += 256) {
+                v.Xb[o + c] = Xt[ot + c];
+                v.gb[o + c] = gt[ot + c];
+            }
         return;
     }
+    if (src == 0) return;
+    const double* xs = src == 1 ? Xt + ot : v.Xb + o;
+    const double* gs = src == 1 ? gt + ot : v.gb + o;
     double sy = 0.0;
     for (int c = tid; c < P; c += 256) {
-        const size_t i = (size_t)r * P + c, it = (size_t)j * P + c;
-        const double xn = Xt[it], gn = gt[it];
-        const double s = xn - v.X[i], y = gn - v.g[i];
-        v.s[i] = s;
-        v.y[i] = y;
-        v.X[i] = xn;
-        v.g[i] = gn;
+        const double xn = xs[c], gn = gs[c];
+        const double s = xn - v.X[o + c], y = gn - v.g[o + c];
+        v.s[o + c] = s;
+        v.y[o + c] = y;
+        v.X[o + c] = xn;
+        v.g[o + c] = gn;
         sy = fma(s, y, sy);
     }
     sy = pgl_blk_sum(sy, red);
     if (tid == 0) {
-        v.f[r] = ft[j];
+        double fn = src == 1 ? ft[j] : v.fb[r];
+        if (!(fn <= 1e16)) fn = 1e16;
+        v.fprev[r] = v.f[r];
+        v.f[r] = fn;
         v.acc[r] = 1.0;
-        const bool u = sy > 1e-12;
+        const double rho = 1.0 / sy;
+        const bool u = sy > 0.0 && rho - rho == 0.0;         // curvature condition holds (always after a Wolfe step)
         v.upd[r] = u ? 1.0 : 0.0;
-        v.rho[r] = u ? 1.0 / sy : 0.0;
+        v.rho[r] = u ? rho : 0.0;
     }
 }
 
-// after t = H g_new: the rank-3 factors of the inverse-Hessian update, H_new g_new, and the state machine of every row
-// (new direction / restart / freeze / convergence).  scale[r] != 0 asks for H[r] = I afterwards (k_identity_rows).
-__global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const double gtol, const int maxiter)
+// t = H g for the listed rows that have just taken a step (acc = 1), in the same pass over H that applies the pending
+// rank-3 update of the previous iteration: H <- H + U V^T (pend), t = H g.  A row whose H is still hscale * I (ident)
+// is materialised here together with its first update; without a pending update it is not touched at all
+// (k_bfgs_update uses t = hscale * g).  Grid (ceil(P / 32), L); a wave owns 8 rows of H, lanes run along the columns
+// in 16-byte pieces (ld even).  Traffic: one read + one write of P x ld doubles per row and accepted iteration.
+#define PGL_HM_ROWS 8
+__global__ __launch_bounds__(256) void k_bfgs_hmul(const BfgsView v, const int* __restrict__ rows,
+                                                   double* __restrict__ H, const int ld)
+{
+    const int j = blockIdx.y, r = rows ? rows[j] : j;
+    if (v.acc[r] == 0.0) return;
+    const bool ident = v.ident[r] != 0.0, pend = v.pend[r] != 0.0;
+    if (ident && !pend) return;
+    const int P = v.P, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 4 + wv) * PGL_HM_ROWS;
+    if (i0 >= P) return;
+    const double hs = v.hscale[r];
+    const double* __restrict__ g = v.g + (size_t)r * P;
+    const double* __restrict__ U = v.U + (size_t)r * P * 3;
+    const double* __restrict__ V = v.V + (size_t)r * P * 3;
+    double* Hr = H + (size_t)r * P * ld;
+    double acc[PGL_HM_ROWS], u[PGL_HM_ROWS][3];
+#pragma unroll
+    for (int k = 0; k < PGL_HM_ROWS; ++k) {
+        acc[k] = 0.0;
+        const int i = min(i0 + k, P - 1);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) u[k][e] = pend ? U[(size_t)i * 3 + e] : 0.0;
+    }
+    for (int c = 2 * lane; c < ld; c += 128) {
+        const bool in0 = c < P, in1 = c + 1 < P;
+        const double g0 = in0 ? g[c] : 0.0, g1 = in1 ? g[c + 1] : 0.0;
+        double va[3], vb[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            va[e] = (pend && in0) ? V[(size_t)c * 3 + e] : 0.0;
+            vb[e] = (pend && in1) ? V[(size_t)(c + 1) * 3 + e] : 0.0;
+        }
+        double2 h[PGL_HM_ROWS];
+#pragma unroll
+        for (int k = 0; k < PGL_HM_ROWS; ++k) {
+            const int i = i0 + k;
+            if (ident || i >= P) h[k] = make_double2(i == c ? hs : 0.0, i == c + 1 ? hs : 0.0);
+            else h[k] = *reinterpret_cast<const double2*>(Hr + (size_t)i * ld + c);
+        }
+#pragma unroll
+        for (int k = 0; k < PGL_HM_ROWS; ++k) {
+            const int i = i0 + k;
+            if (pend) {
+                h[k].x += u[k][0] * va[0] + u[k][1] * va[1] + u[k][2] * va[2];
+                h[k].y += u[k][0] * vb[0] + u[k][1] * vb[1] + u[k][2] * vb[2];
+                if (i < P) *reinterpret_cast<double2*>(Hr + (size_t)i * ld + c) = h[k];
+            }
+            acc[k] = fma(h[k].x, g0, fma(h[k].y, g1, acc[k]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PGL_HM_ROWS; ++k) {
+        double a = acc[k];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0 && i0 + k < P) v.t[(size_t)r * P + i0 + k] = a;
+    }
+}
+
+// After the line-search step (and t = H g_new for the rows that moved): the rank-3 factors of the inverse-Hessian
+// update  H_new = (I - rho s y^T) H (I - rho y s^T) + rho s s^T = H + U V^T,  H_new g_new, the next direction and the
+// start of its line search, restart / freeze of stalled rows, convergence flags.  init_scaling != 0: the first update
+// after a (re)start is preceded by H <- (s.y / y.y) I (Nocedal & Wright (6.20); not scipy's behaviour).
+__global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const double gtol, const int maxiter,
+                                                     const int init_scaling)
 {
     __shared__ double red[4];
     const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
     const size_t o = (size_t)r * P;
-    const bool act = v.active[r] != 0.0, a = v.acc[r] != 0.0, u = v.upd[r] != 0.0;
+    const bool act = v.active[r] != 0.0, a = v.acc[r] != 0.0, u = v.upd[r] != 0.0, st = v.stall[r] != 0.0;
+    if (!act || (!a && !st)) return;                         // finished, or in the middle of a line search
     double* U = v.U + o * 3;
     double* V = v.V + o * 3;
-    if (u) {
-        const double rho = v.rho[r];
-        double yHy = 0.0, vg0 = 0.0, vg2 = 0.0;
-        for (int c = tid; c < P; c += 256) {
-            const double Hy = v.t[o + c] - v.Hg[o + c];
-            yHy = fma(v.y[o + c], Hy, yHy);
-            vg0 = fma(v.s[o + c], v.g[o + c], vg0);
-            vg2 = fma(Hy, v.g[o + c], vg2);
+    bool ident = v.ident[r] != 0.0, pend = v.pend[r] != 0.0;
+    double hs = v.hscale[r];
+    double restarts = v.restarts[r], iters = v.iters[r];
+    bool frozen = false, again = false;
+    if (a) {
+        const bool lazy = ident && !pend;                    // H = hs * I: k_bfgs_hmul left t alone
+        iters += 1.0;
+        restarts = 0.0;
+        if (u) {
+            const double rho = v.rho[r];
+            double sc = 1.0;
+            if (init_scaling && lazy) {                      // H <- (s.y / y.y) I before the first update
+                double yy = 0.0;
+                for (int c = tid; c < P; c += 256) yy = fma(v.y[o + c], v.y[o + c], yy);
+                yy = pgl_blk_sum(yy, red);
+                const double gam = (1.0 / rho) / yy;
+                if (gam > 0.0 && gam - gam == 0.0) { sc = gam / hs; hs = gam; }
+            }
+            double yHy = 0.0, vg0 = 0.0, vg2 = 0.0;
+            for (int c = tid; c < P; c += 256) {
+                const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
+                const double Hy = tc - sc * v.Hg[o + c];
+                yHy = fma(v.y[o + c], Hy, yHy);
+                vg0 = fma(v.s[o + c], v.g[o + c], vg0);
+                vg2 = fma(Hy, v.g[o + c], vg2);
+            }
+            yHy = pgl_blk_sum(yHy, red);
+            vg0 = pgl_blk_sum(vg0, red);
+            vg2 = pgl_blk_sum(vg2, red);
+            const double c0 = (1.0 + rho * yHy) * rho;
+            for (int c = tid; c < P; c += 256) {
+                const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
+                const double s = v.s[o + c], Hy = tc - sc * v.Hg[o + c];
+                const double u0 = c0 * s, u1 = -rho * Hy, u2 = -rho * s;
+                U[3 * c] = u0; U[3 * c + 1] = u1; U[3 * c + 2] = u2;
+                V[3 * c] = s; V[3 * c + 1] = s; V[3 * c + 2] = Hy;
+                v.Hg[o + c] = tc + (u0 * vg0 + u1 * vg0 + u2 * vg2);          // H_new g_new
+            }
+            ident = lazy;                                    // still not materialised: hs * I + U V^T at the next pass
+            pend = true;
+        } else {
+            for (int c = tid; c < P; c += 256) v.Hg[o + c] = lazy ? hs * v.g[o + c] : v.t[o + c];
+            ident = lazy;
+            pend = false;
         }
-        yHy = pgl_blk_sum(yHy, red);
-        vg0 = pgl_blk_sum(vg0, red);
-        vg2 = pgl_blk_sum(vg2, red);
-        const double c0 = (1.0 + rho * yHy) * rho;
-        for (int c = tid; c < P; c += 256) {
-            const double s = v.s[o + c], Hy = v.t[o + c] - v.Hg[o + c];
-            const double u0 = c0 * s, u1 = -rho * Hy, u2 = -rho * s;
-            U[3 * c] = u0; U[3 * c + 1] = u1; U[3 * c + 2] = u2;
-            V[3 * c] = s; V[3 * c + 1] = s; V[3 * c + 2] = Hy;
-            v.Hg[o + c] = v.t[o + c] + (u0 * vg0 + u1 * vg0 + u2 * vg2);      // H_new g_new
-        }
-    } else {
-        for (int c = tid; c < P; c += 256) {
-            U[3 * c] = 0.0; U[3 * c + 1] = 0.0; U[3 * c + 2] = 0.0;
-            V[3 * c] = 0.0; V[3 * c + 1] = 0.0; V[3 * c + 2] = 0.0;
-            v.Hg[o + c] = v.t[o + c];
-        }
+        __syncthreads();
+    } else {                                                 // stalled line search: restart once, then freeze
+        again = restarts == 0.0;
+        if (again) restarts = 1.0;
+        else frozen = true;
     }
-    __syncthreads();
-    // ---- state machine ----
     double sl = 0.0, gg = 0.0, gmax = 0.0;
     for (int c = tid; c < P; c += 256) {
         const double gc = v.g[o + c];
@@ -5183,36 +5367,39 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
     sl = pgl_blk_sum(sl, red);
     gg = pgl_blk_sum(gg, red);
     gmax = pgl_blk_max(gmax, red);
-    const double iters = v.iters[r] + (a ? 1.0 : 0.0);
-    double restarts = a ? 0.0 : v.restarts[r];
-    const bool fail = act && !a;
-    const bool stalled = fail && v.nhalf[r] >= 30.0;
-    const bool again = stalled && restarts == 0.0;
-    const bool frozen = (v.frozen[r] != 0.0) || (stalled && !again);
-    if (again) restarts += 1.0;
     const bool newls = a || again;
-    const bool reset = (newls && sl >= 0.0) || again;       // not a descent direction / restart: H = I
-    if (newls) {
+    const bool reset = newls && (again || !(sl < 0.0));      // restart / not a descent direction: H = I
+    if (newls)
         for (int c = tid; c < P; c += 256) {
             const double gc = v.g[o + c];
             if (reset) v.Hg[o + c] = gc;
             v.p[o + c] = reset ? -gc : -v.Hg[o + c];
         }
-    } else if (reset) {
-        for (int c = tid; c < P; c += 256) v.Hg[o + c] = v.g[o + c];
-    }
     if (tid == 0) {
         v.iters[r] = iters;
         v.restarts[r] = restarts;
-        v.frozen[r] = frozen ? 1.0 : 0.0;
-        v.scale[r] = reset ? 1.0 : 0.0;
-        if (newls) {
-            v.slope[r] = reset ? -gg : sl;
-            v.alpha[r] = again ? fmin(1.0 / fmax(sqrt(gg), 1e-300), 1.0) : 1.0;
-            v.nhalf[r] = 0.0;
+        if (frozen) v.frozen[r] = 1.0;
+        if (reset) { ident = true; pend = false; hs = 1.0; }
+        v.ident[r] = ident ? 1.0 : 0.0;
+        v.pend[r] = pend ? 1.0 : 0.0;
+        v.hscale[r] = hs;
+        const bool go = !frozen && gmax > gtol && iters < (double)maxiter;
+        if (newls && go) {
+            const double slope = reset ? -gg : sl;
+            const double f = v.f[r];
+            const double fprev = again ? f + sqrt(gg) / 2.0 : v.fprev[r];
+            v.fprev[r] = fprev;
+            v.slope[r] = slope;
+            PglLs s;
+            const double a0 = pgl_ls_first_step(f, fprev, slope);
+            pgl_ls_start(&s, a0, f, slope, PGL_LS_FTOL, PGL_LS_STPMIN, PGL_LS_STPMAX);
+            pgl_ls_store(v, r, &s);
+            v.alpha[r] = a0;
+            v.fb[r] = f;
         }
-        v.active[r] = (act && !frozen && gmax > gtol && iters < (double)maxiter) ? 1.0 : 0.0;
+        v.active[r] = go ? 1.0 : 0.0;
         v.acc[r] = 0.0;                                      // cleared for the next launch
         v.upd[r] = 0.0;
+        v.stall[r] = 0.0;
     }
 }

@@ -3,11 +3,13 @@ Lock-step BFGS for all neurons with the optimizer state resident on the GPU.
 
 The N per-neuron MAP problems of coord_descent (coord_descent.py:161-204, 243-247) are independent given
 the network (neuron n's parameters only enter ll_n), so the whole sweep over n = 0..N-1
-runs as one batched BFGS: per trial point one fused ll+grad launch on device pointers; the priors, the
-chain rules between the model's own variables and the flat feature weights the device consumes, and the
-dense inverse-Hessian updates (M x P x P) are torch tensor ops on the same GPU -- nothing but a few scalars
-crosses PCIe.  PyTorch is plumbing here (device memory + batched BLAS); the likelihood and its gradient
-come from the HIP kernels.
+runs as one batched BFGS: per trial step one fused ll+grad launch on device pointers, and around it the
+optimizer itself as HIP row kernels (pgl_bfgs_*: one workgroup per neuron) -- the algorithm scipy runs for
+the reference (BFGS from H = I, More'-Thuente strong-Wolfe line search with scipy's constants and first
+trial step, csrc/pglm_linesearch.h), so a neuron's iterates are those of its sequential scipy fit up to
+rounding; the dense inverse Hessians (M x P x P) are read and written once per accepted iteration
+(pgl_bfgs_hmul_dev).  Nothing but the active flags crosses PCIe.  PyTorch is plumbing here (device memory,
+and the chain rules / priors of the packings whose rows are not the device's own theta rows).
 
 Every packing of coord_descent's per-neuron vector that the scoped models produce is served
 (`_Packing`): [bias, w_stim, w_ir] (standard_glm: the vector IS the device's theta row),
@@ -41,7 +43,7 @@ class _Packing(object):
     BFGS started from H = I is equivariant under permutations of the coordinates, so the order of the
     blocks inside a row (here: bias, bkgd, imp in natural neuron order) does not change the iterates."""
 
-    def __init__(self, population, torch):
+    def __init__(self, population, torch, handles=(), shard=None):
         self.torch = torch
         glm = population.glm
         self.glm = glm
@@ -58,13 +60,12 @@ class _Packing(object):
         self.dirichlet = isinstance(glm.imp_model, DirichletImpulses)
         self.Pp = 1 + self.nbk + self.N * self.B
         # pgl_ll_grad_list_dev with a separable stimulus: only when the device evaluates it at the frame rate
-        # (pgl_info 'stim_path' == 2; the tap-rate kernels take neuron ranges only)
+        # (pgl_info 'stim_path' == 2; the tap-rate kernels take neuron ranges only) -- on EVERY handle that will be
+        # launched, for the whole shard and for a one-neuron list
         sepf = False
-        if self.bk == 'st_sep' and getattr(population, '_current', None) is not None:
-            try:
-                sepf = population._handle(population._current).info()['stim_path'] == 2
-            except Exception:
-                sepf = False
+        if self.bk == 'st_sep' and handles:
+            lo, hi = (0, self.N) if shard is None else shard
+            sepf = all(h.info(a, b)['stim_path'] == 2 for h in handles for (a, b) in ((lo, hi), (lo, lo + 1)))
         self.list_launch = self.bk != 'st_sep' or sepf
         # the row IS the device's theta row and its prior is one of the forms the row kernels know
         # (pgl_bfgs_objective_dev): the whole state machine then runs as HIP row kernels.  Separable stimulus: the block
@@ -199,29 +200,29 @@ class _Packing(object):
 
 
 def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False,
-                           reduce=None, lag=None, init_scaling=False, row_kernels=True):
+                           reduce=None, lag=None, init_scaling=False, max_trials=100):
     """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations).
 
     Everything runs on one dedicated torch stream that the device handles are switched to
-    (pgl_set_stream): prior terms, the fused ll+grad launches, the line-search bookkeeping and the
-    inverse-Hessian updates are ordered by the stream, and the host never waits for the launch it has
+    (pgl_set_stream): trial points, the fused ll+grad launches, priors, the line-search steps and the
+    inverse-Hessian passes are ordered by the stream, and the host never waits for the launch it has
     just queued.  What steers the loop -- which neurons are still active -- reaches the host `lag`
-    launches late (default: 1 with the HIP row kernels, 2 with framework tensor ops) through pinned memory: the active set only ever shrinks, so a launch over the stale
-    (larger) list evaluates a few rows whose results are masked out on the device, and the host keeps
-    queueing torch ops while the GPU is busy with the previous evaluations.  Neurons that have converged
+    launches late (default 1) through pinned memory: the active set only ever shrinks, so a launch over the
+    stale (larger) list evaluates a few rows whose results the row kernels ignore, and the host keeps
+    queueing while the GPU is busy with the previous evaluations.  Neurons that have converged
     drop out of the launch list (pgl_ll_grad_list_dev evaluates an arbitrary list of neurons), so late,
-    poorly conditioned neurons do not pay for the whole population.  A neuron whose backtracking fails
-    restarts once from steepest descent before it is frozen (scipy's BFGS stops there with "precision
-    loss", coord_descent.py:194-199).
+    poorly conditioned neurons do not pay for the whole population.
 
-    `row_kernels`: for rows that are the device's own theta rows (standard_glm-like models) the line-search and
-    update bookkeeping runs as HIP row kernels (_lockstep_bfgs_rows); False keeps it in framework tensor ops
-    (same iterates; the path every other packing takes).
+    Every neuron runs its own state machine -- "line search at step alpha along p" -- and every launch
+    evaluates the pending trial step of the listed neurons, whichever iteration each of them is in: a neuron
+    whose step is accepted moves on without waiting for the others.  Where scipy's BFGS gives up on a line
+    search ("precision loss", coord_descent.py:194-199) the neuron takes the best sufficient-decrease step of
+    that search if there is one, else restarts once from steepest descent, then is frozen.
 
     `init_scaling`: scale the identity of a (re)started inverse Hessian by s.y / y.y before the first update
-    (Nocedal & Wright 6.20).  Off by default, like scipy's BFGS: measured on the named configurations it cuts the
-    evaluations of the badly scaled spatiotemporal_glm (impulse prior precision 1e6 next to O(1e3) curvatures) from
-    4 700 to 250 per 225 iterations, but costs standard_glm 5x the iterations (C3: 22 -> 121).
+    (Nocedal & Wright 6.20).  Off by default, like scipy's BFGS.
+
+    `max_trials`: trial steps per line search (scipy's DCSRCH: 100).
 
     `reduce`: optional callable applied in place to the packed device tensor [ll | grad] of every
     evaluation before the priors are added -- the all-reduce of a time-sharded multi-GPU fit (every rank
@@ -245,8 +246,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     try:
         with torch.cuda.stream(stream):
             out = _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M,
-                                 verbose, reduce, max(0, int(lag)) if lag is not None else None, init_scaling,
-                                 row_kernels)
+                                 verbose, reduce, 1 if lag is None else max(0, int(lag)), init_scaling, max_trials)
             stream.synchronize()
     finally:
         # also on the error path: kernels still queued on `stream` read the optimizer state and the handles' scratch;
@@ -260,59 +260,67 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     return out
 
 
-def _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce,
-                        lag, pk):
-    """The same state machines as _lockstep_bfgs with all row-wise bookkeeping in HIP row kernels
-    (pgl_bfgs_trial / objective / accept / update_dev, one workgroup per neuron row): per launch of trial points
-    ~10 kernels -- trial, fused ll+grad, objective, accept, batched GEMV, update, batched rank-3 update, identity
-    rows, the copy of the active flags -- instead of ~110 framework kernels of 4 us each.  For rows that are the
-    device's own theta rows [bias, w_stim, w_ir] (standard_glm-like models)."""
+def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce,
+                   lag, init_scaling, max_trials):
+    pk = _Packing(population, torch, handles, (n_lo, n_hi))
     h0 = handles[0]
-    P = pk.Pp
+    P = pk.Pp                                                 # length of an optimisation row
+    Pth = population.glm.P                                    # length of a device theta row
+    ld = P + (P & 1)
     nst = h0.bfgs_state_doubles(M, P)
     st = torch.zeros(nst, dtype=torch.float64, device=dev)
     MP = M * P
-
-    def vec(i):
-        return st[i * MP:(i + 1) * MP].view(M, P)
-    X, g, p, Hg, t_ = vec(0), vec(1), vec(2), vec(3), vec(6)
-    U, V = st[7 * MP:10 * MP].view(M, P, 3), st[10 * MP:13 * MP].view(M, P, 3)
-    sc = st[13 * MP:].view(12, M)
-    f, alpha, slope, scale, iters, active, frozen = sc[0], sc[1], sc[2], sc[4], sc[5], sc[8], sc[9]
+    X, g = st[0:MP].view(M, P), st[MP:2 * MP].view(M, P)
+    sc = st[15 * MP:].view(-1, M)
+    f, iters, active, frozen, nfev = sc[0], sc[6], sc[8], sc[9], sc[16]
+    # dense inverse Hessians: touched by pgl_bfgs_hmul_dev only, written before they are read
+    H = torch.empty((M, P, ld), dtype=torch.float64, device=dev)
     X.copy_(torch.tensor(pk.pack(x, n_lo, n_hi), dtype=torch.float64, device=dev))
     Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
-    prm = pk.prior_params()
+    prm = pk.prior_params() if pk.identity else None
     n_evals, neuron_evals = [0], [0]
 
-    def evaluate(Xt, idx32, L):
-        """f and g (fit_glm's NaN rules applied) of the L rows Xt for the neurons idx32 (None: the whole shard);
-        returned as views of one block [f | g]."""
+    def evaluate(Xt, rows32, idx32, L):
+        """f = -(log prior + sum_data ll) and its gradient (fit_glm's NaN rules applied) at the L rows Xt of the
+        neurons idx32 (None: the whole shard); returned as (L,), (L, P) contiguous tensors."""
+        scatter = idx32 is not None and not pk.list_launch
+        if scatter:
+            # no neuron lists on this device path: the whole shard with the trial rows scattered into the current point
+            Xe = X.index_copy(0, rows32.long(), Xt)
+            th, ecnt, eidx = pk.theta(Xe), M, None
+        else:
+            th, ecnt, eidx = (Xt if pk.identity else pk.theta(Xt)), L, idx32
         tot = None
         for h in handles:
-            buf = torch.empty(L * (1 + P), dtype=torch.float64, device=dev)      # [ll | grad]: one all-reduce
-            if idx32 is None:
-                h.ll_grad_dev(Xt.data_ptr(), Weff.data_ptr(), buf.data_ptr(), buf[L:].data_ptr(), n_lo, n_hi)
+            buf = torch.empty(ecnt * (1 + Pth), dtype=torch.float64, device=dev)      # [ll | grad]: one all-reduce
+            if eidx is None:
+                h.ll_grad_dev(th.data_ptr(), Weff.data_ptr(), buf.data_ptr(), buf[ecnt:].data_ptr(), n_lo, n_hi)
             else:
-                h.ll_grad_list_dev(idx32.data_ptr(), L, Xt.data_ptr(), Weff.data_ptr(), buf.data_ptr(),
-                                   buf[L:].data_ptr())
+                h.ll_grad_list_dev(eidx.data_ptr(), ecnt, th.data_ptr(), Weff.data_ptr(), buf.data_ptr(),
+                                   buf[ecnt:].data_ptr())
             if reduce is not None:
                 reduce(buf)
             tot = buf if tot is None else tot.add_(buf)
-        h0.bfgs_objective_dev(L, P, Xt.data_ptr(), tot.data_ptr(), tot[L:].data_ptr(), *prm)
         n_evals[0] += 1
-        neuron_evals[0] += L
-        return tot[:L], tot[L:].view(L, P)
+        neuron_evals[0] += ecnt
+        if pk.identity:                                       # rows are theta rows: priors + NaN rules in one row kernel
+            h0.bfgs_objective_dev(L, P, Xt.data_ptr(), tot.data_ptr(), tot[L:].data_ptr(), *prm)
+            return tot[:L], tot[L:].view(L, P)
+        llt, Gth = tot[:ecnt], tot[ecnt:].view(ecnt, Pth)
+        if scatter:
+            llt, Gth = llt[rows32.long()], Gth[rows32.long()]
+        lp, G = pk.prior(Xt)
+        fv = -(lp + llt)
+        gv = -(G + pk.chain(Xt, Gth))
+        fv = torch.where(torch.isnan(fv), torch.full_like(fv, 1e16), fv)
+        gv = torch.where(torch.isnan(gv).any(1)[:, None], torch.zeros_like(gv), gv)
+        return fv.contiguous(), gv.contiguous()
 
-    f0, g0 = evaluate(X, None, M)
+    f0, g0 = evaluate(X, None, None, M)
     f.copy_(f0)
     g.copy_(g0)
-    Hg.copy_(g0)
-    p.copy_(-g0)
-    slope.copy_(-(g0 * g0).sum(1))
-    alpha.copy_(torch.clamp(1.0 / g0.norm(dim=1).clamp_min(1e-300), max=1.0))
-    active.copy_((g0.abs().amax(1) > gtol).to(torch.float64))
-    H = torch.eye(P, dtype=torch.float64, device=dev).repeat(M, 1, 1)
-    max_launches = maxiter * 31 + 2
+    h0.bfgs_init_dev(st.data_ptr(), M, P, gtol)
+    max_launches = maxiter * 20 + 2
     ring = [torch.empty(M, dtype=torch.float64).pin_memory() for _ in range(lag + 1)]
     pending = []
 
@@ -346,12 +354,10 @@ def _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gto
         Xt = torch.empty((L, P), dtype=torch.float64, device=dev)
         rp = rows32.data_ptr() if rows32 is not None else 0
         h0.bfgs_trial_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr())
-        ft, gt = evaluate(Xt, idx32, L)
-        h0.bfgs_accept_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr(), ft.data_ptr(), gt.data_ptr())
-        torch.bmm(H, g.unsqueeze(2), out=t_.unsqueeze(2))       # t = H g_new: the one full read of H per launch
-        h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter)
-        H.baddbmm_(U, V.transpose(1, 2))                        # H += U V^T (zero factors for rows without an update)
-        h0.reset_identity_dev(H.data_ptr(), scale.data_ptr(), M, P)
+        ft, gt = evaluate(Xt, rows32, idx32, L)
+        h0.bfgs_linesearch_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr(), ft.data_ptr(), gt.data_ptr(), max_trials)
+        h0.bfgs_hmul_dev(st.data_ptr(), M, P, rp, L, H.data_ptr(), ld)       # rows that moved: H += U V^T, t = H g
+        h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling)
         publish(launches)
     it = int(iters.max())
     gmax = g.abs().amax(1)
@@ -360,192 +366,13 @@ def _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gto
     pk.unpack(x, X.cpu().numpy(), n_lo, n_hi)
     population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
                                  'neuron_evaluations': neuron_evals[0],
+                                 'line_search_steps': int(nfev.sum()),
+                                 'neuron_iterations': int(iters.sum()),
                                  'converged_gtol': n_conv, 'stalled': n_frozen,
-                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'hip row kernels',
-                                 'lag': lag, 'init_scaling': False}
-    return f.cpu().numpy(), it, n_evals[0]
-
-
-def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose,
-                   reduce=None, lag=2, init_scaling=False, row_kernels=True):
-    pk = _Packing(population, torch)
-    if row_kernels and pk.identity and not init_scaling:
-        # (queueing a launch takes ~10 library calls here: one launch of run-ahead keeps the GPU fed)
-        return _lockstep_bfgs_rows(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose,
-                                   reduce, 1 if lag is None else lag, pk)
-    lag = 2 if lag is None else lag
-    X = torch.tensor(pk.pack(x, n_lo, n_hi), dtype=torch.float64, device=dev)
-    Pp = X.shape[1]
-    P = population.glm.P
-    Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
-    n_evals = [0]
-    neuron_evals = [0]
-    rows_all = torch.arange(M, device=dev)
-
-    def evaluate(Xt, rows, Xfull=None):
-        """nlp and its gradient at the rows Xt (cnt, Pp) of the neurons `rows` (None: the whole shard)."""
-        cnt = Xt.shape[0]
-        lp, G = pk.prior(Xt)
-        if rows is not None and not pk.list_launch:
-            # no neuron lists on this device path: evaluate the whole shard with the trial rows scattered
-            # into the current point
-            Xe = Xfull.index_copy(0, rows, Xt)
-            th, idx, ecnt = pk.theta(Xe), None, M
-        else:
-            th = pk.theta(Xt)
-            idx = None if rows is None else (rows + n_lo).to(torch.int32).contiguous()
-            ecnt = cnt
-        Gth = torch.zeros((ecnt, P), dtype=torch.float64, device=dev) if len(handles) > 1 else None
-        llt = None
-        for h in handles:
-            buf = torch.empty(ecnt * (1 + P), dtype=torch.float64, device=dev)     # [ll | grad]: one all-reduce
-            ll, gr = buf[:ecnt], buf[ecnt:].view(ecnt, P)
-            if idx is None:
-                h.ll_grad_dev(th.data_ptr(), Weff.data_ptr(), ll.data_ptr(), gr.data_ptr(), n_lo, n_hi)
-            else:
-                h.ll_grad_list_dev(idx.data_ptr(), ecnt, th.data_ptr(), Weff.data_ptr(), ll.data_ptr(),
-                                   gr.data_ptr())
-            if reduce is not None:
-                reduce(buf)
-            llt = ll if llt is None else llt + ll
-            Gth = gr if Gth is None else Gth.add_(gr)
-        if ecnt != cnt:
-            llt, Gth = llt[rows], Gth[rows]
-        lp = lp + llt
-        G = G + pk.chain(Xt, Gth)
-        n_evals[0] += 1
-        neuron_evals[0] += ecnt
-        f, g = -lp, -G
-        f = torch.where(torch.isnan(f), torch.full_like(f, 1e16), f)
-        bad = torch.isnan(g).any(1)
-        g = torch.where(bad[:, None], torch.zeros_like(g), g)
-        return f, g
-
-    f, g = evaluate(X, None)
-    eye = torch.eye(Pp, dtype=torch.float64, device=dev)
-    H = eye.repeat(M, 1, 1)
-    Hg = g.clone()                                              # H g, carried along: one pass over H per launch
-    active = g.abs().amax(1) > gtol
-    frozen = torch.zeros(M, dtype=torch.bool, device=dev)       # line search failed twice in a row
-    restarts = torch.zeros(M, dtype=torch.int64, device=dev)
-    iters = torch.zeros(M, dtype=torch.int64, device=dev)       # BFGS iterations of every neuron
-    nhalf = torch.zeros(M, dtype=torch.int64, device=dev)       # step halvings of the current line search
-    fresh = torch.ones(M, dtype=torch.bool, device=dev)         # H is still the identity of a (re)start
-
-    def first_step(gg):
-        return torch.clamp(1.0 / gg.norm(dim=1).clamp_min(1e-300), max=1.0)
-
-    # Every neuron runs its own BFGS state machine -- "line search at step alpha along p" -- and every launch
-    # evaluates the pending trial point of the listed neurons, whether that is the first trial of a new
-    # iteration or a backtracking trial: a neuron whose trial succeeds moves on to its next iteration without
-    # waiting for the neurons that still backtrack.  The iterates of a neuron are those of the iteration-
-    # synchronous loop (its trial points do not depend on the others); the number of launches is the largest
-    # number of trials any neuron needs instead of the sum over iterations of the per-iteration maximum.
-    p = -Hg
-    slope = (p * g).sum(1)
-    alpha = first_step(g)
-    max_launches = maxiter * 31 + 2
-    # the active mask reaches the host `lag` launches late (pinned ring + events)
-    ring = [torch.empty(M, dtype=torch.bool).pin_memory() for _ in range(lag + 1)]
-    pending = []
-
-    def publish(k):
-        hb = ring[k % (lag + 1)]
-        hb.copy_(active, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        pending.append((hb, ev))
-
-    publish(0)
-    rows, L = None, M                                           # launch list (None: all M rows) and its length
-    launches = 0
-    while launches < max_launches:
-        if len(pending) > lag:
-            hb, ev = pending.pop(0)
-            ev.synchronize()                                    # a launch `lag` back: normally long done
-            act_h = hb.numpy()
-            n_act = int(act_h.sum())
-            if n_act == 0:
-                break
-            if n_act < L:
-                idx_h = np.nonzero(act_h)[0]
-                L = n_act
-                rows = torch.from_numpy(idx_h).to(dev, non_blocking=True)
-            if verbose:
-                print("batched BFGS launch %d: %d neurons active %d launches ago, list of %d"
-                      % (launches, n_act, lag, L))
-        launches += 1
-        ridx = rows_all if rows is None else rows
-        Xr, ar = X[ridx], alpha[ridx]
-        Xt = Xr + ar[:, None] * p[ridx]
-        ft, gt = evaluate(Xt, rows, X)
-        ok = active[ridx] & (ft <= f[ridx] + 1e-4 * ar * slope[ridx])
-        acc = torch.zeros(M, dtype=torch.bool, device=dev)
-        acc[ridx] = ok
-        fail = active & ~acc
-        # ---- failed trials: halve the step; after 30 halvings restart once from steepest descent, then freeze
-        alpha = torch.where(fail, alpha * 0.5, alpha)
-        nhalf = torch.where(fail, nhalf + 1, nhalf)
-        stalled = fail & (nhalf >= 30)
-        # ---- accepted trials: BFGS update of H with (s, y), new direction
-        Xn = X.index_copy(0, ridx, torch.where(ok[:, None], Xt, Xr))
-        fn = f.index_copy(0, ridx, torch.where(ok, ft, f[ridx]))
-        gn = g.index_copy(0, ridx, torch.where(ok[:, None], gt, g[ridx]))
-        s = Xn - X
-        y = gn - g
-        sy = (s * y).sum(1)
-        upd = acc & (sy > 1e-12)
-        # first update after a (re)start from H = I: H <- (s.y / y.y) I before the update (Nocedal & Wright 6.20) --
-        # BFGS from the identity learns one direction per iteration, and a prior of precision 1e6 on 192 of 199
-        # coordinates (spatiotemporal_glm's impulse weights) would cost it ~200 iterations of 20 step halvings each
-        first = upd & fresh
-        gam = torch.where(first, sy / (y * y).sum(1).clamp_min(1e-300), torch.ones_like(sy))
-        if init_scaling:
-            handles[0].reset_identity_dev(H.data_ptr(), torch.where(first, gam, torch.zeros_like(gam)).data_ptr(), M, Pp)
-            Hg = Hg * gam[:, None]
-        fresh = fresh & ~upd
-        # H g_new: the one full read of H (M x P x P) per launch; H y = H g_new - H g follows from it
-        t = torch.bmm(H, gn[:, :, None])[:, :, 0]
-        rho = torch.where(upd, 1.0 / sy.clamp_min(1e-300), torch.zeros_like(sy))
-        Hy = torch.where(upd[:, None], t - Hg, torch.zeros_like(t))
-        yHy = (y * Hy).sum(1)
-        c = (1.0 + rho * yHy) * rho
-        # H += c s s^T - rho (Hy s^T + s Hy^T) as ONE rank-3 update: a single read-modify-write of H
-        # (rows without an update carry rho = 0: their H is rewritten unchanged)
-        U = torch.stack((c[:, None] * s, -rho[:, None] * Hy, -rho[:, None] * s), dim=2)       # (M, P, 3)
-        V = torch.stack((s, s, Hy), dim=2)                                                    # (M, P, 3)
-        H.baddbmm_(U, V.transpose(1, 2))
-        t = t + torch.bmm(U, torch.bmm(V.transpose(1, 2), gn[:, :, None]))[:, :, 0]          # H_new g_new
-        X, f, g, Hg = Xn, fn, gn, t
-        iters = torch.where(acc, iters + 1, iters)
-        restarts = torch.where(acc, torch.zeros_like(restarts), restarts)
-        again = stalled & (restarts == 0)
-        frozen = frozen | (stalled & ~again)
-        restarts = torch.where(again, restarts + 1, restarts)
-        # new line search for the accepted and the restarted neurons
-        newls = acc | again
-        pn = -Hg
-        sl = (pn * g).sum(1)
-        reset = (newls & (sl >= 0)) | again                         # not a descent direction / restart: H = I
-        handles[0].reset_identity_dev(H.data_ptr(), reset.to(torch.float64).data_ptr(), M, Pp)   # only the flagged rows
-        fresh = fresh | reset
-        Hg = torch.where(reset[:, None], g, Hg)
-        pn = torch.where(reset[:, None], -g, pn)
-        sl = torch.where(reset, (pn * g).sum(1), sl)
-        p = torch.where(newls[:, None], pn, p)
-        slope = torch.where(newls, sl, slope)
-        alpha = torch.where(newls, torch.where(again, first_step(g), torch.ones_like(alpha)), alpha)
-        nhalf = torch.where(newls, torch.zeros_like(nhalf), nhalf)
-        active = active & (~frozen) & (g.abs().amax(1) > gtol) & (iters < maxiter)
-        publish(launches)
-    it = int(iters.max())
-    gmax = g.abs().amax(1)
-    n_conv = int((gmax <= gtol).sum())
-    n_frozen = int((frozen & (gmax > gtol)).sum())
-    pk.unpack(x, X.cpu().numpy(), n_lo, n_hi)
-    population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
-                                 'neuron_evaluations': neuron_evals[0],
-                                 'converged_gtol': n_conv, 'stalled': n_frozen,
-                                 'maxiter': M - n_conv - n_frozen, 'bookkeeping': 'torch tensor ops',
-                                 'lag': lag, 'init_scaling': bool(init_scaling)}
+                                 'maxiter': M - n_conv - n_frozen,
+                                 'bookkeeping': 'hip row kernels' + ('' if pk.identity else ' (priors / chain rule: torch)'),
+                                 'line_search': "More'-Thuente strong Wolfe (scipy's DCSRCH constants)",
+                                 'lag': lag, 'init_scaling': bool(init_scaling),
+                                 'per_neuron': {'iterations': [int(v) for v in iters.cpu().numpy()],
+                                                'line_search_steps': [int(v) for v in nfev.cpu().numpy()]}}
     return f.cpu().numpy(), it, n_evals[0]
