@@ -719,6 +719,13 @@ def test_lockstep_map_separable_stimulus_row_kernels_and_lists():
     for n in (0, 3, 5):
         nv = popn.extract_vars(copy.deepcopy(x0), n)
         res = cd.fit_glm(nv, n, prms)
+        if res.status == 2 and res.nit <= 2:
+            # neuron 3 starts at an objective of 4e21 (exp nonlinearity, prior draw of the stimulus weights): scipy's first
+            # line search meets inf, its fallback search fails and the fit stops where it started ("precision loss");
+            # the lock-step fit takes the best sufficient-decrease point of the stuck search and carries on to the optimum
+            assert n == 3 and res.fun > 1e20 and fa[n] < 0.0 and sa['per_neuron']['iterations'][n] > 20, (n, res.fun, fa[n])
+            assert np.max(np.abs(popn.compute_grad(xa, n))) < 1e-3
+            continue
         # (~100+ BFGS iterations: list launches sum the listed rows in another order than range launches, the two
         #  trajectories drift apart by rounding and may stop a few iterations apart -- at the same optimum)
         assert abs(res.fun - fa[n]) <= 1e-8 * abs(res.fun), (n, res.fun, fa[n], sa)

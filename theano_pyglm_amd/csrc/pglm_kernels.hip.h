@@ -5170,9 +5170,13 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
         PglLs s;
         pgl_ls_load(v, r, &s);
         const double stp = s.stp;
-        double f = ft[j];
-        if (!(f <= 1e16)) f = 1e16;                          // +inf like NaN (fit_glm maps NaN only; scipy's search stops on inf)
-        int rc = pgl_ls_step(&s, f, dp, PGL_LS_FTOL, PGL_LS_GTOL, PGL_LS_XTOL, PGL_LS_STPMIN, PGL_LS_STPMAX);
+        const double f = ft[j];
+        // an infinite objective or slope ends the search like scipy's ("WARN": its fallback search fails on inf as well);
+        // NaN never arrives here (fit_glm's rule: 1e16 and a zero gradient, applied by the objective)
+        int rc = PGL_LS_WARNING;
+        if (f - f == 0.0 && dp - dp == 0.0)
+            rc = pgl_ls_step(&s, f, dp, PGL_LS_FTOL, PGL_LS_GTOL, PGL_LS_XTOL, PGL_LS_STPMIN, PGL_LS_STPMAX);
+        else s.moved = 0.0;
         if (rc == PGL_LS_EVALUATE && s.nfev >= (double)max_trials) rc = PGL_LS_WARNING;
         int src = 0;                                         // 1: take the trial, 2: take the saved best step
         const int moved = s.moved != 0.0;
@@ -5216,8 +5220,7 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
     }
     sy = pgl_blk_sum(sy, red);
     if (tid == 0) {
-        double fn = src == 1 ? ft[j] : v.fb[r];
-        if (!(fn <= 1e16)) fn = 1e16;
+        const double fn = src == 1 ? ft[j] : v.fb[r];
         v.fprev[r] = v.f[r];
         v.f[r] = fn;
         v.acc[r] = 1.0;
