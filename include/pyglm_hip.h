@@ -288,6 +288,15 @@ int pgl_timing_summary(pgl_handle h, int reset, int* n_launches, double* mean_fu
  * counterpart (Theano's shared variables are synchronous). */
 int pgl_set_stream(pgl_handle h, void* stream);
 
+/* Dev / test: dry run of the kernel dispatch, no device needed -- the names (as in the code object) of the fused kernel
+ * instantiations an evaluation of `count` neurons from n_lo of a population of this shape would launch, one per line.
+ * stim: 0 none / dense stimulus columns, 1 separable by the tap-rate kernels, 2 separable at the frame rate (stimulus
+ * current inside the fused forward where that form exists), 3 at the frame rate through the slab.  path: 0 ll+grad,
+ * 1 ll only, 2 the forward launches of pgl_gibbs_prepare_all.  The reference has no counterpart (Theano picks its own
+ * C implementations); tests hold every reachable instantiation to zero bytes of scratch. */
+int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int n_lo, int count, int path, int opt_kernel,
+                     int opt_f32, char* out, int cap);
+
 /* Launch geometry and algorithmic work of the fused kernel for [n_lo,n_hi):
  * info[0]=blocks, [1]=threads/block, [2]=time chunks, [3]=k-tiles(16 rows),
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),

@@ -68,3 +68,32 @@ def test_profiler_detection_ignores_foreign_preloads(monkeypatch):
     monkeypatch.delenv('LD_PRELOAD')
     monkeypatch.setenv('ROCP_TOOL_LIBRARIES', '/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so')
     assert ge.under_profiler()
+
+
+def test_dispatched_kernels_exist_and_use_no_scratch():
+    """Every kernel instantiation the dispatcher can reach -- a dry run of make_plan and the launch switches over a grid
+    of population shapes, list lengths, stimulus forms, evaluation paths and forcing options (pgl_plan_kernels, no GPU
+    needed) -- is in the built library, nothing is built that no plan reaches, and no kernel of the library (fused or not)
+    uses scratch memory: private_segment_fixed_size = 0 and no spilled VGPRs in the code object's metadata."""
+    import sys
+    import __graft_entry__ as ge
+    ge.build_hip()
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import reachable_kernels as RK
+    built = RK.built_fused()
+    fused = dict((n, r) for n, r in built.items() if n.startswith(RK.FUSED))
+    reach = RK.reachable(auto_only=False)
+    auto = RK.reachable(auto_only=True)
+    assert len(auto) >= 60 and set(auto) <= set(reach)
+    missing = sorted(n for n in reach if n not in fused)
+    assert not missing, "reachable but not built: %s" % missing
+    dead = sorted(n for n in fused if n not in reach)
+    assert not dead, "built but not reachable by any plan: %s" % dead
+    spill = sorted((n, r['scratch'], r['spill_vgpr']) for n, r in built.items() if r['scratch'] > 0 or r['spill_vgpr'] > 0)
+    assert not spill, "kernels with scratch / spilled VGPRs: %s" % spill
+    # the named configurations dispatch to the kernels DESIGN.md names
+    from theano_pyglm_amd import _lib
+    assert _lib.plan_kernels(128, B=5, R=200, nT=600000) == ['k_fused5<18, 22, 1, 0>', 'k_fused5<18, 22, 2, 0>']
+    assert _lib.plan_kernels(32, B=5, R=200, nT=300000) == ['k_fused6<5, 2, 1, 4, 1>']
+    assert _lib.plan_kernels(64, B=3, R=300, Dstim=9, nT=300000) == ['k_fused7<13, 4, 0>']
+    assert _lib.plan_kernels(64, B=3, R=300, Dstim=3 + 1024, nT=300000, stim=2) == ['k_fused7<12, 4, 2>']

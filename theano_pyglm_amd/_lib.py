@@ -32,12 +32,24 @@ SYMBOLS = [
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
     'pgl_bfgs_state_doubles', 'pgl_bfgs_init_dev', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
-    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_update_dev',
+    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_update_dev', 'pgl_plan_kernels',
 ]
 
 
 class PglError(RuntimeError):
     pass
+
+
+def plan_kernels(N, B=5, R=200, Dstim=0, nT=300000, stim=0, n_lo=0, count=None, path=0, opt_kernel=0, opt_f32=0):
+    """Names of the fused kernel instantiations the dispatcher would launch for this shape (pgl_plan_kernels: a dry run,
+    works without a GPU); raises PglError where no plan exists."""
+    lib = load()
+    buf = C.create_string_buffer(4096)
+    rc = lib.pgl_plan_kernels(int(N), int(B), int(R), int(Dstim), int(nT), int(stim), int(n_lo), int(N - n_lo if count is None else count),
+                              int(path), int(opt_kernel), int(opt_f32), buf, 4096)
+    if rc != 0:
+        raise PglError(lib.pgl_last_error().decode())
+    return [ln for ln in buf.value.decode().splitlines() if ln]
 
 
 _lib = None
@@ -126,6 +138,9 @@ def load():
     lib.pgl_gibbs_currents.argtypes = [vp, C.c_int, vp]
     lib.pgl_last_timing.argtypes = [vp, dp, dp]
     lib.pgl_info.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    if hasattr(lib, 'pgl_plan_kernels'):
+        lib.pgl_plan_kernels.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.pgl_simulate.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, vp, vp, vp,
                                  C.c_int64, C.c_uint64, vp, vp]
     for name in SYMBOLS:

@@ -89,7 +89,7 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1, opt_slice_cols = 0;
     long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
@@ -166,7 +166,7 @@ struct Slice {
 static std::vector<Slice> make_slices(const pgl_context* h)
 {
     std::vector<Slice> out;
-    const int maxNs = std::min(128, 640 / h->B);
+    const int maxNs = std::min(128, (h->opt_slice_cols > 0 ? h->opt_slice_cols : 640) / h->B);
     int ds_left = h->sep ? 0 : h->Dstim, ds0 = 0;      // a separable stimulus is not a set of feature columns
     for (int np0 = 0; np0 < h->N; np0 += maxNs) {
         Slice sl{np0, std::min(maxNs, h->N - np0), 0, 0};
@@ -184,7 +184,7 @@ static std::vector<Slice> make_slices(const pgl_context* h)
 }
 
 static const int kKTW[] = {1, 2, 3, 5, 7, 10, 20};
-static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16, 20};     // k-tiles per half, two-pass kernel (on the fly)
+static const int kKTH[] = {1, 2, 3, 5, 7, 10, 13, 16};         // k-tiles per half, two-pass kernel (on the fly)
 // resident-tile kernel: (L, H) k-tile pairs; pass 1 (forward + L columns of G) gets the smaller share
 #ifndef PGL_SPLIT_L
 #define PGL_SPLIT_L 18       // L / H k-tiles of the 40-k-tile (K = 640) split; measured: 18/22 (see docs/NOTEBOOK.md §4.1)
@@ -224,10 +224,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         if (h->opt_kernel == 3) pl.version = 4;
         // two-pass kernel on resident tiles from 5 post tiles on; from 4 when the feature row is too long for
         // the resident K-split kernel (measured at K = 640: 64 neurons 2.05 ms against 2.33 ms of k_fused2)
-        // (force7 with a feature row too long for k_fused7 -- a short neuron list of a wide separable-stimulus population:
-        // the slab-input form of the two-pass kernel, whatever the number of post tiles)
+        // (force7 with a feature row too long for k_fused7 (> 16 k-tiles: its G no longer fits the registers beside the
+        // epilogue) -- e.g. a short neuron list of a wide separable-stimulus population: the slab-input form of the two-pass
+        // kernel, whatever the number of post tiles)
         else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT == 4 && need > 20))) ||
-                 (force7 && need > 20 && (h->opt_kernel == 0 || h->opt_kernel == 7)))
+                 (force7 && need > 16 && (h->opt_kernel == 0 || h->opt_kernel == 7)))
             pl.version = 5;
     }
     pl.tile0 = (int)(h->t_lo / 16);
@@ -239,6 +240,9 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         // fall back to on-the-fly generation (version 4) when the device cannot spare them
         if (!img_room(h, (size_t)pl.nTiles * img_pair_bytes(pl.ktl, pl.kth))) pl.version = 4;
     }
+    // the in-kernel-feature two-pass kernel carries at most 16 k-tiles per half in its registers (k_fused3<20, ..> spilled
+    // 22 VGPRs): rows of 33-40 k-tiles go to the K-split kernel, which is as fast there (2.20 against 2.16 ms at N = 128)
+    if (pl.version == 4 && (need + 1) / 2 > 16) pl.version = 2;
     pl.RP = h->Rk + 32;
     if (pl.version == 3) {
         while (pl.RP % 64 != 8) ++pl.RP;  // f32 table rows one 32-byte span apart (mod 256 B)
@@ -346,13 +350,17 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     }
     // version 7: no K split at all -- one wave per post tile carries the whole feature row (<= 20 k-tiles)
     // through forward, epilogue and backward; small workgroups, several per CU (k_fused7)
-    static const int kKT7[] = {1, 2, 3, 5, 7, 10, 12, 13, 16, 20};
+    static const int kKT7[] = {1, 2, 3, 5, 7, 10, 12, 13, 16};
     pl.nw7 = 0;
     pl.wg7 = 1;
     // (measured, tools/small_shape_scan.py / config_table.py: 3-4 post tiles 46 TFLOP/s against 39 of the
-    // K-split kernel at C5; with 1-2 post tiles only 2-6 waves fit a CU and the 4-wave K-split form wins)
-    if ((pl.version == 2 || pl.version == 6) && !pl.f32 && single_slice && pl.nPT <= 4 && need <= 20 &&
-        ((h->opt_kernel == 0 && pl.nPT >= 3) || h->opt_kernel == 7 || force7) && h->opt_ptw == 0) {
+    // K-split kernel at C5; with 1-2 post tiles only 2-6 waves fit a CU and the 4-wave K-split form wins -- except one
+    // post tile of 4-5 k-tiles (N = 16 at B = 5: 0.065 against 0.083 ms, tools/shape_sweep.py).  Rows of 17-20 k-tiles
+    // (N = 52..64 at B = 5) stay with the K-split kernel: 160 registers of G beside the epilogue spill (9-108 VGPRs
+    // by variant) and k_fused6 is the faster one there anyway, 0.49 against 0.57 ms at N = 64)
+    if ((pl.version == 2 || pl.version == 6) && !pl.f32 && single_slice && pl.nPT <= 4 && need <= 16 &&
+        ((h->opt_kernel == 0 && (pl.nPT >= 3 || (pl.nPT == 1 && need >= 4 && need <= 5))) || h->opt_kernel == 7 || force7) &&
+        h->opt_ptw == 0) {
         int kt7 = 0;
         for (int k : kKT7)
             if (k >= need) {
@@ -436,6 +444,27 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     return PGL_OK;
 }
 
+// Dry run of the dispatch (pgl_plan_kernels): when g_dry is set the launch_* templates record the name of the kernel
+// instantiation they would launch (as the code object's demangled symbol reads) and launch nothing.  The recorded set
+// over a grid of shapes is the set of instantiations the dispatcher can reach: tests/test_capi_symbols.py holds every
+// one of them to zero bytes of scratch, tools/reachable_kernels.py diffs it against the built library.
+static thread_local std::vector<std::string>* g_dry = nullptr;
+static bool dry_record(const char* fam, std::initializer_list<int> args, const char* tail = nullptr)
+{
+    if (!g_dry) return false;
+    std::string n = std::string(fam) + "<";
+    bool first = true;
+    for (int a : args) {
+        if (!first) n += ", ";
+        n += std::to_string(a);
+        first = false;
+    }
+    if (tail) n += std::string(", ") + tail;
+    n += ">";
+    g_dry->push_back(n);
+    return true;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs several microseconds of host time: it is issued once per
 // kernel instantiation and device (and again only for a larger size), not on every launch -- the small configurations
 // are bound by the host's submission rate (tools/step_bench.py)
@@ -458,6 +487,7 @@ static hipError_t ensure_dyn_lds(K kern, size_t bytes)
 template <int KTW, int PTW, int NW, int CAP, typename FT>
 static hipError_t launch_fused2_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (dry_record("k_fused2", {KTW, PTW, NW, CAP}, sizeof(FT) == 4 ? "float" : "double")) return hipSuccess;
     auto kern = k_fused2<KTW, PTW, NW, CAP, FT>;
     hipError_t e = ensure_dyn_lds(kern, pl.lds);
     if (e != hipSuccess) return e;
@@ -484,6 +514,11 @@ static hipError_t launch_fused2_k(const Plan& pl, const FusedParams& fp, hipStre
 template <int KTH>
 static hipError_t launch_fused3_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
+    if (g_dry) {
+        dry_record("k_fused3", {KTH, PGL_CAP, 1});
+        if (fp.want_grad) dry_record("k_fused3", {KTH, PGL_CAP, 2});
+        return hipSuccess;
+    }
     auto k1 = k_fused3<KTH, PGL_CAP, 1>;
     auto k2 = k_fused3<KTH, PGL_CAP, 2>;
     hipError_t e = ensure_dyn_lds(k1, pl.lds);
@@ -507,7 +542,6 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
     case 10: return launch_fused3_t<10>(pl, fp, s);
     case 13: return launch_fused3_t<13>(pl, fp, s);
     case 16: return launch_fused3_t<16>(pl, fp, s);
-    case 20: return launch_fused3_t<20>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -516,6 +550,11 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
 template <int KTL, int KTH, int XIN = 0>
 static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
+    if (g_dry) {
+        if (pass != 2) dry_record("k_fused5", {KTL, KTH, 1, XIN});
+        if (pass != 1 && fp.want_grad) dry_record("k_fused5", {KTL, KTH, 2, 0});
+        return hipSuccess;
+    }
     auto k1 = k_fused5<KTL, KTH, 1, XIN>;
     auto k2 = k_fused5<KTL, KTH, 2>;
     const size_t lds2 = (size_t)2 * pgl_img_bytes(KTH) + 256;
@@ -564,13 +603,29 @@ static hipError_t launch_fused5_xin(const Plan& pl, const FusedParams& fp, hipSt
     return hipErrorInvalidValue;
 }
 
+// Instantiations of the switch below that no plan of make_plan selects (tools/reachable_kernels.py: dry run of the
+// dispatch over a grid of shapes, with and without forcing options) are not built; tests/test_capi_symbols.py fails when a
+// reachable instantiation is missing from the library, so a change of make_plan shows up here.
+constexpr bool fused6_built(int KTW, int PTW, int MT, int NW)
+{
+    if (NW == 4) return MT == 1 && ((PTW == 1 && KTW <= 3) || (PTW == 2 && KTW <= 7));
+    if (MT == 2) return PTW == 4 && KTW >= 2 && KTW <= 7;
+    return (PTW == 1 && (KTW == 2 || KTW == 3)) || (PTW == 2 && (KTW == 5 || KTW == 7)) || (PTW == 4 && KTW == 10);
+}
+constexpr bool fused7_built(int KT, int NWV, int XIO)
+{
+    return !(XIO == 0 && ((KT == 1 && NWV >= 2) || (KT == 2 && NWV == 4)));
+}
+
 // occ != nullptr: no launch, *occ = workgroups of this instantiation a CU holds with pl.lds bytes of LDS
 template <int KTW, int PTW, int MT, int NW, int DB = 1>
 static hipError_t launch_fused6_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int* occ)
 {
     constexpr size_t need = (size_t)(DB ? 2 : 1) * MT * pgl_img_bytes(KTW * (NW / PTW)) + (size_t)MT * NW * 2048 + 256 + (size_t)NW * 384;
-    if constexpr (need <= 160 * 1024 && KTW * 4 <= 40) {
+    if constexpr (need <= 160 * 1024 && KTW * 4 <= 40 && (DB == 0 || fused6_built(KTW, PTW, MT, NW))) {
         auto kern = k_fused6<KTW, PTW, MT, NW, DB>;
+        if (!occ && dry_record("k_fused6", {KTW, PTW, MT, NW, DB})) return hipSuccess;
+        if (occ && g_dry) return hipErrorInvalidValue;           // (dry run: no device to ask; the caller's default holds)
         hipError_t e = ensure_dyn_lds(kern, pl.lds);
         if (e != hipSuccess) return e;
         if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kern, NW * 64, pl.lds);
@@ -656,11 +711,16 @@ static int gibbs_rate_wg_per_cu(size_t lds)
 template <int KT, int NWV, int XIO = 0>
 static hipError_t launch_fused7_t(const Plan& pl, const FusedParams& fp, hipStream_t s)
 {
-    auto kern = k_fused7<KT, NWV, XIO>;
-    hipError_t e = ensure_dyn_lds(kern, pl.lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NWV * 64), pl.lds, s, fp);
-    return hipGetLastError();
+    if constexpr (fused7_built(KT, NWV, XIO)) {
+        if (dry_record("k_fused7", {KT, NWV, XIO})) return hipSuccess;
+        auto kern = k_fused7<KT, NWV, XIO>;
+        hipError_t e = ensure_dyn_lds(kern, pl.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(NWV * 64), pl.lds, s, fp);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
 }
 
 template <int NWV>
@@ -676,7 +736,6 @@ static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStre
     case 12: return launch_fused7_t<12, NWV>(pl, fp, s);
     case 13: return launch_fused7_t<13, NWV>(pl, fp, s);
     case 16: return launch_fused7_t<16, NWV>(pl, fp, s);
-    case 20: return launch_fused7_t<20, NWV>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -695,8 +754,6 @@ static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipSt
         case 10: return launch_fused7_t<10, 4, 2>(pl, fp, s);
         case 12: return launch_fused7_t<12, 4, 2>(pl, fp, s);
         case 13: return launch_fused7_t<13, 4, 2>(pl, fp, s);
-        case 16: return launch_fused7_t<16, 4, 2>(pl, fp, s);
-        case 20: return launch_fused7_t<20, 4, 2>(pl, fp, s);
         }
         return hipErrorInvalidValue;
     }
@@ -710,7 +767,6 @@ static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipSt
     case 12: return launch_fused7_t<12, 4, 1>(pl, fp, s);
     case 13: return launch_fused7_t<13, 4, 1>(pl, fp, s);
     case 16: return launch_fused7_t<16, 4, 1>(pl, fp, s);
-    case 20: return launch_fused7_t<20, 4, 1>(pl, fp, s);
     }
     return hipErrorInvalidValue;
 }
@@ -865,6 +921,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
+    case 93: h->opt_slice_cols = value; return PGL_OK;      // dev: feature columns per slice of the 3-phase path (0 = 640)
     case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels
     case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer form of k_fused6
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
@@ -1532,6 +1589,33 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
     return PGL_OK;
 }
 
+// The path an evaluation of neurons [n_lo, n_hi) (or of a list of n_hi - n_lo neurons) takes and its launch plans:
+//   sepf   -- separable stimulus at the frame rate: impulse columns on resident tiles (k_fused7 with the slab-input form up to
+//             four post tiles, the two-pass kernel from five on or when the feature row is too long for k_fused7), the
+//             stimulus current / its gradients by k_sepf_*; neuron lists are fine there (the stimulus kernels work on the
+//             listed rows, the fused kernel maps rows to neurons).  A kernel forced by PGL_OPT_KERNEL other than 7 / 4 keeps
+//             the stimulus on the 3-phase path it asks for;
+//   sliced -- the 3-phase path (more than one slice of feature columns, or a separable stimulus by the tap-rate kernels).
+// One function for enqueue_ll_grad, pgl_info and the dry run of the dispatch (pgl_plan_kernels).
+static int select_plans(const pgl_context* h, int n_lo, int n_hi, const std::vector<Slice>& slices, std::vector<Plan>& plans,
+                        bool& sepf, bool& sliced)
+{
+    plans.assign(slices.size(), Plan());
+    sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
+           (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4);
+    if (sepf) {
+        int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
+        if (rc) return rc;
+        sepf = (plans[0].version == 7 && plans[0].nw7 == 4) || (plans[0].version == 5 && plans[0].ktl >= 5);
+    }
+    for (size_t i = 0; i < slices.size() && !sepf; ++i) {
+        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1 && !h->sep);
+        if (rc) return rc;
+    }
+    sliced = !sepf && (slices.size() > 1 || h->sep);     // else the separable stimulus rides on the 3-phase path
+    return PGL_OK;
+}
+
 // Enqueue one evaluation on the handle's stream.  All pointers are device pointers.
 //  * one slice (N <= 128 and N*B + Dstim <= 640): prep + fused kernel + finalize;
 //  * otherwise the 3-phase path: per slice a forward-only launch accumulating the currents in
@@ -1541,24 +1625,12 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
                            const double* d_Weff, double* d_ll, double* d_grad)
 {
     const std::vector<Slice> slices = make_slices(h);
-    std::vector<Plan> plans(slices.size());
-    // separable stimulus at the frame rate: impulse columns on resident tiles (k_fused7, slab-input form), the stimulus
-    // current / its gradients by k_sepf_*; needs a short feature row (<= 4 post tiles, <= 320 columns)
-    // (neuron lists are fine here: the stimulus kernels work on the listed rows, the fused kernel maps rows to neurons)
-    // (a kernel forced by PGL_OPT_KERNEL other than 7 / 4 keeps the stimulus on the 3-phase path it asks for)
-    bool sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
-                (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4);
-    if (sepf) {
-        int rc = make_plan(h, n_lo, n_hi, slices[0], plans[0], true, true);
-        if (rc) return rc;
-        // up to four post tiles: k_fused7 (slab in / residual out); five to eight: the two-pass kernel (slab in)
-        sepf = (plans[0].version == 7 && plans[0].nw7 == 4) || (plans[0].version == 5 && plans[0].ktl >= 5);
-    }
-    for (size_t i = 0; i < slices.size() && !sepf; ++i) {
-        int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], slices.size() == 1 && !h->sep);
+    std::vector<Plan> plans;
+    bool sepf = false, sliced = false;
+    {
+        int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced);
         if (rc) return rc;
     }
-    const bool sliced = !sepf && (slices.size() > 1 || h->sep);     // else the separable stimulus rides on the 3-phase path
     size_t maxG = 0, maxLL = 0;
     for (const Plan& pl : plans) {
         maxG = std::max(maxG, (size_t)pl.nChunks * pl.nPT * pl.KT * 256 * 8);
@@ -1589,7 +1661,8 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepfParams sp;
         // up to four post tiles with the (5, 3) table: the stimulus current rides in the forward contraction
-        const bool fused_fwd = pl.version == 7 && h->sepA_ok && h->opt_sepf != 3;
+        // (beyond 13 k-tiles the five extra k-steps do not fit the registers: k_fused7<16, 4, 2> spills -- slab form there)
+        const bool fused_fwd = pl.version == 7 && pl.KT <= 13 && h->sepA_ok && h->opt_sepf != 3;
         rc = sepf_forward(h, pl, d_theta, sp, fused_fwd);
         if (rc) return rc;
         FusedParams fp;
@@ -1927,23 +2000,84 @@ int pgl_set_stream(pgl_handle h, void* stream)
     return PGL_OK;
 }
 
+// Dry run of the dispatch, no device needed: the fused kernel instantiations (names as in the code object) that an
+// ll(+grad) evaluation of `count` neurons starting at n_lo -- a range, or a list -- of a population of this shape would
+// launch, one per line in `out`.  stim: 0 none / dense stimulus columns (Dstim of them), 1 separable stimulus by the
+// tap-rate kernels, 2 separable at the frame rate with the stimulus current inside the fused forward where that form
+// exists, 3 at the frame rate through the slab.  path: 0 ll+grad, 1 ll only, 2 the forward launches of pgl_gibbs_prepare_all.
+int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int n_lo, int count, int path, int opt_kernel,
+                     int opt_f32, char* out, int cap)
+{
+    if (!out || cap <= 0) return fail(PGL_ERR_ARG, "null argument");
+    if (N <= 0 || B <= 0 || B > PGL_MAXB || R <= 0 || nT <= 0 || Dstim < 0 || count <= 0 || n_lo < 0 || n_lo + count > N)
+        return fail(PGL_ERR_ARG, "bad shape");
+    pgl_context c;
+    c.N = N; c.B = B; c.R = R; c.Rk = R; c.nT = nT; c.Dstim = Dstim; c.Kimp = N * B;
+    c.nT16 = (int)((nT + 15) / 16); c.t_lo = 0; c.t_hi = nT; c.numCU = 256;
+    c.sep = stim >= 1; c.sepf = stim >= 2; c.sepA_ok = stim == 2; c.opt_sepf = 0;
+    c.Ktot = c.Kimp + (c.sep ? 0 : Dstim);
+    c.opt_kernel = opt_kernel; c.opt_f32 = opt_f32;
+    std::vector<std::string> names;
+    g_dry = &names;
+    int rc = PGL_OK;
+    hipError_t e = hipSuccess;
+    FusedParams fp{};
+    const std::vector<Slice> slices = make_slices(&c);
+    std::vector<Plan> plans;
+    if (path == 2) {
+        plans.assign(slices.size(), Plan());
+        for (size_t i = 0; i < slices.size() && rc == PGL_OK; ++i) {
+            rc = make_plan(&c, 0, N, slices[i], plans[i], false);
+            if (rc == PGL_OK) e = launch_any(plans[i], fp, nullptr);
+        }
+    } else {
+        const bool grad = path == 0;
+        fp.want_grad = grad;
+        bool sepf = false, sliced = false;
+        rc = select_plans(&c, n_lo, n_lo + count, slices, plans, sepf, sliced);
+        if (rc == PGL_OK) {
+            const Plan& pl = plans[0];
+            if (sepf) {
+                if (pl.version == 5) {
+                    e = launch_fused5_xin(pl, fp, nullptr, 1);
+                    if (e == hipSuccess && grad) e = launch_fused5_xin(pl, fp, nullptr, 2);
+                } else {
+                    e = launch_fused7_xio(pl, fp, nullptr, (pl.KT <= 13 && c.sepA_ok && c.opt_sepf != 3) ? 2 : 1);
+                }
+            } else if (!sliced) {
+                if (pl.version == 5 && grad) {
+                    e = launch_fused5(pl, fp, nullptr, 1);
+                    if (e == hipSuccess) e = launch_fused5(pl, fp, nullptr, 2);
+                } else {
+                    e = launch_any(pl, fp, nullptr);
+                }
+            } else {
+                for (size_t i = 0; i < slices.size() && e == hipSuccess; ++i) e = launch_any(plans[i], fp, nullptr);
+            }
+        }
+    }
+    g_dry = nullptr;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(PGL_ERR_UNSUPPORTED, "no kernel instantiation for this plan");
+    std::string all;
+    for (const std::string& n : names) all += n + "\n";
+    if ((int)all.size() + 1 > cap) return fail(PGL_ERR_ARG, "output buffer too small");
+    std::memcpy(out, all.c_str(), all.size() + 1);
+    return PGL_OK;
+}
+
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
 {
     if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
     const std::vector<Slice> slices = make_slices(h);
-    Plan pl;
     // the stimulus path an evaluation would take: 0 none / dense feature columns, 1 separable by the tap-rate kernels on
     // the 3-phase path, 2 separable at the frame rate (k_sepf_*, impulse columns on resident tiles)
-    int stim_path = h->sep ? 1 : 0;
-    int rc = PGL_OK;
-    if (h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
-        (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4)) {
-        rc = make_plan(h, n_lo, n_hi, slices[0], pl, true, true);
-        if (rc) return rc;
-        if ((pl.version == 7 && pl.nw7 == 4) || (pl.version == 5 && pl.ktl >= 5)) stim_path = 2;
-    }
-    if (stim_path != 2) rc = make_plan(h, n_lo, n_hi, slices[0], pl, slices.size() == 1 && !h->sep);
+    std::vector<Plan> plans;
+    bool sepf = false, sliced = false;
+    int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced);
     if (rc) return rc;
+    const int stim_path = sepf ? 2 : (h->sep ? 1 : 0);
+    const Plan& pl = plans[0];
     const double P = 1.0 + h->Dstim + h->Kimp;
     double v[13];
     v[12] = stim_path;

@@ -71,7 +71,8 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
                              // CU: 3 000 of 11 600 cycles per tile and wave at C2) -- behind an MFMA that wait is free
 #endif
 #ifndef PGL_WREG_MAX
-#define PGL_WREG_MAX 40      // k_fused7: up to this many k-steps the wave's Wmat fragments stay in registers for the whole chunk
+#define PGL_WREG_MAX 28      // k_fused7: up to this many k-steps the wave's Wmat fragments stay in registers for the whole chunk
+                             // (40 = ten k-tiles: 80 registers of fragments beside 80 of G and the epilogue spilled 4-74 VGPRs)
 #endif
 #ifndef PGL_LDS1
 #define PGL_LDS1 1           // A-fragment reads of the resident-tile kernels as single ds_read_b64 (volatile: the compiler's
@@ -889,6 +890,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
         const int t0 = tile * TT;
         const int cur = (tile & 1) * N;
         const int nxt = ((tile + 1) & 1) * N;
+        // the staging code below indexes by thread id; with G taking 160 of the 256 registers at KTW = 20 the compiler's
+        // hoisting of its thread-id arithmetic out of the tile loop (quotients by Dstim, ring addresses) ended in
+        // scratch: behind this opaque copy it is recomputed per tile instead (a few integer instructions)
+        int tid = threadIdx.x;
+        if (KTW >= 20) asm volatile("" : "+v"(tid));
         // ---- prefetch (registers): the events that ENTER neuron tid's window with tile+1 (the
         // window slides by 16 bins: ~0.3 new events per neuron), windows of tile+2 ----
         int2 pf[NPF];
@@ -960,8 +966,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
             pgl_d2 wr[PW2];
             double ar[PA];
+            int lanew = lane;
+            if (KTW >= 20) asm volatile("" : "+v"(lanew));        // (its 64-bit byte offset is not kept across the tile loop)
 #pragma unroll
-            for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lane];
+            for (int s = 0; s < PW2; ++s) wr[s] = wr2[s * 64 + lanew];
 #pragma unroll
             for (int s = 0; s < PA; ++s) ar[s] = (double)fa[4 * s];
 #pragma unroll
@@ -969,7 +977,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
                 const double a = ar[s % PA];
                 const double b = (s & 1) ? wr[(s / 2) % PW2].y : wr[(s / 2) % PW2].x;
                 if (s + PA < KSW) ar[s % PA] = (double)fa[4 * (s + PA)];
-                if ((s & 1) && (s / 2 + PW2 < KSW / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lane];
+                if ((s & 1) && (s / 2 + PW2 < KSW / 2)) wr[(s / 2) % PW2] = wr2[(s / 2 + PW2) * 64 + lanew];
                 if (s & 1)
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
                 else
@@ -1028,6 +1036,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
             for (int e = 0; e < EPW; ++e) {
                 const int r = er[e];
                 double x = bias_l;
+                if (KTW >= 20) {                          // no register for it across the tile loop: read again (L1)
+                    int nl = nloc;
+                    asm volatile("" : "+v"(nl));
+                    x = valid_n ? p.bias[nl] : 0.0;
+                }
 #pragma unroll
                 for (int k2 = 0; k2 < KSPLIT; ++k2)
                     x += Xp[(size_t)(ptl + PTW * k2) * 256 + r * 64 + lane];
@@ -3750,6 +3763,16 @@ __global__ __launch_bounds__(256) void k_gibbs_pre_features(const GibbsColsParam
         if (b < p.B) fs[(size_t)b * p.fs_stride + (t - p.t_lo)] = acc[b];
 }
 
+// softplus(x) - max(x, 0) with the reference's NaN semantics, all-f64: the path of a wave that holds an element near the
+// under / overflow of lam.  lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700 (incl. +inf): lam = x,
+// nothing beyond the max term.  Not inlined: it runs for a handful of waves per launch and would otherwise cost the
+// rate loop registers at its 128-VGPR operating point.
+__device__ __noinline__ double pgl_gibbs_careful_tail(const double xq)
+{
+    const double lam = pgl_lambda_only(xq, 1, PGL_C);
+    return (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
+}
+
 // (four waves per SIMD = four workgroups per CU is the operating point: the register allocator is held to 128 VGPRs)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gibbs_rate_cols(const GibbsColsParams p)
 {
@@ -3960,12 +3983,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         d = pgl_softplus_tail_tab(fabs(xq), TB, (pgl_k_cdp)PGL_SPC);
 #endif
                     } else {
-                        const double* cg = PGL_C;
-                        asm volatile("" : "+s"(cg));       // rare path: its scalar loads stay in here
-                        const double lam = pgl_lambda_only(xq, 1, cg);
-                        // reference semantics: lam == 0 makes log(lam)*S NaN even for S = 0 (glm.py:52); x >= 700
-                        // (incl. +inf): lam = x, nothing beyond the max term
-                        d = (xq >= 700.0) ? 0.0 : ((lam == 0.0) ? __builtin_nan("") : lam - __builtin_fmax(xq, 0.0));
+                        d = pgl_gibbs_careful_tail(xq);    // rare path, out of line: its registers are not the loop's
                     }
                     accq += v ? d : 0.0;
                 }

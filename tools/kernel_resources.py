@@ -23,7 +23,8 @@ def extract_code_object(lib, outdir):
 def kernel_resources(lib):
     """{demangled kernel name: {'scratch': bytes, 'vgpr': n, 'agpr': n, 'sgpr': n, 'lds': bytes, 'spill_vgpr': n}}"""
     with tempfile.TemporaryDirectory() as d:
-        co = extract_code_object(lib, d)
+        # a bare device ELF (hipcc -save-temps: *-gfx950.out) is read as it is
+        co = lib if lib.endswith(('.out', '.co', '.hsaco')) else extract_code_object(lib, d)
         notes = subprocess.check_output([os.path.join(LLVM, 'llvm-readelf'), '--notes', co]).decode()
     out = {}
     cur = {}

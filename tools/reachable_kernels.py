@@ -1,0 +1,69 @@
+"""The set of fused kernel instantiations the dispatcher can reach, from a dry run of make_plan / the launch switches over
+a grid of shapes (pgl_plan_kernels: no GPU needed), against the instantiations in the built library:
+
+    python tools/reachable_kernels.py            # summary + instantiations no plan reaches + reachable ones with scratch
+
+`reachable(auto_only)` is what tests/test_capi_symbols.py uses: every instantiation reachable WITHOUT a forcing option
+must exist in the library and use no scratch."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from theano_pyglm_amd import _lib
+
+FUSED = ('k_fused2<', 'k_fused3<', 'k_fused5<', 'k_fused6<', 'k_fused7<', 'k_fused<')
+
+
+def shapes():
+    Ns = list(range(1, 137)) + list(range(144, 521, 8))
+    for N in Ns:
+        counts = sorted(set(c for c in (N, 1, 15, 16, 17, 32, 33, 48, 49, 64, 65, 80, 100, 128) if c <= N))
+        for B in range(1, 9):
+            for nT in (64, 600000):
+                for stim, Ds in ((0, 0), (0, 9), (0, 200), (1, 3 + 24), (2, 3 + 24), (3, 3 + 24), (2, 4 + 1024)):
+                    for count in counts:
+                        yield N, B, nT, stim, Ds, count
+
+
+def reachable(auto_only=True):
+    """{kernel name: example shape}"""
+    out = {}
+    opts = (0,) if auto_only else (0, 2, 3, 4, 6, 7)
+    for N, B, nT, stim, Ds, count in shapes():
+        for ok in opts:
+            for f32 in ((0, 1) if stim == 0 else (0,)):
+                for path in (0, 1, 2):
+                    if path == 2 and count != N:
+                        continue
+                    try:
+                        names = _lib.plan_kernels(N, B=B, R=200, Dstim=Ds, nT=nT, stim=stim, count=count, path=path,
+                                                  opt_kernel=ok, opt_f32=f32)
+                    except _lib.PglError:
+                        continue                     # no plan for this shape (the evaluation raises the same error)
+                    for n in names:
+                        out.setdefault(n, (N, B, nT, stim, Ds, count, path, ok, f32))
+    return out
+
+
+def built_fused():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kernel_resources as KR
+    res = KR.kernel_resources(_lib.LIB_PATH)
+    return dict((KR.short(n), r) for n, r in res.items())
+
+
+if __name__ == '__main__':
+    auto = reachable(True)
+    forced = reachable(False)
+    built = built_fused()
+    bf = dict((n, r) for n, r in built.items() if n.startswith(FUSED))
+    print("fused instantiations built: %d; reachable by the automatic dispatch: %d; reachable with a forcing option: %d"
+          % (len(bf), len(auto), len(forced)))
+    miss = sorted(n for n in forced if n not in bf)
+    print("reachable but NOT built (%d): %s" % (len(miss), miss))
+    dead = sorted(n for n in bf if n not in forced)
+    print("built but not reachable (%d):" % len(dead))
+    for n in dead:
+        print("   ", n)
+    bad = sorted(n for n in auto if n in bf and bf[n]['scratch'] > 0)
+    print("automatically dispatched with scratch (%d): %s" % (len(bad), [(n, bf[n]['scratch'], auto[n]) for n in bad]))
+    bad2 = sorted(n for n in forced if n in bf and bf[n]['scratch'] > 0 and n not in auto)
+    print("reachable only with a forcing option, with scratch (%d): %s" % (len(bad2), [(n, bf[n]['scratch'], forced[n]) for n in bad2]))
