@@ -82,8 +82,7 @@ def test_dispatched_kernels_exist_and_use_no_scratch():
     import reachable_kernels as RK
     built = RK.built_fused()
     fused = dict((n, r) for n, r in built.items() if n.startswith(RK.FUSED))
-    reach = RK.reachable(auto_only=False)
-    auto = RK.reachable(auto_only=True)
+    auto, reach = RK.reachable_both()
     assert len(auto) >= 60 and set(auto) <= set(reach)
     missing = sorted(n for n in reach if n not in fused)
     assert not missing, "reachable but not built: %s" % missing

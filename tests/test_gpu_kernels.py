@@ -407,7 +407,10 @@ def test_two_pass_kernel_shapes_and_agreement():
               H.Problem(128, 700, H.std_ibasis(), seed=83, Dstim=0, w_scale=0.5)):
         ll, g = _check(p)                                  # default: resident feature tiles (k_fused5)
         assert p.device().info()['kernel_version'] == 5
-        for kern, ver in ((2, 2), (3, 4), (4, 5)):         # K-split, two-pass on the fly, two-pass resident
+        # K-split, two-pass on the fly (rows of more than 32 k-tiles -- N = 128 -- go to the K-split kernel: k_fused3 holds
+        # at most 16 k-tiles per half in its registers), two-pass resident
+        need = -(-(p.N * p.B + p.Dstim) // 16)
+        for kern, ver in ((2, 2), (3, 4 if need <= 32 else 2), (4, 5)):
             dk = p.device()
             dk.set_option(_lib.OPT_KERNEL, kern)
             assert dk.info()['kernel_version'] == ver

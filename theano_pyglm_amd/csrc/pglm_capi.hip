@@ -78,7 +78,7 @@ struct pgl_context {
     int sepq = 0, sepM = 0, sepJ = 0, sepBTp = 0;
     int sepNH = 0, sepGs = 0;            // A-fragment table of the fused forward (k_fused7<.., 2>): head tiles, log2 gcd(q, 16)
     bool sepA_ok = false;
-    DevBuf sepC, sepA, YfT, Hb, wpart, QvT;
+    DevBuf sepC, sepA, sepAT, sepD, YfT, Hb, wpart, QvT;
     int opt_sepf = 0;                    // dev option 94: 2 = never take the frame-rate path, 3 = stimulus current through the slab (k_sepf_fwd)
     const int* cur_pidx = nullptr;       // post-neuron list of the evaluation being enqueued (device)
     int gibbs_npost = -1;
@@ -152,6 +152,7 @@ struct Plan {
     int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
     int sb6 = 0;                        // version 6: one image buffer per workgroup (k_fused6 DB = 0)
     int nw7, wg7;                       // version 7: waves per workgroup (1, 2, 4), workgroups per CU
+    size_t lds7x = 0;                   // version 7: extra LDS of the separable-stimulus forms
     size_t lds;
     bool f32;
 };
@@ -368,7 +369,8 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
                 break;
             }
         const int nw7 = (pl.nPT >= 3 || force7) ? 4 : pl.nPT;       // force7: the slab-input form exists for 4 waves only
-        const size_t lds7 = (size_t)2 * pgl_img_bytes(kt7) + 256 + (size_t)nw7 * 192 * 8;
+        // (force7 = separable stimulus: + the per-wave accumulators of the fused stimulus backward, k_fused7<.., 3>)
+        const size_t lds7 = (size_t)2 * pgl_img_bytes(kt7) + 256 + (size_t)nw7 * 192 * 8 + (force7 ? (size_t)nw7 * 320 * 8 : 0);
         bool ok = kt7 > 0 && lds7 <= 160 * 1024;
         if (ok && h->opt_kernel == 0 && find_img(h, kt7 << 8, pl.tile0, pl.nTiles) < 0)
             ok = img_room(h, (size_t)pl.nTiles * pgl_img_bytes(kt7));
@@ -379,6 +381,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             pl.PTW = nw7; pl.KSPLIT = 1; pl.KTW = kt7; pl.KT = kt7; pl.wpb = nw7;
             pl.nPB = (pl.nPT + nw7 - 1) / nw7;
             pl.mt = 0;
+            pl.lds7x = force7 ? (size_t)nw7 * 320 * 8 : 0;
         }
     }
     pl.KS = pl.KT * 4;
@@ -410,7 +413,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         return PGL_OK;
     }
     if (pl.version == 7) {
-        pl.lds = (size_t)2 * pgl_img_bytes(pl.KT) + 256 + (size_t)pl.nw7 * 192 * 8;
+        pl.lds = (size_t)2 * pgl_img_bytes(pl.KT) + 256 + (size_t)pl.nw7 * 192 * 8 + pl.lds7x;
         return PGL_OK;
     }
     if (pl.version == 6) {
@@ -610,7 +613,8 @@ constexpr bool fused6_built(int KTW, int PTW, int MT, int NW)
 {
     if (NW == 4) return MT == 1 && ((PTW == 1 && KTW <= 3) || (PTW == 2 && KTW <= 7));
     if (MT == 2) return PTW == 4 && KTW >= 2 && KTW <= 7;
-    return (PTW == 1 && (KTW == 2 || KTW == 3)) || (PTW == 2 && (KTW == 5 || KTW == 7)) || (PTW == 4 && KTW == 10);
+    // (four post tiles, one tile per step: the long-row form, and every row length on recordings of fewer than four tiles)
+    return (PTW == 1 && (KTW == 2 || KTW == 3)) || (PTW == 2 && (KTW == 5 || KTW == 7)) || (PTW == 4 && KTW >= 2);
 }
 constexpr bool fused7_built(int KT, int NWV, int XIO)
 {
@@ -744,6 +748,18 @@ static hipError_t launch_fused7_k(const Plan& pl, const FusedParams& fp, hipStre
 static hipError_t launch_fused7_xio(const Plan& pl, const FusedParams& fp, hipStream_t s, int xio = 1)
 {
     if (pl.nw7 != 4) return hipErrorInvalidValue;
+    if (xio == 3) {                              // ... and its backward inside the kernel as well (no residual slab)
+        switch (pl.KT) {
+        case 1: return launch_fused7_t<1, 4, 3>(pl, fp, s);
+        case 2: return launch_fused7_t<2, 4, 3>(pl, fp, s);
+        case 3: return launch_fused7_t<3, 4, 3>(pl, fp, s);
+        case 5: return launch_fused7_t<5, 4, 3>(pl, fp, s);
+        case 7: return launch_fused7_t<7, 4, 3>(pl, fp, s);
+        case 10: return launch_fused7_t<10, 4, 3>(pl, fp, s);
+        case 12: return launch_fused7_t<12, 4, 3>(pl, fp, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (xio == 2) {                              // stimulus current inside the forward contraction
         switch (pl.KT) {
         case 1: return launch_fused7_t<1, 4, 2>(pl, fp, s);
@@ -888,7 +904,7 @@ int pgl_destroy(pgl_handle h)
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
-                      &h->spart, &h->sepC, &h->sepA, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
+                      &h->spart, &h->sepC, &h->sepA, &h->sepAT, &h->sepD, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
@@ -1206,8 +1222,20 @@ static int build_frame_table(pgl_handle h, const double* basis_t, int Rt, int Bt
                     }
             }
         }
+        // ... and the A^T fragments of the fused backward (k_fused7<.., 3>): D[(j', bt)][n] += sum_i A[i][(j', bt)] r[i][n] as
+        // eight MFMAs (two accumulator tiles of 16 columns x four k-steps of four bins); lane l of fragment 4 mt + ks holds
+        // column 16 mt + (l & 15) of bin 4 ks + (l >> 4)
+        std::vector<double> AT((size_t)(NH + NP) * 8 * 64, 0.0);
+        for (long long e = 0; e < NH + NP; ++e)
+            for (int k = 0; k < 18; ++k)
+                for (int i = 0; i < 16; ++i) {
+                    const double v = A[((size_t)e * 5 + k / 4) * 64 + (k % 4) * 16 + i];
+                    AT[((size_t)e * 8 + (k / 16) * 4 + i / 4) * 64 + (i % 4) * 16 + (k % 16)] = v;
+                }
         ENSURE(h->sepA, A.size() * 8);
         HIPCHK(hipMemcpyAsync(h->sepA.p, A.data(), A.size() * 8, hipMemcpyHostToDevice, h->stream));
+        ENSURE(h->sepAT, AT.size() * 8);
+        HIPCHK(hipMemcpyAsync(h->sepAT.p, AT.data(), AT.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->sepNH = (int)NH; h->sepGs = gs;
         h->sepA_ok = true;
@@ -1359,6 +1387,7 @@ static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, Sep
     if (rc) return rc;
     sp.Ctab = (const double*)h->sepC.p; sp.YfT = (const double*)h->YfT.p; sp.theta = d_theta;
     sp.X = (double*)h->Xbuf.p; sp.Hb = nullptr; sp.wpart = nullptr; sp.QvT = nullptr; sp.grad = nullptr;
+    sp.D = nullptr; sp.B0 = sp.B1 = 0; sp.SL = 0; sp.tilesPerChunk = 0;
     sp.P = P; sp.Bt = h->sepBt; sp.M = h->sepM; sp.q = h->sepq; sp.npost = pl.npost; sp.nPT = pl.nPT; sp.ldy = ldy;
     sp.tile0 = pl.tile0; sp.nTiles = pl.nTiles; sp.Tstim = h->sepT;
     const long long tb = (long long)pl.tile0 * 16, te = tb + (long long)pl.nTiles * 16;
@@ -1367,16 +1396,28 @@ static int sepf_forward(pgl_handle h, const Plan& pl, const double* d_theta, Sep
     return launch_sepf_any(h, 0, sp);
 }
 
-// backward: the slab holds r = d ll / d x; writes the w_t and w_x columns of d_grad
-static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad)
+// backward: the slab holds r = d ll / d x (fused_bwd: the fused kernel left the per-base pieces sp.D instead); writes the
+// w_x columns of d_grad and the w_t columns -- fused_bwd: their block partials sp.wpart, nwt of them, which the trailing
+// blocks of k_finalize sum
+static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad, bool fused_bwd = false, int* nwt = nullptr)
 {
     const long long nF = sp.F1 - sp.F0 + 1;
-    ENSURE(h->Hb, (size_t)nF * h->sepJ * sp.ldy * 8);
-    ENSURE(h->wpart, (size_t)nF * h->sepBTp * sp.ldy * 8);
     ENSURE(h->QvT, (size_t)h->sepT * sp.ldy * 8);
-    sp.Hb = (double*)h->Hb.p; sp.wpart = (double*)h->wpart.p; sp.QvT = (double*)h->QvT.p; sp.grad = d_grad;
-    int rc = launch_sepf_any(h, 1, sp);
-    if (!rc) rc = launch_sepf_any(h, 2, sp);
+    int rc = PGL_OK;
+    if (fused_bwd) {
+        const int nblk = (int)((h->sepT + 15) / 16);
+        ENSURE(h->wpart, (size_t)nblk * 3 * sp.ldy * 8);
+        sp.wpart = (double*)h->wpart.p; sp.QvT = (double*)h->QvT.p; sp.grad = d_grad;
+        hipLaunchKernelGGL(k_sepf_finish_d, dim3((unsigned)nblk), dim3(1024), 0, h->stream, sp);
+        HIPCHK(hipGetLastError());
+        if (nwt) *nwt = nblk;
+    } else {
+        ENSURE(h->Hb, (size_t)nF * h->sepJ * sp.ldy * 8);
+        ENSURE(h->wpart, (size_t)nF * h->sepBTp * sp.ldy * 8);
+        sp.Hb = (double*)h->Hb.p; sp.wpart = (double*)h->wpart.p; sp.QvT = (double*)h->QvT.p; sp.grad = d_grad;
+        rc = launch_sepf_any(h, 1, sp);
+        if (!rc) rc = launch_sepf_any(h, 2, sp);
+    }
     if (rc) return rc;
     // d ll / d w_x[n][x] = sum_f (stim . basis_x)[f][x] QvT[f][n]
     if (gemm_aligned(h->zfT.p, h->sepT)) {                             // m = x (rows of zfT: f contiguous), n = n, k = f
@@ -1478,6 +1519,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.mode = mode; fp.Xbuf = (double*)h->Xbuf.p; fp.xstride = pl.nPT * 16;
     fp.sepA = nullptr; fp.sepZ = nullptr; fp.sepTheta = nullptr; fp.sepT = 0;
     fp.sepLdy = fp.sepQ = fp.sepM = fp.sepNH = fp.sepG = fp.sepBt = 0;
+    fp.sepAT = nullptr; fp.sepD = nullptr; fp.sepB0 = 0; fp.sepSL = 0;
     fp.spk = (const int2*)h->spk.p; fp.wlo = (const int*)h->wlo.p; fp.whi = (const int*)h->whi.p;
     fp.S = (const uint8_t*)h->S.p; fp.fstim = (const double*)h->fstim.p; fp.phi = (const double*)h->phi.p;
     fp.Wfrag = (const double*)h->Wfrag.p; fp.bias = (const double*)h->bias.p;
@@ -1520,7 +1562,8 @@ static int launch_prep(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo, 
 
 static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
                                 const double* d_Weff, double* d_ll, double* d_grad, bool with_ll = false,
-                                int kt0 = 0, int nkt = -1, hipStream_t stream = nullptr)
+                                int kt0 = 0, int nkt = -1, hipStream_t stream = nullptr,
+                                const double* wtpart = nullptr, int nwt = 0, int ldy = 0)
 {
     if (nkt < 0) nkt = pl.KT;
     if (!stream) stream = h->stream;
@@ -1533,11 +1576,12 @@ static int launch_finalize_grad(pgl_handle h, const Plan& pl, const Slice& sl, i
     if (with_ll) nwf = std::max(nwf, 4);                  // the ll blocks reduce with 256 threads (pgl_reduce_ll)
     int blocks = (int)((nfrag + 63) / 64);
     if (with_ll) blocks += pl.npost;                      // trailing blocks (one per neuron) reduce ll and d ll / d bias
+    if (with_ll && wtpart) blocks += h->sepBt;            // ... and the w_t partials of the fused stimulus backward
     hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(64 * nwf), 0, stream, (const double*)h->Gpart.p,
                        (const double*)h->llpart.p, (const double*)h->gbpart.p, d_Weff, d_ll, d_grad,
                        sl.Ns, h->B, sl.Ds, sl.Ns * h->B, sl.Ns * h->B + sl.Ds, pl.KT, n_lo, pl.npost,
                        pl.nPT, pl.nChunks, h->N, sl.np0, h->Dstim, sl.ds0, with_ll ? pl.KSPLIT : 0, kt0,
-                       nkt, h->cur_pidx);
+                       nkt, h->cur_pidx, wtpart, nwt, ldy, h->sepBt);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -1663,8 +1707,23 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         // up to four post tiles with the (5, 3) table: the stimulus current rides in the forward contraction
         // (beyond 13 k-tiles the five extra k-steps do not fit the registers: k_fused7<16, 4, 2> spills -- slab form there)
         const bool fused_fwd = pl.version == 7 && pl.KT <= 13 && h->sepA_ok && h->opt_sepf != 3;
+        // ... and its backward too (k_fused7<.., 3>: no residual slab, no k_sepf_bwd) up to 12 k-tiles (registers);
+        // dev option 94 = 4 keeps the slab form
+        const bool fused_bwd = fused_fwd && d_grad && pl.KT <= 12 && h->opt_sepf != 4;
         rc = sepf_forward(h, pl, d_theta, sp, fused_fwd);
         if (rc) return rc;
+        if (fused_bwd) {
+            // pieces of the stimulus backward: one per frame base and chunk that holds tiles of it
+            const long long q = h->sepq, M = h->sepM;
+            const long long tE = (long long)pl.tile0 + pl.nTiles - 1;
+            sp.B0 = std::max<long long>(((long long)pl.tile0 * 16) / q - M, 0);
+            sp.B1 = std::max<long long>((tE * 16) / q - M, 0);
+            const long long span = ((M + 1) * q + 15) / 16 + 1;               // tiles of base 0, the longest
+            sp.SL = (int)(span / pl.tilesPerChunk) + 2;
+            sp.tilesPerChunk = pl.tilesPerChunk;
+            ENSURE(h->sepD, (size_t)(sp.B1 - sp.B0 + 1) * sp.SL * pl.nPT * 320 * 8);
+            sp.D = (const double*)h->sepD.p;
+        }
         FusedParams fp;
         fill_params(h, pl, slices[0], n_lo, d_grad != nullptr, 0, fp);
         if (direct) {
@@ -1676,19 +1735,24 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             fp.sepLdy = sp.ldy; fp.sepQ = h->sepq; fp.sepM = h->sepM; fp.sepNH = h->sepNH; fp.sepG = h->sepGs;
             fp.sepBt = h->sepBt;
         }
+        if (fused_bwd) {
+            fp.sepAT = (const double*)h->sepAT.p; fp.sepD = (double*)h->sepD.p; fp.sepB0 = sp.B0; fp.sepSL = sp.SL;
+        }
         hipError_t e = hipSuccess;
         if (pl.version == 5) {                   // pass 1 (slab in, residuals out) and, for the gradient, pass 2
             e = launch_fused5_xin(pl, fp, h->stream, 1);
             if (e == hipSuccess && d_grad) e = launch_fused5_xin(pl, fp, h->stream, 2);
         } else {
-            e = launch_fused7_xio(pl, fp, h->stream, fused_fwd ? 2 : 1);
+            e = launch_fused7_xio(pl, fp, h->stream, fused_bwd ? 3 : (fused_fwd ? 2 : 1));
         }
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
         if (d_grad) {
-            rc = sepf_backward(h, sp, d_grad);
+            int nwt = 0;
+            rc = sepf_backward(h, sp, d_grad, fused_bwd, &nwt);
             if (rc) return rc;
             if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true);
+            rc = launch_finalize_grad(h, pl, slices[0], n_lo, d_Weff, d_ll, d_grad, true, 0, -1, nullptr,
+                                      fused_bwd ? (const double*)h->wpart.p : nullptr, nwt, sp.ldy);
             if (rc) return rc;
         } else {
             if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
@@ -2042,7 +2106,10 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
                     e = launch_fused5_xin(pl, fp, nullptr, 1);
                     if (e == hipSuccess && grad) e = launch_fused5_xin(pl, fp, nullptr, 2);
                 } else {
-                    e = launch_fused7_xio(pl, fp, nullptr, (pl.KT <= 13 && c.sepA_ok && c.opt_sepf != 3) ? 2 : 1);
+                    {
+                        const bool ff = pl.KT <= 13 && c.sepA_ok && c.opt_sepf != 3;
+                        e = launch_fused7_xio(pl, fp, nullptr, (ff && grad && pl.KT <= 12) ? 3 : (ff ? 2 : 1));
+                    }
                 }
             } else if (!sliced) {
                 if (pl.version == 5 && grad) {

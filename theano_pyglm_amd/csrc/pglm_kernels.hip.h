@@ -151,7 +151,24 @@ struct FusedParams {
     long long sepT;                      // stimulus frames
     int sepLdy, sepQ, sepM, sepNH, sepG; // NH head tiles with their own A fragments, gcd(q, 16) = 1 << sepG
     int sepBt;                           // temporal bases in use (<= 3)
+    // ... and its backward in the same kernel (want_grad): D[(j', bt)][n] += sum_i A[i][(j', bt)] r[i][n] as eight more
+    // MFMAs per tile (A^T fragments by tile phase: sepAT), accumulated in registers over the tiles that share a frame
+    // base and written out when the base changes -- sepD[base - sepB0][slot][post tile][5][64] (registers 0..3 = columns
+    // 0..15 in the accumulator layout, 4 = columns 16, 17 in lane groups 0, 1), slot = chunk - (chunk of the base's first
+    // tile).  No residual slab, no k_sepf_bwd pass over it; k_sepf_finish_d folds the pieces.  Null: slab form.
+    const double* __restrict__ sepAT;    // [phases as sepA][8][64]
+    double* __restrict__ sepD;
+    long long sepB0;                     // frame base of the evaluated range's first tile
+    int sepSL;                           // slots per base
 };
+
+// geometry shared by k_fused7 (writer) and k_sepf_finish_d (reader): the first tile whose frame base is b, for the
+// evaluated tiles [tile0, ...), and the chunk that holds it
+__device__ __forceinline__ long long pgl_sepd_first_tile(const long long b, const int M, const int q, const long long tile0)
+{
+    const long long t = (b <= 0) ? 0 : ((b + M) * (long long)q + 15) / 16;
+    return t > tile0 ? t : tile0;
+}
 
 // The Wmat B fragments (k-steps ks0 .. ks0 + NS - 1, lane group grp) of local post neuron nloc, as k_prep_w would
 // write them:  Wmat[k][n] = theta_n[1 + Dstim + k] * Weff[k / B][n]  (impulse columns),  theta_n[1 + k - Kimp]
@@ -2463,7 +2480,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
 
     unsigned char* bufs = smem;                                           // [2][IMG]
     double* Cs = reinterpret_cast<double*>(smem + (size_t)2 * IMG);       // [32] math constants
-    double* const wscratch = Cs + 32 + wave * 192;                        // spike compaction scratch
+    double* const wscratch_base = Cs + 32;
+    double* const wscratch = wscratch_base + wave * 192;                  // spike compaction scratch
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
     d4_t G[KT];
@@ -2506,16 +2524,21 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     double* const xslab = XIO ? p.Xbuf + (size_t)(active ? pt : 0) * 256 + lane : nullptr;
     const size_t xstride = (size_t)p.nPT * 256;
     // XIO = 2: the lane's five B entries are (j', bt) = divmod(4 s + grp, 3) of its neuron
-    constexpr int SF = (XIO == 2) ? 5 : 1;
-    double sfa[SF], sfz[SF], sfw[SF];
-    int sfj[SF], sepF = 0, sepO = 0;
-    if constexpr (XIO == 2) {
+    constexpr int SF = (XIO >= 2) ? 5 : 1;
+    double sfa[SF], sfz[SF];
+    int sepF = 0, sepO = 0, sepPh = 0;
+    long long sepBase = 0;
+    constexpr bool SBWC = (XIO == 3);                                   // stimulus backward inside this kernel
+    const bool SBW = SBWC && p.want_grad;
+    // its accumulators (five values per lane) live in LDS between the tiles: in registers they would be alive across
+    // the rate epilogue, where this kernel has none to spare (22-30 VGPRs spilled at 12-13 k-tiles)
+    double* const Dl = wscratch_base + NWV * 192 + wave * 320 + lane;
+    if constexpr (XIO >= 2) {
 #pragma unroll
-        for (int s = 0; s < SF; ++s) {
-            const int k = 4 * s + grp;
-            sfj[s] = k / 3;
-            sfw[s] = (valid_n && k < 18 && k - 3 * (k / 3) < p.sepBt) ? p.sepTheta[(size_t)nloc * p.P + 1 + (k - 3 * (k / 3))] : 0.0;
-            sfa[s] = sfz[s] = 0.0;
+        for (int s = 0; s < SF; ++s) sfa[s] = sfz[s] = 0.0;
+        if (SBW) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) Dl[r * 64] = 0.0;
         }
     }
     auto load_counts = [&](const int tile, unsigned (&dst)[4]) {
@@ -2533,7 +2556,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     };
     // XIO = 2: A fragments and z of a tile are requested when the tile starts and used behind its K loop
     auto load_stim = [&](const int tile) {
-        if constexpr (XIO == 2) {
+        if constexpr (XIO >= 2) {
             // frame and offset of the tile's first bin: one division per chunk, then increments (q >= 16)
             if (tile == tile_beg) {
                 const int tb = tile * TT;
@@ -2548,14 +2571,23 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             }
             const int ph = (tile < p.sepNH) ? tile : p.sepNH + (sepO >> p.sepG);
             const long long base = (sepF > p.sepM) ? sepF - p.sepM : 0;
+            sepPh = ph;
+            sepBase = base;
             const double* ap = p.sepA + (size_t)ph * (SF * 64) + lane;
             const double* zp = p.sepZ + (valid_n ? nloc : 0);
+            const double* wp = p.sepTheta + (size_t)(valid_n ? nloc : 0) * p.P + 1;
+            // w_t of the lane's neuron: read again per tile (L1) rather than held across the epilogue
+            const double w0 = wp[0], w1 = wp[(p.sepBt > 1) ? 1 : 0], w2 = wp[(p.sepBt > 2) ? 2 : 0];
 #pragma unroll
             for (int s = 0; s < SF; ++s) {
-                long long f = base + sfj[s];
+                // the lane's B entry of k-step s: (j', bt) = divmod(4 s + grp, 3)
+                const int k = 4 * s + grp, j = k / 3, bt = k - 3 * j;
+                long long f = base + j;
                 f = (f < p.sepT) ? f : p.sepT - 1;
                 sfa[s] = ap[s * 64];
-                sfz[s] = zp[(size_t)f * p.sepLdy];
+                const double z = zp[(size_t)f * p.sepLdy];
+                const double w = (bt == 0) ? w0 : ((bt == 1) ? w1 : w2);
+                sfz[s] = (valid_n && k < 18 && bt < p.sepBt) ? z * w : 0.0;
             }
         }
     };
@@ -2641,7 +2673,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             } else {
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
-                constexpr int PW2 = (KS / 2 < PGL_PW / 2) ? KS / 2 : PGL_PW / 2;
+                constexpr int PWX = SBWC ? PGL_PW / 2 : PGL_PW;          // (fused stimulus backward: a shorter Wmat ring, registers)
+                constexpr int PW2 = (KS / 2 < PWX / 2) ? KS / 2 : PWX / 2;
                 const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
 #pragma unroll
@@ -2662,13 +2695,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                 }
             }
         }
-        if constexpr (XIO == 2) {                         // the stimulus current: five more k-steps
+        if constexpr (XIO >= 2) {                         // the stimulus current: five more k-steps
 #pragma unroll
             for (int s = 0; s < SF; ++s) {
                 if (s & 1)
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s] * sfw[s], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s], acc1, 0, 0, 0);
                 else
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s] * sfw[s], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sfa[s], sfz[s], acc0, 0, 0, 0);
             }
         }
         PGL_PROF_MARK(3);
@@ -2727,10 +2760,22 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
         PGL_PROF_MARK(4);
         if (PGL_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
         if constexpr (XIO != 0) {
-            if (p.want_grad) {
+            if (p.want_grad && !SBW) {
                 double* xs_ = xslab + (size_t)(tile - p.tile0) * xstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xs_[r * 64] = rr[r];
+            }
+        }
+        // stimulus backward: the A^T fragments of this tile's phase, in flight behind the backward MFMAs below
+        // (columns 0..15 requested here, 16..17 -- the second accumulator tile -- twelve MFMAs before the end of the
+        //  backward loop: all eight at once did not fit the registers of the 12- and 13-k-tile forms)
+        double sbt[SBWC ? 8 : 1];
+        const double* const atp = SBWC ? p.sepAT + (size_t)sepPh * (8 * 64) + lane : nullptr;
+        if constexpr (SBWC) {
+            if (SBW) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sbt[s] = atp[s * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- backward over all K ----
@@ -2753,6 +2798,45 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
                         if (more) piece((s + 1) / DSS - 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
+                if constexpr (SBWC) {
+                    if (s == ((NS > 12) ? NS - 12 : 0) && SBW) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 4; u < 8; ++u) sbt[u] = atp[u * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if constexpr (SBWC) {
+                if (SBW) {
+                    d4_t Dst[2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Dst[0][r] = Dl[r * 64];
+                    Dst[1] = (d4_t){Dl[4 * 64], 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        Dst[s >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sbt[s], rr[s & 3], Dst[s >> 2], 0, 0, 0);
+                    // the next tile has another frame base (or the chunk ends): write the piece out
+                    bool flush = !more;
+                    if (more) {
+                        const int o2 = sepO + TT;
+                        const long long F2 = sepF + ((o2 >= p.sepQ) ? 1 : 0);
+                        flush = ((F2 > p.sepM) ? F2 - p.sepM : 0) != sepBase;
+                    }
+                    if (flush) {
+                        const long long tf = pgl_sepd_first_tile(sepBase, p.sepM, p.sepQ, p.tile0);
+                        const int slot = chunk - (int)((tf - p.tile0) / p.tilesPerChunk);
+                        double* dp = p.sepD + ((((size_t)(sepBase - p.sepB0) * p.sepSL + slot) * p.nPT + pt) * 5) * 64 + lane;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dp[r * 64] = Dst[0][r];
+                        dp[4 * 64] = Dst[1][0];
+                        Dst[0] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                        Dst[1] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Dl[r * 64] = Dst[0][r];
+                    Dl[4 * 64] = Dst[1][0];
                 }
             }
         }
@@ -2871,7 +2955,8 @@ __global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ Gp
                            double* __restrict__ ll_out, double* __restrict__ grad_out, int N, int B,
                            int Dstim, int Kimp, int Ktot, int KT, int n_lo, int npost, int nPT,
                            int nChunks, int Nall, int np0, int DsAll, int ds0, int nsub, int kt0,
-                           int nkt, const int* __restrict__ pidx)
+                           int nkt, const int* __restrict__ pidx, const double* __restrict__ wtpart = nullptr,
+                           int nwt = 0, int ldy = 0, int Bt = 0)
 {
     // reduces the k-tiles [kt0, kt0 + nkt) of every post tile (the two halves of the two-pass
     // kernels are reduced by separate launches: the first one runs beside pass 2).
@@ -2891,7 +2976,26 @@ __global__ __launch_bounds__(1024) void k_finalize(const double* __restrict__ Gp
         // ll reduction into this launch (nsub > 0) -- it then runs beside the G reduction
         if (nsub <= 0) return;
         const int n = (int)blockIdx.x - gblocks;
-        if (n >= npost) return;
+        if (n >= npost) {
+            // ... and behind them (fused stimulus backward): d ll / d w_t[n][bt] = sum over the nwt block partials of
+            // k_sepf_finish_d, one block per temporal basis, wave w takes the partials w, w + nwf, ... (fixed order)
+            const int bt = n - npost;
+            if (wtpart == nullptr || bt >= Bt || grad_out == nullptr) return;
+            const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            if (lane < ldy) {
+                int i = w, u = 0;
+                for (; i < nwt; i += nwf, ++u) a[u & 3] += wtpart[((size_t)i * 3 + bt) * ldy + lane];
+            }
+            red[w][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+            __syncthreads();
+            if (w == 0 && lane < npost) {
+                double v = 0.0;
+                for (int j = 0; j < nwf; ++j) v += red[j][lane];
+                grad_out[(size_t)lane * P + 1 + bt] = v;
+            }
+            return;
+        }
         pgl_reduce_ll(llpart, gbpart, ll_out, grad_out, n, P, nPT, nChunks, nsub, red);
         return;
     }
@@ -4542,6 +4646,10 @@ struct SepfParams {
     double* __restrict__ grad;           // (npost, P): the w_t columns are written by k_sepf_finish
     int P, Bt, M, q, npost, nPT, ldy, tile0, nTiles;
     long long Tstim, F0, F1;             // frames that hold bins of the tile range
+    // fused stimulus backward (k_fused7<.., 3> -> k_sepf_finish_d): pieces D[base - B0][slot][post tile][5][64]
+    const double* __restrict__ D;
+    long long B0, B1;                    // frame bases of the first / last evaluated tile
+    int SL, tilesPerChunk;
 };
 
 template <int J, int BT>
@@ -4715,6 +4823,73 @@ __global__ __launch_bounds__(1024) void k_sepf_finish(const SepfParams p, const 
             for (int w = 0; w < 16; ++w) v += red[w][lane];
             p.grad[(size_t)n * p.P + 1 + bt] = v;
         }
+    }
+}
+
+// Fused stimulus backward, second half: k_fused7<.., 3> left D[(j', bt)][n] = sum_i A[i][(j', bt)] r[i][n] per frame base b
+// (column (j', bt) belongs to frame min(b + j', Tstim - 1)), one piece per chunk that holds tiles of the base.  Here, per
+// frame f and row n (one wave per frame, 16 frames per block, lanes = the <= 64 rows of the four post tiles):
+//   Dt[f][bt] = sum of the pieces' columns (f - b, bt) over the bases b = f - 5 .. f (and, for the last frame, of the
+//               columns that clamp onto it),
+//   QvT[f][n] = sum_bt Dt w_t[n][bt]          (d ll / d z_n[f]: the d/dw_x GEMM follows),
+//   wpart[block][bt][n] = sum over the block's frames of Dt z_n[f]   (d ll / d w_t: summed over the blocks by the
+//               trailing blocks of k_finalize, in a fixed order).
+// Which (base, slot) pieces exist follows from the launch geometry alone (pgl_sepd_first_tile): nothing is zeroed.
+__global__ __launch_bounds__(1024) void k_sepf_finish_d(const SepfParams p)
+{
+    __shared__ double red[16][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane, pt = lane >> 4, col = lane & 15;
+    const long long f = (long long)blockIdx.x * 16 + wave;
+    const bool vn = n < p.ldy && pt < p.nPT;
+    const long long tileE = (long long)p.tile0 + p.nTiles - 1;
+    double dt[3] = {0.0, 0.0, 0.0};
+    auto gather = [&](const long long fv) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const long long b = fv - j;
+            if (b < p.B0 || b > p.B1) continue;
+            const long long tf = pgl_sepd_first_tile(b, p.M, p.q, p.tile0);
+            long long tl = ((b + 1 + p.M) * (long long)p.q + 15) / 16 - 1;
+            if (tl > tileE) tl = tileE;
+            const int c0 = (int)((tf - p.tile0) / p.tilesPerChunk), c1 = (int)((tl - p.tile0) / p.tilesPerChunk);
+            for (int sl = 0; sl <= c1 - c0; ++sl) {
+                const double* dp = p.D + ((((size_t)(b - p.B0) * p.SL + sl) * p.nPT + pt) * 5) * 64 + col;
+#pragma unroll
+                for (int bt = 0; bt < 3; ++bt) {
+                    const int c = 3 * j + bt;
+                    const int o = (c < 16) ? (c >> 2) * 64 + (c & 3) * 16 : 4 * 64 + (c - 16) * 16;
+                    dt[bt] += dp[o];
+                }
+            }
+        }
+    };
+    if (vn && f < p.Tstim) {
+        gather(f);
+        if (f == p.Tstim - 1)
+            for (long long fv = f + 1; fv <= p.B1 + 5; ++fv) gather(fv);
+    }
+    double gw[3] = {0.0, 0.0, 0.0};
+    if (vn && f < p.Tstim) {
+        const bool vr = n < p.npost;
+        const double z = p.YfT[(size_t)f * p.ldy + n];
+        double q = 0.0;
+#pragma unroll
+        for (int bt = 0; bt < 3; ++bt) {
+            const double w = (vr && bt < p.Bt) ? p.theta[(size_t)n * p.P + 1 + bt] : 0.0;
+            q = fma(dt[bt], w, q);
+            gw[bt] = dt[bt] * z;
+        }
+        p.QvT[(size_t)f * p.ldy + n] = q;
+    }
+#pragma unroll
+    for (int bt = 0; bt < 3; ++bt) red[wave][bt][lane] = gw[bt];
+    __syncthreads();
+    if (wave < 3 && vn) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][wave][lane];
+        p.wpart[((size_t)blockIdx.x * 3 + wave) * p.ldy + n] = v;
     }
 }
 

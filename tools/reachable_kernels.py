@@ -17,30 +17,38 @@ def shapes():
     for N in Ns:
         counts = sorted(set(c for c in (N, 1, 15, 16, 17, 32, 33, 48, 49, 64, 65, 80, 100, 128) if c <= N))
         for B in range(1, 9):
-            for nT in (64, 600000):
-                for stim, Ds in ((0, 0), (0, 9), (0, 200), (1, 3 + 24), (2, 3 + 24), (3, 3 + 24), (2, 4 + 1024)):
+            for nT in (16, 64, 600000):          # (one and four 16-bin tiles: the kernels' tile-pair forms need four)
+                for stim, Ds in ((0, 0), (0, 2), (0, 9), (0, 200), (1, 3 + 24), (2, 3 + 24), (3, 3 + 24), (2, 4 + 1024)):
                     for count in counts:
                         yield N, B, nT, stim, Ds, count
 
 
-def reachable(auto_only=True):
-    """{kernel name: example shape}"""
-    out = {}
-    opts = (0,) if auto_only else (0, 2, 3, 4, 6, 7)
+def reachable_both():
+    """({kernel name: example shape} for the automatic dispatch, the same including the forcing options)"""
+    auto, forced = {}, {}
     for N, B, nT, stim, Ds, count in shapes():
-        for ok in opts:
+        for ok in (0, 2, 3, 4, 6, 7):
             for f32 in ((0, 1) if stim == 0 else (0,)):
                 for path in (0, 1, 2):
                     if path == 2 and count != N:
                         continue
+                    key = (N, B, nT, stim, Ds, count, path, ok, f32)
                     try:
                         names = _lib.plan_kernels(N, B=B, R=200, Dstim=Ds, nT=nT, stim=stim, count=count, path=path,
                                                   opt_kernel=ok, opt_f32=f32)
-                    except _lib.PglError:
-                        continue                     # no plan for this shape (the evaluation raises the same error)
+                    except _lib.PglError as e:
+                        if 'no kernel instantiation' not in str(e):
+                            continue                 # no plan for this shape (the evaluation raises the same error)
+                        names = ['MISSING: N=%d B=%d nT=%d stim=%d Dstim=%d count=%d path=%d opt_kernel=%d f32=%d' % key]
                     for n in names:
-                        out.setdefault(n, (N, B, nT, stim, Ds, count, path, ok, f32))
-    return out
+                        forced.setdefault(n, key)
+                        if ok == 0:
+                            auto.setdefault(n, key)
+    return auto, forced
+
+
+def reachable(auto_only=True):
+    return reachable_both()[0 if auto_only else 1]
 
 
 def built_fused():
@@ -51,8 +59,7 @@ def built_fused():
 
 
 if __name__ == '__main__':
-    auto = reachable(True)
-    forced = reachable(False)
+    auto, forced = reachable_both()
     built = built_fused()
     bf = dict((n, r) for n, r in built.items() if n.startswith(FUSED))
     print("fused instantiations built: %d; reachable by the automatic dispatch: %d; reachable with a forcing option: %d"
