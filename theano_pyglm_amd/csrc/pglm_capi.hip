@@ -938,7 +938,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
     case 93: h->opt_slice_cols = value; return PGL_OK;      // dev: feature columns per slice of the 3-phase path (0 = 640)
-    case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels
+    case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels, 3 = stimulus current through the slab, 4 = residual slab + k_sepf_bwd (no fused backward)
     case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer form of k_fused6
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;

@@ -2673,8 +2673,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
             } else {
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
-                constexpr int PWX = SBWC ? PGL_PW / 2 : PGL_PW;          // (fused stimulus backward: a shorter Wmat ring, registers)
-                constexpr int PW2 = (KS / 2 < PWX / 2) ? KS / 2 : PWX / 2;
+                constexpr int PW2 = (KS / 2 < PGL_PW / 2) ? KS / 2 : PGL_PW / 2;
                 const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
 #pragma unroll

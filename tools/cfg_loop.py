@@ -20,6 +20,14 @@ if cfg == 'C5S':          # stress variant: D_stim = 1024 pixels, identity spati
     dev.set_stimulus_separable(stim, 0.1, np.ascontiguousarray(H.golden()['lr2d_ibasis_t']), None)
     theta = np.concatenate((p.theta[:, :1], 0.3 * rng.standard_normal((N, 3)), 0.05 * rng.standard_normal((N, 1024)),
                             p.theta[:, 1:]), axis=1)
+if len(sys.argv) > 3:
+    dev.set_option(94, int(sys.argv[3]))      # dev: 2 tap-rate kernels, 3 stimulus current through the slab, 4 residual slab + k_sepf_bwd
+import time
 for i in range(reps):
     ll, g = dev.ll_grad(theta, p.Weff)
 print(cfg, dev.info()['kernel_version'], "fused %.3f ms total %.3f ms" % dev.last_timing())
+ts = []
+for i in range(20):
+    ll, g = dev.ll_grad(theta, p.Weff)
+    ts.append(dev.last_timing())
+print("median of 20: fused %.4f ms total %.4f ms" % (np.median([t[0] for t in ts]), np.median([t[1] for t in ts])))
