@@ -806,3 +806,58 @@ def test_narrow_post_blocks_of_a_wide_population_one_image_buffer():
     ll2, g2 = d.ll_grad(p.theta[:16], W, 0, 16)
     assert np.allclose(ll, ll2, rtol=1e-12, atol=0) and np.allclose(g, g2, rtol=1e-11, atol=1e-11 * np.abs(g2).max())
     d.close()
+
+
+def test_wide_population_on_resident_tiles():
+    """Populations of more than 128 neurons (more than 640 feature columns) on the resident-tile two-pass kernels: equal-width
+    column slices, forward-only passes of the first slices adding their currents in the slab (k_fused5<.., 1, 2 / 3>), pass 1 of
+    the last slice from the slab, pass 2 on the H and -- for the earlier slices -- the L column parts (k_fused5<.., 2, 0, 1>).
+    Against the in-kernel-feature K-split path (PGL_OPT_KERNEL = 2) to 1e-12, the oracle, for whole populations, a neuron
+    range, a neuron list (pgl_ll_grad_list_dev), a time range off the tile grid, ll only; dense stimulus columns ride in
+    the last slice.  With one feature per neuron (B = 1 rows are too short for the two-pass kernel) the K-split path stays."""
+    import torch
+    from theano_pyglm_amd import _lib
+    for N, nT, Ds in ((130, 3000, 0), (160, 2500, 0), (200, 2000, 7), (256, 2000, 0), (300, 1500, 0)):
+        p = H.Problem(N, nT, H.std_ibasis(), seed=N, Dstim=Ds, w_scale=0.5)
+        d = p.device()
+        assert d.info()['kernel_version'] == 5 and d.info()['resident_feature_bytes'] > 0
+        names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], Dstim=Ds, nT=nT)
+        assert all(n.startswith('k_fused5<') for n in names) and any(n.endswith('2, 0, 1>') for n in names), names
+        ll, g = d.ll_grad(p.theta, p.Weff)
+        d2 = p.device()
+        d2.set_option(_lib.OPT_KERNEL, 2)
+        assert d2.info()['kernel_version'] == 2
+        ll2, g2 = d2.ll_grad(p.theta, p.Weff)
+        assert np.allclose(ll, ll2, rtol=1e-12) and H.rel_err(g, g2) < 1e-11
+        llo, go = p.oracle_ll_grad(N - 3, N)
+        assert np.allclose(ll[N - 3:], llo, rtol=LL_RTOL) and H.rel_err(g[N - 3:], go) < G_RTOL
+        ll_only, _ = d.ll_grad(p.theta, p.Weff, want_grad=False)
+        assert np.array_equal(ll_only, ll)
+        lo, hi = 17, N - 9
+        llr, gr = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+        assert np.allclose(llr, ll[lo:hi], rtol=1e-12) and H.rel_err(gr, g[lo:hi]) < 1e-11
+        # a neuron list (what the lock-step optimizer launches once neurons have converged)
+        idx = np.sort(np.random.RandomState(N).permutation(N)[:37]).astype(np.int32)
+        d_idx = torch.from_numpy(idx).cuda()
+        d_th = torch.from_numpy(np.ascontiguousarray(p.theta[idx])).cuda()
+        d_W = torch.from_numpy(np.ascontiguousarray(p.Weff)).cuda()
+        d_ll = torch.zeros(len(idx), dtype=torch.float64, device='cuda')
+        d_g = torch.zeros((len(idx), p.P), dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        d.ll_grad_list_dev(d_idx.data_ptr(), len(idx), d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+        d.sync()
+        assert np.allclose(d_ll.cpu().numpy(), ll[idx], rtol=1e-12) and H.rel_err(d_g.cpu().numpy(), g[idx]) < 1e-11
+        d.set_time_range(160, nT - 37)
+        d2.set_time_range(160, nT - 37)
+        llt, gt = d.ll_grad(p.theta, p.Weff)
+        llt2, gt2 = d2.ll_grad(p.theta, p.Weff)
+        assert np.allclose(llt, llt2, rtol=1e-12) and H.rel_err(gt, gt2) < 1e-11
+        d.close()
+        d2.close()
+    p = H.Problem(160, 1000, H.std_ibasis()[:, :1], seed=5, w_scale=0.5)        # B = 1: 80-column slices
+    d = p.device()
+    assert d.info()['kernel_version'] == 2
+    ll, g = d.ll_grad(p.theta, p.Weff)
+    llo, go = p.oracle_ll_grad(0, 2)
+    assert np.allclose(ll[:2], llo, rtol=LL_RTOL) and H.rel_err(g[:2], go) < G_RTOL
+    d.close()

@@ -60,7 +60,7 @@ struct pgl_context {
         int key = 0, tile0 = 0, ntiles = 0;   // key = ktl << 8 | kth (kth = 0: one-part images); 0 = empty / stale
         unsigned long long stamp = 0;
     };
-    static constexpr int NIMG = 3;
+    static constexpr int NIMG = 8;          // (a wide population keeps one image set per column slice)
     ImgSlot imgs[NIMG];
     int img_cur = 0;
     unsigned long long img_clock = 0;
@@ -164,10 +164,14 @@ struct Slice {
     int np0, Ns, ds0, Ds;
 };
 
-static std::vector<Slice> make_slices(const pgl_context* h)
+static std::vector<Slice> make_slices(const pgl_context* h, bool balanced = false)
 {
     std::vector<Slice> out;
-    const int maxNs = std::min(128, (h->opt_slice_cols > 0 ? h->opt_slice_cols : 640) / h->B);
+    int maxNs = std::min(128, (h->opt_slice_cols > 0 ? h->opt_slice_cols : 640) / h->B);
+    // balanced: slices of equal width (N = 160: 80 + 80, not 128 + 32) -- every slice then has a long enough feature row for
+    // the two-pass kernel on resident tiles (the wide-population path).  The K-split kernel of the other sliced paths pads
+    // its rows to 5 / 10 / 20 / 40 k-tiles and is better off with full 640-column slices and a short last one.
+    if (balanced && h->N > maxNs) maxNs = (h->N + (h->N + maxNs - 1) / maxNs - 1) / ((h->N + maxNs - 1) / maxNs);
     int ds_left = h->sep ? 0 : h->Dstim, ds0 = 0;      // a separable stimulus is not a set of feature columns
     for (int np0 = 0; np0 < h->N; np0 += maxNs) {
         Slice sl{np0, std::min(maxNs, h->N - np0), 0, 0};
@@ -207,7 +211,7 @@ static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(kt
 static int fused6_wg_per_cu(const Plan& pl);
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
-                     bool single_slice = true, bool force7 = false)
+                     bool single_slice = true, bool force7 = false, bool wide = false)
 {
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
@@ -232,11 +236,14 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
                  (force7 && need > 16 && (h->opt_kernel == 0 || h->opt_kernel == 7)))
             pl.version = 5;
     }
+    // wide: one column slice of a wide population on the resident-tile two-pass kernel (select_plans has checked the
+    // row lengths and the memory)
+    if (wide) pl.version = 5;
     pl.tile0 = (int)(h->t_lo / 16);
     pl.nTiles = (int)((h->t_hi + 15) / 16) - pl.tile0;
     pl.ktl = pl.kth = 0;
     if (pl.version == 5 && !pick_pair(need, pl.ktl, pl.kth)) pl.version = 4;
-    if (pl.version == 5 && h->opt_kernel == 0 && find_img(h, pl.ktl << 8 | pl.kth, pl.tile0, pl.nTiles) < 0) {
+    if (pl.version == 5 && !wide && h->opt_kernel == 0 && find_img(h, pl.ktl << 8 | pl.kth, pl.tile0, pl.nTiles) < 0) {
         // resident feature tiles need nTiles * (L + H image bytes) of HBM (3.1 GB at C3); in auto mode
         // fall back to on-the-fly generation (version 4) when the device cannot spare them
         if (!img_room(h, (size_t)pl.nTiles * img_pair_bytes(pl.ktl, pl.kth))) pl.version = 4;
@@ -554,8 +561,8 @@ template <int KTL, int KTH, int XIN = 0>
 static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
     if (g_dry) {
-        if (pass != 2) dry_record("k_fused5", {KTL, KTH, 1, XIN});
-        if (pass != 1 && fp.want_grad) dry_record("k_fused5", {KTL, KTH, 2, 0});
+        if (pass != 2) dry_record("k_fused5", {KTL, KTH, 1, XIN, 0});
+        if (pass != 1 && fp.want_grad) dry_record("k_fused5", {KTL, KTH, 2, 0, 0});
         return hipSuccess;
     }
     auto k1 = k_fused5<KTL, KTH, 1, XIN>;
@@ -602,6 +609,57 @@ static hipError_t launch_fused5_xin(const Plan& pl, const FusedParams& fp, hipSt
     case 12 << 8 | 14: return launch_fused5_t<12, 14, 1>(pl, fp, s, pass);
     case 14 << 8 | 18: return launch_fused5_t<14, 18, 1>(pl, fp, s, pass);
     case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L, 1>(pl, fp, s, pass);
+    }
+    return hipErrorInvalidValue;
+}
+
+// column slices of a wide population (N > 128 or more than 640 feature columns) on resident tiles.  mode 0: forward only,
+// the slice's partial currents written to the slab; 1: forward only, added to the slab; 2: the last slice -- pass 1 from the
+// slab (epilogue, residuals out, G of its L columns); 3: pass 2 on the H part; 4: pass 2 on the L part (the gradient of the
+// L columns of a slice whose pass 1 was forward only)
+template <int KTL, int KTH>
+static hipError_t launch_fused5_wide_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int mode)
+{
+    const size_t lds2h = (size_t)2 * pgl_img_bytes(KTH) + 256, lds2l = (size_t)2 * pgl_img_bytes(KTL) + 256;
+    if (g_dry) {
+        if (mode <= 1) dry_record("k_fused5", {KTL, KTH, 1, mode == 0 ? 2 : 3, 0});
+        else if (mode == 2) dry_record("k_fused5", {KTL, KTH, 1, 1, 0});
+        else dry_record("k_fused5", {KTL, KTH, 2, 0, mode == 4 ? 1 : 0});
+        return hipSuccess;
+    }
+    hipError_t e = hipSuccess;
+    if (mode == 0) {
+        auto k = k_fused5<KTL, KTH, 1, 2, 0>;
+        if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    } else if (mode == 1) {
+        auto k = k_fused5<KTL, KTH, 1, 3, 0>;
+        if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    } else if (mode == 2) {
+        auto k = k_fused5<KTL, KTH, 1, 1, 0>;
+        if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+    } else if (mode == 3) {
+        auto k = k_fused5<KTL, KTH, 2, 0, 0>;
+        if ((e = ensure_dyn_lds(k, lds2h)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), lds2h, s, fp);
+    } else {
+        auto k = k_fused5<KTL, KTH, 2, 0, 1>;
+        if ((e = ensure_dyn_lds(k, lds2l)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), lds2l, s, fp);
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_fused5_wide(const Plan& pl, const FusedParams& fp, hipStream_t s, int mode)
+{
+    switch (pl.ktl << 8 | pl.kth) {
+    case 5 << 8 | 5: return launch_fused5_wide_t<5, 5>(pl, fp, s, mode);
+    case 7 << 8 | 7: return launch_fused5_wide_t<7, 7>(pl, fp, s, mode);
+    case 9 << 8 | 11: return launch_fused5_wide_t<9, 11>(pl, fp, s, mode);
+    case 12 << 8 | 14: return launch_fused5_wide_t<12, 14>(pl, fp, s, mode);
+    case 14 << 8 | 18: return launch_fused5_wide_t<14, 18>(pl, fp, s, mode);
+    case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_wide_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L>(pl, fp, s, mode);
     }
     return hipErrorInvalidValue;
 }
@@ -901,7 +959,7 @@ int pgl_destroy(pgl_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->S, &h->ST, &h->spk, &h->wlo, &h->whi, &h->phi, &h->fstim, &h->theta,
                       &h->Weff, &h->ll, &h->grad, &h->Wfrag, &h->bias, &h->Gpart, &h->llpart,
-                      &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
+                      &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->imgs[3].buf, &h->imgs[4].buf, &h->imgs[5].buf, &h->imgs[6].buf, &h->imgs[7].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
                       &h->spart, &h->sepC, &h->sepA, &h->sepAT, &h->sepD, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
@@ -1595,10 +1653,12 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
 // column split (ktl, kth): built on first use and after every change of spikes / basis / stimulus
 // features / time range.  A time-sharded rank (pgl_set_time_range) therefore builds and keeps only its
 // own 1/G of the recording.
-static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles)
+static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles, const Slice* sl = nullptr,
+                                 int slice_no = 0)
 {
     // kth == 0: one image per tile holding all ktl k-tiles (k_fused6); else the L / H pair of k_fused5
-    const int key = ktl << 8 | kth;
+    // sl: the images of ONE column slice of a wide population (key carries the slice number)
+    const int key = (sl ? (slice_no + 1) << 16 : 0) | ktl << 8 | kth;
     int slot = find_img(h, key, tile0, ntiles);
     if (slot >= 0) {
         h->img_cur = slot;
@@ -1622,8 +1682,9 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
     dim3 grid((unsigned)ntiles, kth ? 2 : 1);
     hipLaunchKernelGGL(k_build_fimg, grid, dim3(256), (size_t)h->B * h->Rk * 8, h->stream,
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
-                       (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, h->N, h->B,
-                       h->Rk, h->sep ? 0 : h->Dstim, ktl, kth, tile0, (unsigned char*)im.buf.p);
+                       (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, sl ? sl->Ns : h->N, h->B,
+                       h->Rk, sl ? sl->Ds : (h->sep ? 0 : h->Dstim), ktl, kth, tile0, (unsigned char*)im.buf.p,
+                       h->N, sl ? sl->np0 : 0, h->Dstim, sl ? sl->ds0 : 0);
     HIPCHK(hipGetLastError());
     im.key = key;
     im.tile0 = tile0;
@@ -1641,10 +1702,53 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
 //             the stimulus on the 3-phase path it asks for;
 //   sliced -- the 3-phase path (more than one slice of feature columns, or a separable stimulus by the tap-rate kernels).
 // One function for enqueue_ll_grad, pgl_info and the dry run of the dispatch (pgl_plan_kernels).
-static int select_plans(const pgl_context* h, int n_lo, int n_hi, const std::vector<Slice>& slices, std::vector<Plan>& plans,
-                        bool& sepf, bool& sliced)
+static int select_plans(const pgl_context* h, int n_lo, int n_hi, std::vector<Slice>& slices, std::vector<Plan>& plans,
+                        bool& sepf, bool& sliced, bool* wide_out = nullptr)
 {
+    slices = make_slices(h, wide_out != nullptr);
     plans.assign(slices.size(), Plan());
+    if (wide_out) *wide_out = false;
+    // wide -- more than one slice of feature columns (N > 128 or more than 640 columns) with every slice on the resident-tile
+    //         two-pass kernel: forward-only passes of the first slices add their currents in the slab, the last slice runs
+    //         pass 1 from the slab, then the pass-2 kernels take the gradients of all column parts from the residuals.
+    //         Needs rows of 7 .. 40 k-tiles in every slice (equal-width slices see to that from B = 2 on), no separable
+    //         stimulus, f64 features, and the memory for one image set per slice; else the in-kernel-feature path below.
+    if (wide_out && slices.size() > 1 && slices.size() <= (size_t)pgl_context::NIMG && !h->sep && !h->opt_f32 &&
+        (h->opt_kernel == 0 || h->opt_kernel == 4)) {
+        bool ok = true;
+        size_t bytes = 0;
+        for (const Slice& sl : slices) {
+            const int need = (sl.Ns * h->B + sl.Ds + 15) / 16;
+            int ktl = 0, kth = 0;
+            if (sl.Ns <= 0 || need < 7 || need > 40 || !pick_pair(need, ktl, kth)) { ok = false; break; }
+            const int tile0 = (int)(h->t_lo / 16), nTiles = (int)((h->t_hi + 15) / 16) - tile0;
+            bytes += (size_t)nTiles * img_pair_bytes(ktl, kth);
+        }
+        if (ok && h->opt_kernel == 0) {
+            // the image sets that are not resident yet must fit (with the residual slab) into 90 % of the free memory
+            size_t free_b = 0, total_b = 0, have = 0;
+            for (int i = 0; i < pgl_context::NIMG; ++i)
+                if (h->imgs[i].key >> 16) have += h->imgs[i].buf.cap;
+            if (bytes > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes - have > free_b / 10 * 9) ok = false;
+        }
+        if (ok) {
+            for (size_t i = 0; i < slices.size(); ++i) {
+                int rc = make_plan(h, n_lo, n_hi, slices[i], plans[i], false, false, true);
+                if (rc) return rc;
+                if (plans[i].version != 5) ok = false;
+            }
+        }
+        if (ok) {
+            sepf = false;
+            sliced = true;
+            *wide_out = true;
+            return PGL_OK;
+        }
+    }
+    if (wide_out) {
+        slices = make_slices(h);
+        plans.assign(slices.size(), Plan());
+    }
     sepf = h->sep && h->sepf && h->opt_sepf != 2 && slices.size() == 1 && !h->opt_f32 &&
            (h->opt_kernel == 0 || h->opt_kernel == 7 || h->opt_kernel == 4);
     if (sepf) {
@@ -1668,11 +1772,11 @@ static int select_plans(const pgl_context* h, int n_lo, int n_hi, const std::vec
 static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_theta,
                            const double* d_Weff, double* d_ll, double* d_grad)
 {
-    const std::vector<Slice> slices = make_slices(h);
+    std::vector<Slice> slices;
     std::vector<Plan> plans;
-    bool sepf = false, sliced = false;
+    bool sepf = false, sliced = false, wide = false;
     {
-        int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced);
+        int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced, &wide);
         if (rc) return rc;
     }
     size_t maxG = 0, maxLL = 0;
@@ -1817,6 +1921,53 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
                                pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
             HIPCHK(hipGetLastError());
         }
+    } else if (wide) {
+        // a wide population on resident tiles: one image set, one set of Wmat fragments and up to three launches of the two-pass
+        // kernel per column slice; currents and residuals travel in the slab
+        const Plan& p0 = plans[0];
+        const size_t S = slices.size();
+        ENSURE(h->Xbuf, (size_t)p0.nTiles * p0.nPT * 256 * 8);
+        std::vector<int> slot(S);
+        for (size_t i = 0; i < S; ++i) {
+            int rc = ensure_feature_images(h, plans[i].ktl, plans[i].kth, p0.tile0, p0.nTiles, &slices[i], (int)i);
+            if (rc) return rc;
+            slot[i] = h->img_cur;
+        }
+        if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        auto params = [&](const size_t i, FusedParams& fp) {
+            h->img_cur = slot[i];
+            fill_params(h, plans[i], slices[i], n_lo, d_grad != nullptr, 0, fp);
+        };
+        for (size_t i = 0; i < S; ++i) {                       // forward: the slices add up in the slab; the last one closes
+            int rc = launch_prep(h, plans[i], slices[i], n_lo, d_theta, d_Weff);
+            if (rc) return rc;
+            FusedParams fp;
+            params(i, fp);
+            const bool last = i + 1 == S;
+            hipError_t e = launch_fused5_wide(plans[i], fp, h->stream, last ? 2 : (i == 0 ? 0 : 1));
+            if (e == hipSuccess && last && d_grad) e = launch_fused5_wide(plans[i], fp, h->stream, 3);
+            if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("wide launch: ") + hipGetErrorString(e));
+        }
+        if (d_grad) {
+            int rc = launch_finalize_grad(h, plans[S - 1], slices[S - 1], n_lo, d_Weff, d_ll, d_grad, true);
+            if (rc) return rc;
+            for (size_t i = 0; i + 1 < S; ++i) {               // the gradients of the earlier slices from the residuals
+                FusedParams fp;
+                params(i, fp);
+                hipError_t e = launch_fused5_wide(plans[i], fp, h->stream, 4);
+                if (e == hipSuccess) e = launch_fused5_wide(plans[i], fp, h->stream, 3);
+                if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("wide backward launch: ") + hipGetErrorString(e));
+                rc = launch_finalize_grad(h, plans[i], slices[i], n_lo, d_Weff, d_ll, d_grad);
+                if (rc) return rc;
+            }
+        } else {
+            const Plan& pl = plans[S - 1];
+            hipLaunchKernelGGL(k_finalize_ll, dim3(pl.npost), dim3(256), 0, h->stream,
+                               (const double*)h->llpart.p, (const double*)h->gbpart.p, d_ll, d_grad, P,
+                               pl.npost, pl.nPT, pl.nChunks, pl.KSPLIT);
+            HIPCHK(hipGetLastError());
+        }
+        if (rec) HIPCHK(hipEventRecord(h->ev[2], h->stream));
     } else {
         const Plan& p0 = plans[0];
         const int xs = p0.nPT * 16;
@@ -2086,7 +2237,7 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
     int rc = PGL_OK;
     hipError_t e = hipSuccess;
     FusedParams fp{};
-    const std::vector<Slice> slices = make_slices(&c);
+    std::vector<Slice> slices = make_slices(&c);
     std::vector<Plan> plans;
     if (path == 2) {
         plans.assign(slices.size(), Plan());
@@ -2097,11 +2248,21 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
     } else {
         const bool grad = path == 0;
         fp.want_grad = grad;
-        bool sepf = false, sliced = false;
-        rc = select_plans(&c, n_lo, n_lo + count, slices, plans, sepf, sliced);
+        bool sepf = false, sliced = false, wide = false;
+        rc = select_plans(&c, n_lo, n_lo + count, slices, plans, sepf, sliced, &wide);
         if (rc == PGL_OK) {
             const Plan& pl = plans[0];
-            if (sepf) {
+            if (wide) {
+                const size_t S = slices.size();
+                for (size_t i = 0; i < S && e == hipSuccess; ++i) {
+                    e = launch_fused5_wide(plans[i], fp, nullptr, i + 1 == S ? 2 : (i == 0 ? 0 : 1));
+                    if (e == hipSuccess && i + 1 == S && grad) e = launch_fused5_wide(plans[i], fp, nullptr, 3);
+                }
+                for (size_t i = 0; i + 1 < S && e == hipSuccess && grad; ++i) {
+                    e = launch_fused5_wide(plans[i], fp, nullptr, 4);
+                    if (e == hipSuccess) e = launch_fused5_wide(plans[i], fp, nullptr, 3);
+                }
+            } else if (sepf) {
                 if (pl.version == 5) {
                     e = launch_fused5_xin(pl, fp, nullptr, 1);
                     if (e == hipSuccess && grad) e = launch_fused5_xin(pl, fp, nullptr, 2);
@@ -2136,12 +2297,12 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
 int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
 {
     if (!h || !info) return fail(PGL_ERR_ARG, "null argument");
-    const std::vector<Slice> slices = make_slices(h);
+    std::vector<Slice> slices;
     // the stimulus path an evaluation would take: 0 none / dense feature columns, 1 separable by the tap-rate kernels on
     // the 3-phase path, 2 separable at the frame rate (k_sepf_*, impulse columns on resident tiles)
     std::vector<Plan> plans;
-    bool sepf = false, sliced = false;
-    int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced);
+    bool sepf = false, sliced = false, wide = false;
+    int rc = select_plans(h, n_lo, n_hi, slices, plans, sepf, sliced, &wide);
     if (rc) return rc;
     const int stim_path = sepf ? 2 : (h->sep ? 1 : 0);
     const Plan& pl = plans[0];
@@ -2156,6 +2317,15 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
             : (pl.version == 4) ? 2.0 * (double)pl.nTiles * pl.nPT * 2048.0
             : (pl.version == 6 || pl.version == 7) ? v[10] * pl.nPB : 0.0;
+    if (wide) {                              // every column slice has its image set; each post block streams all of them
+        v[10] = v[11] = 0.0;
+        for (const Plan& q : plans) {
+            const double b = (double)q.nTiles * (double)img_pair_bytes(q.ktl, q.kth);
+            v[10] += b;
+            v[11] += 2.0 * b * q.nPB;
+        }
+        v[11] += 2.0 * (double)plans.size() * (double)pl.nTiles * pl.nPT * 2048.0;
+    }
     v[0] = pl.blocks; v[1] = pl.threads; v[2] = pl.nChunks; v[3] = pl.KT; v[4] = (double)pl.lds;
     v[5] = 16;
     const double nrows = (double)(h->t_hi - h->t_lo);

@@ -1633,8 +1633,11 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
                                                     const double* __restrict__ phi,
                                                     const double* __restrict__ fstim, long long nT,
                                                     int N, int B, int R, int Dstim, int ktl, int kth,
-                                                    int tile0, unsigned char* __restrict__ Fimg)
+                                                    int tile0, unsigned char* __restrict__ Fimg,
+                                                    int Nall, int np0, int DsAll, int ds0)
 {
+    // N presynaptic neurons from np0 on and Dstim stimulus columns from ds0 on: the whole feature row, or one column slice of
+    // a wide population (Nall / DsAll = the strides of the window tables and of fstim)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* phiS = reinterpret_cast<double*>(smem);
     for (int i = threadIdx.x; i < B * R; i += blockDim.x) phiS[i] = phi[i];
@@ -1654,9 +1657,9 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
             const long long tg = (long long)tile * 16 + t;
             if (col < Kimp) {
                 const int np = col / B, b = col - np * B;
-                v = conv_one(spk, wlo[(size_t)tile * N + np], whi[(size_t)tile * N + np], (int)tg, R, phiS + b * R);
+                v = conv_one(spk, wlo[(size_t)tile * Nall + np0 + np], whi[(size_t)tile * Nall + np0 + np], (int)tg, R, phiS + b * R);
             } else if (col < Kimp + Dstim) {
-                v = (tg < nT) ? fstim[tg * Dstim + (col - Kimp)] : 0.0;
+                v = (tg < nT) ? fstim[tg * DsAll + ds0 + (col - Kimp)] : 0.0;
             }
         }
         dst[i] = v;
@@ -1741,7 +1744,7 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 // ---------------------------------------------------------------------------
 // XIN = 1 (pass 1): the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] -- the stimulus current of a
 // separable stimulus (k_sepf_fwd) -- which pass 1 then overwrites with the residuals as always
-template <int KTL, int KTH, int PASS, int XIN = 0>
+template <int KTL, int KTH, int PASS, int XIN = 0, int PART = 0>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
     constexpr int TT = 16, NW = 8;
@@ -1750,7 +1753,14 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int KSL = 4 * KTL;                 // k-steps of the L part
     constexpr int RSL = pgl_img_rsh(KTL), RSH = pgl_img_rsh(KTH);
     constexpr int IMGL = pgl_img_bytes(KTL), IMGH = pgl_img_bytes(KTH);
-    constexpr int KTG = (PASS == 1) ? KTL : KTH; // k-tiles of G this pass accumulates
+    // pass 2 works on the H part of the column split (PART = 0) or, for the earlier column slices of a wide population whose
+    // forward-only pass 1 left their L columns without a gradient, on the L part (PART = 1)
+    constexpr int KTP = PART ? KTL : KTH;        // k-tiles of the part pass 2 walks
+    constexpr int IMGP = PART ? pgl_img_bytes(KTL) : pgl_img_bytes(KTH);
+    constexpr size_t OFFP = PART ? 0 : (size_t)pgl_img_bytes(KTL);   // its offset inside a tile's image pair
+    constexpr int KTG = (PASS == 1) ? KTL : KTP; // k-tiles of G this pass accumulates
+    constexpr bool FWO = (PASS == 1) && (XIN >= 2);   // forward only: raw currents to the slab (XIN = 3: added to what is there)
+    constexpr bool XRD = (XIN == 1) || (XIN == 3);    // the currents start from the slab
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     PGL_PROF_ENTRY
 
@@ -1766,8 +1776,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     // pass 1: L buffers at 0 and IMGL, H buffer behind them; pass 2: two H buffers
     unsigned char* buf0 = smem;
     unsigned char* buf2 = smem + IMGL;           // pass 1 only
-    unsigned char* buf1 = smem + ((PASS == 1) ? 2 * IMGL : IMGH);
-    double* Cs = reinterpret_cast<double*>(smem + ((PASS == 1) ? 2 * IMGL + IMGH : 2 * IMGH));
+    unsigned char* buf1 = smem + ((PASS == 1) ? 2 * IMGL : IMGP);
+    double* Cs = reinterpret_cast<double*>(smem + ((PASS == 1) ? 2 * IMGL + IMGH : 2 * IMGP));
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
     d4_t G[KTG];
@@ -1792,8 +1802,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     // backward over one image of KTG k-tiles.  The DMA rounds of up to two images of the next tile
     // (NR0 rounds g0 -> l0, then NR1 rounds g1 -> l1) go out between the MFMAs.
     constexpr int NRL = (IMGL / 1024 + 7) / 8, NRH = (IMGH / 1024 + 7) / 8;
-    constexpr int NR0 = (PASS == 1) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
-    constexpr int RSG = (PASS == 1) ? RSL : RSH;
+    constexpr int NR0 = (PASS == 1 || PART) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
+    constexpr int RSG = (PASS == 1 || PART) ? RSL : RSH;
     auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
                         unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
         const double* fb = reinterpret_cast<const double*>(Fb) + pgl_img_brow(grp) * RSG + col;
@@ -1808,7 +1818,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / KTG)) * RSG + 16 * (s % KTG));
         auto round = [&](const int j) {
             if (j < NR0) {
-                pgl_dma_round<(PASS == 1) ? KTL : KTH>(g0, l0, j, wave, lane);
+                pgl_dma_round<(PASS == 1 || PART) ? KTL : KTH>(g0, l0, j, wave, lane);
             } else {
                 pgl_dma_round<KTH>(g1, l1, j - NR0, wave, lane);
             }
@@ -1927,9 +1937,9 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 }
             }
             PGL_PROF_MARK(0);
-            const bool do_bwd = active && p.want_grad && !PGL_DBG(16);
-            double xin[XIN ? 4 : 1];
-            if constexpr (XIN != 0) {                     // requested in front of the barrier: its wait hides the latency
+            const bool do_bwd = !FWO && active && p.want_grad && !PGL_DBG(16);
+            double xin[XRD ? 4 : 1];
+            if constexpr (XRD) {                          // requested in front of the barrier: its wait hides the latency
                 const double* xs_ = rslab + (size_t)(tile - p.tile0) * rstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xin[r] = xs_[r * 64];
@@ -1940,14 +1950,27 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             PGL_PROF_MARK(2);
             // ---- epilogue on the accumulator registers ----
             double rr[4];
-            if (active) {
+            if constexpr (FWO) {
+                // forward only (an earlier column slice of a wide population): the partial currents go to the slab
+                if (active) {
+                    double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double x = acc0[r] + acc1[r];
+                        if constexpr (XRD) x += xin[r];
+                        rs[r * 64] = x;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rr[r] = 0.0;
+            } else if (active) {
                 bool done = false;
                 if (PGL_ENE == 4 && !PGL_DBG(4) && (long long)t0 + TT <= p.t_hi) {
                     // whole tile inside the evaluated range: four elements at a time, fixed order
                     double xs[4], term4 = 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
-                    if constexpr (XIN != 0) {
+                    if constexpr (XRD) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xs[r] += xin[r];
                     }
@@ -1970,7 +1993,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                         for (int e = 0; e < ENE; ++e) {
                             const int r = ENE * h2 + e;
                             xe[e] = bias_l + (acc0[r] + acc1[r]);
-                            if constexpr (XIN != 0) xe[e] += xin[r];
+                            if constexpr (XRD) xe[e] += xin[r];
                             se[e] = (double)scb[r];
                             const long long tg = (long long)t0 + grp + 4 * r;
                             vte[e] = valid_n && (tg < p.t_hi);
@@ -2021,12 +2044,12 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             PGL_PROF_MARK(6);
         }
         PGL_PROF_STORE(1);
-        if (active) {
+        if (active && !FWO) {
             const size_t slot = (size_t)chunk * p.nPT + pt;
             p.llpart[slot * 64 + lane] = ll_acc;
             p.gbpart[slot * 64 + lane] = gb_acc;
         }
-        if (active && p.want_grad) {
+        if (active && p.want_grad && !FWO) {
             double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, 0, p.nChunks, chunk, lane);
             const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
@@ -2039,7 +2062,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         // =============================== pass 2 ===============================
         double rv[4] = {0.0, 0.0, 0.0, 0.0}, rn[4] = {0.0, 0.0, 0.0, 0.0};
         if (tile_beg < tile_end) {
-            pgl_dma_half<KTH>(fimg + (size_t)tile_beg * IMGS + IMGL, buf0, wave, lane);
+            pgl_dma_half<KTP>(fimg + (size_t)tile_beg * IMGS + OFFP, buf0, wave, lane);
             if (active) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
@@ -2059,22 +2082,22 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             const bool more = tile + 1 < tile_end;
             const bool do_bwd = active && !PGL_DBG(16);
             if (more) {
-                if (!do_bwd) pgl_dma_half<KTH>(fimg + (size_t)(tile + 1) * IMGS + IMGL, Hn, wave, lane);
+                if (!do_bwd) pgl_dma_half<KTP>(fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn, wave, lane);
                 if (active) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
                 }
             }
             PGL_PROF_MARK(2);
-            if (do_bwd) bwd_half(Hb, rv, fimg + (size_t)(tile + 1) * IMGS + IMGL, Hn, nullptr, nullptr, more);
+            if (do_bwd) bwd_half(Hb, rv, fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn, nullptr, nullptr, more);
             PGL_PROF_MARK(3);
         }
         PGL_PROF_STORE(2);
         if (active) {
-            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, KTL, p.nChunks, chunk, lane);
+            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, PART ? 0 : KTL, p.nChunks, chunk, lane);
             const size_t gcs = (size_t)p.nChunks * 64;
 #pragma unroll
-            for (int kt = 0; kt < KTH; ++kt) {
+            for (int kt = 0; kt < KTP; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
             }
