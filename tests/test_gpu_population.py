@@ -868,3 +868,26 @@ def test_bfgs_hmul_kernel_against_dense_algebra():
         for m in range(4, M):
             assert torch.equal(H[m], H0[m]) and bool((t[m] == -7.0).all())
     d.close()
+
+
+def test_sta_factorisation_on_the_gpu_matches_lapack_svd():
+    """smart_init.leading_singular_pairs (batched Gram matrices + one batched symmetric eigensolve on the GPU) against
+    np.linalg.svd -- what the reference calls per neuron (smart_init.py:68-72): leading singular value to 1e-12, the vectors
+    up to the pair's common sign, for wide (300 x 1024 STA), tall and noise-only matrices; same values as the host routine."""
+    from theano_pyglm_amd.inference.smart_init import leading_singular_pairs, leading_singular_pair
+    rng = np.random.default_rng(11)
+    for shape, planted in (((300, 1024), 2.0), ((300, 1024), 0.0), ((40, 7), 1.0), ((12, 300), 0.3)):
+        S = rng.standard_normal((6,) + shape)
+        for i in range(6):
+            S[i] += planted * np.outer(rng.standard_normal(shape[0]), rng.standard_normal(shape[1]))
+        U, Sig, V = leading_singular_pairs(S)
+        for i in range(6):
+            u0, s0, v0 = np.linalg.svd(S[i], full_matrices=False)
+            sg = np.sign(u0[:, 0].dot(U[i]))
+            gap = s0[0] / s0[1]
+            tol = 1e-9 / max(gap - 1.0, 1e-3)            # (the vectors of a nearly degenerate pair are ill-conditioned)
+            assert abs(Sig[i] - s0[0]) <= 1e-12 * s0[0]
+            assert np.max(np.abs(U[i] - sg * u0[:, 0])) < tol and np.max(np.abs(V[i] - sg * v0[0])) < tol
+            assert U[i][np.argmax(np.abs(U[i]))] > 0
+            uh, sh, vh = leading_singular_pair(S[i])
+            assert abs(sh - Sig[i]) <= 1e-12 * sh and np.max(np.abs(uh - U[i])) < tol and np.max(np.abs(vh - V[i])) < tol

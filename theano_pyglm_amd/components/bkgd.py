@@ -141,6 +141,8 @@ class SpatiotemporalStimulus(Component):
         if self.bkgd_model['temporal_basis']['norm']:
             ibt = ibt / ibt.sum(axis=0, keepdims=True)          # bkgd.py:294-296
         self.ibasis_t, self.ibasis_x = ibt, ibx
+        # a pixel stimulus: the spatial basis is the identity (checked once: the comparison reads D^2 numbers)
+        self.identity_x = ibx.shape[0] == ibx.shape[1] and bool(np.array_equal(ibx, np.eye(ibx.shape[0])))
         self.Bt, self.Bx = ibt.shape[1], ibx.shape[1]
         self.n_vars = self.Bx + self.Bt
         # Device layout.  Narrow stimuli (the template's D_stim = 3): the Bt*Bx dense feature columns
@@ -205,9 +207,7 @@ class SpatiotemporalStimulus(Component):
     def upload(self, handle, data):
         stim = np.asarray(data['stim'], dtype=float)
         if self.separable:
-            ident = self.ibasis_x.shape[0] == self.ibasis_x.shape[1] and \
-                np.array_equal(self.ibasis_x, np.eye(self.ibasis_x.shape[0]))
-            handle.set_stimulus_separable(stim, data['dt_stim'], self.ibasis_t, None if ident else self.ibasis_x)
+            handle.set_stimulus_separable(stim, data['dt_stim'], self.ibasis_t, None if self.identity_x else self.ibasis_x)
         else:
             handle.set_stimulus(stim, data['dt_stim'], self.ibasis_t, self.ibasis_x, layout=0)
 
