@@ -322,6 +322,20 @@ def test_sta_matches_oracle():
     data2 = {'S': S[:, [0, 1]], 'dt': 0.001, 'dt_stim': 0.01}
     assert np.allclose(sta(stim2, data2, 30), O.sta(stim2, S[:, [0, 1]], 0.001, 0.01, 30, [0, 1]),
                        rtol=1e-11, atol=1e-14)
+    # the two device forms -- frame-rate (weights from the event lists + one thin GEMM with the raw stimulus; taken for
+    # an integer dt_stim / dt and an even number of frames) and bin-rate (gather from the interpolated stimulus; dev
+    # option 94 = 7, odd frame counts, other ratios) -- agree; spikes behind the last frame hold it (np.interp)
+    from theano_pyglm_amd import _lib
+    h = _lib.DeviceGlm(N, nT, 1, 1, 'exp', 0.001)
+    h.set_spikes(S)
+    for st, dts in ((stim, 0.1), (stim[:37], 0.1), (stim[:30], 0.1), (rng.randn(700, 4), 0.007)):
+        Af = h.sta(st, dts, L, Ns=[0, 1, 3, 4])
+        h.set_option(94, 7)
+        Ab = h.sta(st, dts, L, Ns=[0, 1, 3, 4])
+        h.set_option(94, 0)
+        assert np.allclose(Af, Ab, rtol=1e-11, atol=1e-14)
+        assert np.allclose(Af, O.sta(st, S, 0.001, dts, L, [0, 1, 3, 4]), rtol=1e-11, atol=1e-14)
+    h.close()
 
 
 def test_initialize_with_sta():

@@ -1512,15 +1512,54 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
     HIPCHK(hipSetDevice(h->device));
     DevBuf dstim, distim, deoff, dpart, dA;
     auto cleanup = [&]() { release(dstim); release(distim); release(deoff); release(dpart); release(dA); };
+    // frame-rate form (k_sta_weights + one thin GEMM): dt_stim an integer multiple of dt, an even number of frames (the
+    // GEMM's 16-byte loads), a weight matrix of at most 2 GB; dev option 94 = 7: the bin-rate form
+    const double ratio = dt_stim / h->dt;
+    const long long q = llround(ratio);
+    const bool frame_rate = q >= 1 && std::fabs(ratio - (double)q) <= 1e-9 * ratio && (Tstim % 2) == 0 && Tstim >= 2 &&
+                            (long long)nSel * L * Tstim <= (1ll << 28) && h->opt_sepf != 7;
     int rc = ensure(dstim, (size_t)Tstim * D * 8);
-    if (!rc) rc = ensure(distim, (size_t)h->nT * D * 8);
+    if (!rc && !frame_rate) rc = ensure(distim, (size_t)h->nT * D * 8);
     if (!rc) rc = ensure(deoff, eoff.size() * sizeof(int));
-    if (!rc) rc = ensure(dpart, (size_t)echunks * nSel * LD * 8);
+    if (!rc && !frame_rate) rc = ensure(dpart, (size_t)echunks * nSel * LD * 8);
     if (!rc) rc = ensure(dA, (size_t)nSel * LD * 8);
     if (rc) { cleanup(); return rc; }
     hipError_t e = hipMemcpyAsync(dstim.p, stim, (size_t)Tstim * D * 8, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(deoff.p, eoff.data(), eoff.size() * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (frame_rate && e == hipSuccess) {
+        DevBuf dW, dscale;
+        std::vector<double> scale((size_t)nSel);
+        for (int i = 0; i < nSel; ++i) {
+            double cnt = 0.0;
+            for (int j = eoff[2 * i]; j < eoff[2 * i + 1]; ++j) cnt += (double)h->h_ev[j].y;
+            scale[i] = (h->dt / dt_stim) / cnt;                   // 0 spikes: inf -> NaN rows, like the reference's 0 / 0
+        }
+        rc = ensure(dW, (size_t)nSel * L * Tstim * 8);
+        if (!rc) rc = ensure(dscale, (size_t)nSel * 8);
+        if (rc) { release(dW); release(dscale); cleanup(); return rc; }
+        e = hipMemcpyAsync(dscale.p, scale.data(), (size_t)nSel * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_sta_weights, dim3((unsigned)((Tstim + 255) / 256), (unsigned)L, (unsigned)nSel), dim3(256), 0,
+                               h->stream, (const int2*)h->spk.p, (const int*)deoff.p, (const double*)dscale.p, L,
+                               (long long)Tstim, (int)q, (double*)dW.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {                                    // A (nSel L, D) = Wt (nSel L, Tstim) . stim (Tstim, D)
+            const int Mrows = nSel * L;
+            hipLaunchKernelGGL((k_gemm_kc<1, 0, 16>), dim3((unsigned)((Mrows + 15) / 16), (unsigned)((D + 15) / 16)), dim3(512), 0,
+                               h->stream, (const double*)dW.p, (long long)Tstim, (const double*)dstim.p, (long long)D,
+                               (double*)dA.p, (long long)D, 1LL, Mrows, D, (int)Tstim);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(A_out, dA.p, (size_t)nSel * LD * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        release(dW); release(dscale);
+        cleanup();
+        if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_sta: ") + hipGetErrorString(e));
+        return PGL_OK;
+    }
     if (e == hipSuccess) {
         const long long total = (long long)h->nT * D;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 65535);

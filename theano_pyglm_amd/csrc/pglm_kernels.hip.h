@@ -5144,6 +5144,44 @@ __global__ __launch_bounds__(256) void k_sta_finish(const double* __restrict__ p
     A[(size_t)i * LD + o] = acc * scale / cnt;
 }
 
+// Spike-triggered average at the stimulus FRAME rate (dt_stim = q dt, q integer): np.interp makes the stimulus of bin tt the
+// mix (1 - a) stim[f] + a stim[f + 1], f = tt / q, a = (tt % q) / q (the last frame beyond the end), so
+//   A[i][l][:] = sum_f Wt[i][l][f] stim[f][:],   Wt[i][l][f] = scale_i * sum over the events (t, c) of neuron i of
+//                c ((1 - a) [tt / q == f] + a [tt / q + 1 == f]),  tt = t - l >= 0
+// -- a (nSel L) x Tstim weight matrix from the event lists (this kernel: one thread per cell, the few events that can
+// reach it found by bisection in the neuron's sorted list) and ONE thin GEMM with the raw stimulus (k_gemm_kc) instead of a
+// gather of L x D doubles per spike from the interpolated stimulus: 138 -> 5 ms at 64 neurons x 300 lags x 1024 pixels.
+__global__ __launch_bounds__(256) void k_sta_weights(const int2* __restrict__ spk, const int* __restrict__ eoff,
+                                                     const double* __restrict__ scale, int L, long long Tstim, int q,
+                                                     double* __restrict__ Wt)
+{
+    const int i = blockIdx.z, l = blockIdx.y;
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= Tstim) return;
+    const int e0 = eoff[2 * i], e1 = eoff[2 * i + 1];
+    // events with tt = t - l in [(f - 1) q, (f + 1) q); the last frame also takes everything beyond it
+    const long long lo_t = (f - 1) * (long long)q + l, hi_t = (f + 1 >= Tstim) ? (1ll << 62) : (f + 1) * (long long)q + l;
+    int a = e0, b = e1;
+    while (a < b) {                                       // first event with t >= lo_t (and t >= l)
+        const int m = (a + b) >> 1;
+        if ((long long)spk[m].x < lo_t) a = m + 1; else b = m;
+    }
+    double acc = 0.0;
+    for (int e = a; e < e1; ++e) {
+        const int2 ev = spk[e];
+        if ((long long)ev.x >= hi_t) break;
+        const long long tt = (long long)ev.x - l;
+        if (tt < 0) continue;
+        const long long fr = tt / q;
+        const double al = (double)(tt - fr * q) / (double)q;
+        double w;
+        if (fr >= Tstim - 1) w = (f == Tstim - 1) ? 1.0 : 0.0;       // np.interp holds the last frame
+        else w = (fr == f) ? 1.0 - al : ((fr + 1 == f) ? al : 0.0);
+        acc = fma((double)ev.y, w, acc);
+    }
+    Wt[((size_t)i * L + l) * Tstim + f] = acc * scale[i];
+}
+
 // transpose of the uint8 count matrix: ST[n][t] = S[t][n]
 __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restrict__ ST,
                                long long nT, int N)
