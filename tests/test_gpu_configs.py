@@ -700,6 +700,33 @@ def _map_compare(N, nT, neurons, seed):
     return st
 
 
+def test_map_lockstep_in_groups_when_the_inverse_hessians_do_not_fit():
+    """fit_glms_batched_torch with a memory budget that holds the inverse Hessians of 5 neurons only: the shard is fitted
+    in consecutive groups -- the fits are independent -- with the same per-neuron results as the one-batch fit (same
+    iterates: a neuron's trial steps do not depend on its batch), merged statistics."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    N, nT = 12, 20000
+    rng = np.random.default_rng(321)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn = Population(make_model('standard_glm', N=N, dt=0.001))
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(5))
+    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+    fa, ita, eva = fit_glms_batched_torch(popn, xa)
+    sa = popn.last_fit_stats
+    P = popn.glm.P
+    fb, itb, evb = fit_glms_batched_torch(popn, xb, hessian_bytes=5.5 * 8 * P * (P + (P & 1)))
+    sb = popn.last_fit_stats
+    assert sb['groups'] == 3 and 'groups' not in sa
+    assert np.allclose(fa, fb, rtol=1e-10, atol=0) and abs(ita - itb) <= 1
+    assert sa['converged_gtol'] == sb['converged_gtol'] == N and len(sb['per_neuron']['iterations']) == N
+    assert np.max(np.abs(np.array(sa['per_neuron']['iterations']) - np.array(sb['per_neuron']['iterations']))) <= 1
+    for n in range(N):
+        # (a group is evaluated by a launch of another shape than the whole shard: the gradients differ in the last bits)
+        assert np.allclose(xa['glms'][n]['imp']['w_ir'], xb['glms'][n]['imp']['w_ir'], rtol=1e-5, atol=1e-7)
+    popn.release_data()
+
+
 def test_map_lockstep_matches_sequential_c2():
     """C2 (N=32, T=300 s): every neuron's lock-step optimum equals the sequential scipy fit."""
     st = _map_compare(32, 300000, range(32), 1234 + 2)
