@@ -11,7 +11,7 @@ nbad = 0
 ncmp = {}
 nnf = 0
 for trial in range(40):
-    N = int(rng.choice([3, 9, 17, 30, 33, 48, 64, 80, 128, 130]))
+    N = int(rng.choice([3, 9, 17, 30, 33, 48, 64, 80, 128, 130, 160, 200, 257, 300]))   # (> 128: column slices on resident tiles)
     kind = str(rng.choice(['explinear', 'exp']))
     nT = int(rng.choice([700, 2500, 6000]))
     Dstim = int(rng.choice([0, 0, 3]))

@@ -1,7 +1,7 @@
 """Random shapes for the separable stimulus at the frame rate (the body of tests/test_gpu_population.py::
 test_separable_stimulus_frame_rate_randomised_shapes with a free seed): default path (stimulus current inside the forward
 contraction where it applies) against the slab form (option 94 = 3) and the tap-rate kernels (94 = 2).  Dev tool:
-python3 tools/r4/fuzz_sepf.py [seed] [cases]"""
+python3 tools/fuzz_sepf.py [seed] [cases]"""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
