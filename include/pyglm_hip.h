@@ -165,7 +165,7 @@ int pgl_sync(pgl_handle h);
  *   (M,P) each: X, g, p, H g, s, y, t = H g_new, Xb, gb (best trial of the running search);
  *   (M,P,3) each: U, V (pending H += U V^T);
  *   (M) each: f, fprev, alpha, slope, rho, hscale, iters, restarts, active, frozen, acc, upd, stall, ident, pend, fb,
- *             nfev;  then the line-search state, (18, M).
+ *             nfev, hk (updates in the history);  then the line-search state, (18, M).
  * The dense inverse Hessians d_H (M, P, ld), ld even and >= P, are the caller's buffer (uninitialised is fine).
  *   init:       X, f, g of every row in place -> steepest-descent start, first trial step min(1, 1.01/|g|)
  *   trial:      Xt[j] = X[r] + alpha[r] p[r], r = d_rows[j] (NULL: j), j < L
@@ -188,7 +188,15 @@ int pgl_bfgs_objective_dev(pgl_handle h, int L, int P, const double* d_Xt, doubl
 int pgl_bfgs_linesearch_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
                             const double* d_f, const double* d_g, int max_trials);
 int pgl_bfgs_hmul_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_H, int ld);
-int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling);
+/* hmul with the inverse Hessians kept implicit: H = hscale I + sum_j U_j V_j^T over the update history that
+ * pgl_bfgs_update_dev appends to -- d_hist [M][Kmax][2][P] (s_j, H y_j), d_coef [M][Kmax][2] -- Kmax >= maxiter;
+ * d_ab: scratch [M][Kmax][2].  Reads 4 hk P numbers per row instead of 2 P^2: the cheaper form whenever 3 maxiter <= P,
+ * and no P^2 memory. */
+int pgl_bfgs_hmul_hist_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_hist,
+                           const double* d_coef, int Kmax, double* d_ab);
+/* d_hist / d_coef NULL: dense form (pgl_bfgs_hmul_dev) */
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling, double* d_hist,
+                        double* d_coef, int Kmax);
 
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
  * fS_out (nT,N,B) row-major, float64. */

@@ -727,6 +727,61 @@ def test_map_lockstep_in_groups_when_the_inverse_hessians_do_not_fit():
     popn.release_data()
 
 
+def test_map_lockstep_implicit_inverse_hessian_equals_dense():
+    """The two forms of the inverse Hessian -- the dense matrices updated in place, and the history of rank-3 factors
+    applied to the gradient (hessian='implicit': what the wide problems use, 3 maxiter <= P) -- are the same algebra:
+    same iterates up to rounding (the sums run in another order), same iteration and evaluation counts, on a
+    standard_glm shard and on a spatiotemporal one whose default form is the implicit one."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    N, nT = 12, 20000
+    rng = np.random.default_rng(322)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn = Population(make_model('standard_glm', N=N, dt=0.001))
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(6))
+    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+    fa, ita, eva = fit_glms_batched_torch(popn, xa, hessian='dense')
+    sa = popn.last_fit_stats
+    fb, itb, evb = fit_glms_batched_torch(popn, xb, hessian='implicit')
+    sb = popn.last_fit_stats
+    assert sa['inverse_hessian'] == 'dense' and sb['inverse_hessian'] == 'implicit'
+    assert np.allclose(fa, fb, rtol=1e-10, atol=0)
+    assert sa['converged_gtol'] == sb['converged_gtol'] == N
+    assert np.max(np.abs(np.array(sa['per_neuron']['iterations']) - np.array(sb['per_neuron']['iterations']))) <= 1
+    for n in range(N):
+        assert np.allclose(xa['glms'][n]['imp']['w_ir'], xb['glms'][n]['imp']['w_ir'], rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        fit_glms_batched_torch(popn, copy.deepcopy(x0), hessian='lbfgs')
+    popn.release_data()
+
+    # 400 pixels (identity spatial basis): P = 1 + 3 + 400 + 3 * 8 > 3 * 40
+    from theano_pyglm_amd.models import templates
+    N, T, D = 8, 20.0, 400
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = D
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
+    popn = Population(make_model(tmpl, N=N, dt=0.001))
+    nT = int(T / 0.001)
+    rng = np.random.default_rng(9)
+    stim = rng.standard_normal((int(T / 0.1), D))
+    S = np.minimum(rng.poisson(25.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': T, 'stim': stim, 'dt_stim': 0.1})
+    assert popn.glm.P == 1 + 3 + D + 3 * N
+    x0 = popn.sample(np.random.RandomState(2))
+    for g in x0['glms']:
+        g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
+    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+    fa, _, _ = fit_glms_batched_torch(popn, xa, maxiter=40, hessian='dense')
+    sa = popn.last_fit_stats
+    fb, _, _ = fit_glms_batched_torch(popn, xb, maxiter=40)
+    sb = popn.last_fit_stats
+    assert sb['inverse_hessian'] == 'implicit'
+    assert np.allclose(fa, fb, rtol=1e-9, atol=0), np.max(np.abs(fa - fb) / np.abs(fa))
+    assert sa['per_neuron']['iterations'] == sb['per_neuron']['iterations']
+    assert sa['line_search_steps'] == sb['line_search_steps']
+    popn.release_data()
+
+
 def test_map_lockstep_matches_sequential_c2():
     """C2 (N=32, T=300 s): every neuron's lock-step optimum equals the sequential scipy fit."""
     st = _map_compare(32, 300000, range(32), 1234 + 2)

@@ -32,7 +32,7 @@ SYMBOLS = [
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
     'pgl_bfgs_state_doubles', 'pgl_bfgs_init_dev', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
-    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_update_dev', 'pgl_plan_kernels',
+    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_hmul_hist_dev', 'pgl_bfgs_update_dev', 'pgl_plan_kernels',
 ]
 
 
@@ -124,7 +124,8 @@ def load():
         lib.pgl_bfgs_objective_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int] + [C.c_double] * 6
         lib.pgl_bfgs_linesearch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int]
         lib.pgl_bfgs_hmul_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
-        lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, C.c_int]
+        lib.pgl_bfgs_hmul_hist_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.pgl_features.argtypes = [vp, vp]
     lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
     lib.pgl_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
@@ -354,9 +355,15 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_bfgs_hmul_dev(self.h, C.c_void_p(d_state), int(M), int(P),
                                         C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_H), int(ld)))
 
-    def bfgs_update_dev(self, d_state, M, P, gtol, maxiter, init_scaling=False):
+    def bfgs_hmul_hist_dev(self, d_state, M, P, d_rows, L, d_hist, d_coef, Kmax, d_ab):
+        _chk(self.lib.pgl_bfgs_hmul_hist_dev(self.h, C.c_void_p(d_state), int(M), int(P),
+                                             C.c_void_p(d_rows) if d_rows else None, int(L), C.c_void_p(d_hist),
+                                             C.c_void_p(d_coef), int(Kmax), C.c_void_p(d_ab)))
+
+    def bfgs_update_dev(self, d_state, M, P, gtol, maxiter, init_scaling=False, d_hist=0, d_coef=0, Kmax=0):
         _chk(self.lib.pgl_bfgs_update_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol), int(maxiter),
-                                          1 if init_scaling else 0))
+                                          1 if init_scaling else 0, C.c_void_p(d_hist) if d_hist else None,
+                                          C.c_void_p(d_coef) if d_coef else None, int(Kmax)))
 
     def sync(self):
         _chk(self.lib.pgl_sync(self.h))

@@ -2163,12 +2163,31 @@ int pgl_bfgs_hmul_dev(pgl_handle h, double* d_state, int M, int P, const int* d_
     return PGL_OK;
 }
 
-int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling)
+int pgl_bfgs_hmul_hist_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_hist,
+                           const double* d_coef, int Kmax, double* d_ab)
+{
+    if (!h || !d_state || !d_hist || !d_coef || !d_ab || M <= 0 || P <= 0 || L <= 0 || L > M || Kmax <= 0)
+        return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    const BfgsView v = pgl_bfgs_view(d_state, M, P);
+    hipLaunchKernelGGL(k_bfgs_hdots, dim3((unsigned)((Kmax + 3) / 4), (unsigned)L), dim3(256), 0, h->stream, v, d_rows, d_hist,
+                       d_coef, Kmax, d_ab);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_bfgs_hcomb, dim3((unsigned)((P + 63) / 64), (unsigned)L), dim3(512), 0, h->stream, v, d_rows, d_hist, Kmax,
+                       (const double*)d_ab);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling, double* d_hist,
+                        double* d_coef, int Kmax)
 {
     if (!h || !d_state || M <= 0 || P <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if ((d_hist != nullptr) != (d_coef != nullptr) || (d_hist && Kmax < maxiter))
+        return fail(PGL_ERR_ARG, "history buffers: both or none, room for maxiter updates");
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_bfgs_update, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol, maxiter,
-                       init_scaling);
+                       init_scaling, d_hist, d_coef, Kmax);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }

@@ -5224,11 +5224,11 @@ struct BfgsView {
     double *X, *g, *p, *Hg, *s, *y, *t, *Xb, *gb;    // (M, P)
     double *U, *V;                                   // (M, P, 3): H += U V^T is the BFGS update
     double *f, *fprev, *alpha, *slope, *rho, *hscale, *iters, *restarts, *active, *frozen, *acc, *upd, *stall, *ident,
-           *pend, *fb, *nfev;                        // (M)
+           *pend, *fb, *nfev, *hk;                   // (M)
     double* ls;                                      // (PGL_LS_NDOUBLES, M): line-search state, field-major
 };
 #define PGL_BFGS_NVEC 9
-#define PGL_BFGS_NSCAL 17
+#define PGL_BFGS_NSCAL 18
 #define PGL_LS_FTOL 1e-4
 #define PGL_LS_GTOL 0.9
 #define PGL_LS_XTOL 1e-14
@@ -5249,7 +5249,7 @@ __host__ __device__ inline BfgsView pgl_bfgs_view(double* st, int M, int P)
     v.f = q; v.fprev = q + M; v.alpha = q + 2 * M; v.slope = q + 3 * M; v.rho = q + 4 * M; v.hscale = q + 5 * M;
     v.iters = q + 6 * M; v.restarts = q + 7 * M; v.active = q + 8 * M; v.frozen = q + 9 * M; v.acc = q + 10 * M;
     v.upd = q + 11 * M; v.stall = q + 12 * M; v.ident = q + 13 * M; v.pend = q + 14 * M; v.fb = q + 15 * M;
-    v.nfev = q + 16 * M;
+    v.nfev = q + 16 * M; v.hk = q + 17 * M;
     v.ls = q + (size_t)PGL_BFGS_NSCAL * M;
     return v;
 }
@@ -5307,7 +5307,7 @@ __global__ __launch_bounds__(256) void k_bfgs_init(const BfgsView v, const doubl
         const double f = v.f[r], fprev = f + sqrt(gg) / 2.0, slope = -gg;
         v.fprev[r] = fprev; v.slope[r] = slope; v.rho[r] = 0.0; v.hscale[r] = 1.0; v.iters[r] = 0.0; v.restarts[r] = 0.0;
         v.frozen[r] = 0.0; v.acc[r] = 0.0; v.upd[r] = 0.0; v.stall[r] = 0.0; v.ident[r] = 1.0; v.pend[r] = 0.0;
-        v.fb[r] = f; v.nfev[r] = 0.0;
+        v.fb[r] = f; v.nfev[r] = 0.0; v.hk[r] = 0.0;
         v.active[r] = gmax > gtol ? 1.0 : 0.0;
         PglLs s;
         const double a0 = pgl_ls_first_step(f, fprev, slope);
@@ -5548,12 +5548,97 @@ __global__ __launch_bounds__(256) void k_bfgs_hmul(const BfgsView v, const int* 
     }
 }
 
+// The same product with the inverse Hessian kept IMPLICIT: H = hscale I + sum_{j < hk} U_j V_j^T over every update so far.
+// The rank-3 factors share two vectors -- U_j = (c0 s, -rho Hy, -rho s), V_j = (s, s, Hy) -- so the history holds (s_j, Hy_j)
+// [row][j][2][P] and (c0_j, rho_j) [row][j][2] (k_bfgs_update appends them), and
+//   U_j V_j^T g = (c0 a - rho b) s_j + (-rho a) Hy_j,   a = s_j . g,  b = Hy_j . g.
+// 4 hk P numbers per row and product instead of the 2 P^2 of the dense form -- less traffic as long as hk <= P / 2 (the
+// driver picks this form when 3 maxiter <= P: at the C5 stress shape, P = 1220, the fit's 225 iterations read 5 x less on
+// average), and no P^2 memory (wide populations).  Two kernels:
+//   k_bfgs_hdots: ab[row][j] = the two coefficients, one wave per (row, j), fixed-order wave reduction;
+//   k_bfgs_hcomb: t = hscale g + sum_j ab[j][0] s_j + ab[j][1] Hy_j for 64 components per block; wave w of 8 takes
+//                 j = w, w + 8, ..., the eight partial sums are added in wave order.
+__global__ __launch_bounds__(256) void k_bfgs_hdots(const BfgsView v, const int* __restrict__ rows,
+                                                    const double* __restrict__ Wh, const double* __restrict__ cs, const int Kmax,
+                                                    double* __restrict__ ab)
+{
+    const int jr = blockIdx.y, r = rows ? rows[jr] : jr;
+    if (v.acc[r] == 0.0) return;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6), P = v.P;
+    if (j >= (int)v.hk[r]) return;
+    const double* __restrict__ g = v.g + (size_t)r * P;
+    const double* __restrict__ W = Wh + ((size_t)r * Kmax + j) * 2 * P;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int i = lane;
+    for (; i + 64 < P; i += 128) {
+        const double g0 = g[i], g1 = g[i + 64];
+        const double s0 = W[i], s1 = W[i + 64], h0 = W[P + i], h1 = W[P + i + 64];
+        a0 = fma(s0, g0, a0);
+        a1 = fma(s1, g1, a1);
+        b0 = fma(h0, g0, b0);
+        b1 = fma(h1, g1, b1);
+    }
+    if (i < P) {
+        a0 = fma(W[i], g[i], a0);
+        b0 = fma(W[P + i], g[i], b0);
+    }
+    double a = a0 + a1, b = b0 + b1;
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0) {
+        const size_t q = ((size_t)r * Kmax + j) * 2;
+        const double c0 = cs[q], rho = cs[q + 1];
+        ab[q] = c0 * a - rho * b;
+        ab[q + 1] = -rho * a;
+    }
+}
+__global__ __launch_bounds__(512) void k_bfgs_hcomb(const BfgsView v, const int* __restrict__ rows,
+                                                    const double* __restrict__ Wh, const int Kmax, const double* __restrict__ ab)
+{
+    __shared__ double part[8][64];
+    const int jr = blockIdx.y, r = rows ? rows[jr] : jr;
+    if (v.acc[r] == 0.0) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, P = v.P, K = (int)v.hk[r];
+    if (K == 0) return;                                      // (no history: k_bfgs_update uses t = hscale g)
+    const int i = blockIdx.x * 64 + lane;
+    const bool in = i < P;
+    const double* __restrict__ W = Wh + (size_t)r * Kmax * 2 * P + (in ? i : 0);
+    const double* __restrict__ c = ab + (size_t)r * Kmax * 2;
+    double acc0 = 0.0, acc1 = 0.0;
+    int j = w;
+    for (; j + 8 < K; j += 16) {
+        const double* u0 = W + (size_t)j * 2 * P;
+        const double* u1 = W + (size_t)(j + 8) * 2 * P;
+        const double s0 = u0[0], h0 = u0[P], s1 = u1[0], h1 = u1[P];
+        acc0 = fma(s0, c[2 * j], acc0);
+        acc0 = fma(h0, c[2 * j + 1], acc0);
+        acc1 = fma(s1, c[2 * j + 16], acc1);
+        acc1 = fma(h1, c[2 * j + 17], acc1);
+    }
+    if (j < K) {
+        const double* u0 = W + (size_t)j * 2 * P;
+        acc0 = fma(u0[0], c[2 * j], acc0);
+        acc0 = fma(u0[P], c[2 * j + 1], acc0);
+    }
+    part[w][lane] = acc0 + acc1;
+    __syncthreads();
+    if (w == 0 && in) {
+        double t = v.hscale[r] * v.g[(size_t)r * P + i];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][lane];
+        v.t[(size_t)r * P + i] = t;
+    }
+}
+
 // After the line-search step (and t = H g_new for the rows that moved): the rank-3 factors of the inverse-Hessian
 // update  H_new = (I - rho s y^T) H (I - rho y s^T) + rho s s^T = H + U V^T,  H_new g_new, the next direction and the
 // start of its line search, restart / freeze of stalled rows, convergence flags.  init_scaling != 0: the first update
 // after a (re)start is preceded by H <- (s.y / y.y) I (Nocedal & Wright (6.20); not scipy's behaviour).
 __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const double gtol, const int maxiter,
-                                                     const int init_scaling)
+                                                     const int init_scaling, double* __restrict__ Wh = nullptr,
+                                                     double* __restrict__ cs = nullptr, const int Kmax = 0)
 {
     __shared__ double red[4];
     const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
@@ -5565,9 +5650,9 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
     bool ident = v.ident[r] != 0.0, pend = v.pend[r] != 0.0;
     double hs = v.hscale[r];
     double restarts = v.restarts[r], iters = v.iters[r];
-    bool frozen = false, again = false;
+    bool frozen = false, again = false, hist_add = false;
     if (a) {
-        const bool lazy = ident && !pend;                    // H = hs * I: k_bfgs_hmul left t alone
+        const bool lazy = ident && !pend;                    // H = hs * I: k_bfgs_hmul / k_bfgs_hcomb left t alone
         iters += 1.0;
         restarts = 0.0;
         if (u) {
@@ -5596,12 +5681,24 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
                 const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
                 const double s = v.s[o + c], Hy = tc - sc * v.Hg[o + c];
                 const double u0 = c0 * s, u1 = -rho * Hy, u2 = -rho * s;
-                U[3 * c] = u0; U[3 * c + 1] = u1; U[3 * c + 2] = u2;
-                V[3 * c] = s; V[3 * c + 1] = s; V[3 * c + 2] = Hy;
                 v.Hg[o + c] = tc + (u0 * vg0 + u1 * vg0 + u2 * vg2);          // H_new g_new
+                if (Wh) {                                    // implicit form: the update joins the history
+                    const size_t hq = ((size_t)r * Kmax + (size_t)v.hk[r]) * 2 * P + c;
+                    Wh[hq] = s;
+                    Wh[hq + P] = Hy;
+                } else {
+                    U[3 * c] = u0; U[3 * c + 1] = u1; U[3 * c + 2] = u2;
+                    V[3 * c] = s; V[3 * c + 1] = s; V[3 * c + 2] = Hy;
+                }
             }
-            ident = lazy;                                    // still not materialised: hs * I + U V^T at the next pass
-            pend = true;
+            if (Wh && tid == 0) {
+                const size_t cq = ((size_t)r * Kmax + (size_t)v.hk[r]) * 2;
+                cs[cq] = c0;
+                cs[cq + 1] = rho;
+            }
+            ident = Wh ? false : lazy;                       // dense: still not materialised -- hs * I + U V^T at the next pass
+            pend = Wh ? false : true;
+            hist_add = Wh != nullptr;
         } else {
             for (int c = tid; c < P; c += 256) v.Hg[o + c] = lazy ? hs * v.g[o + c] : v.t[o + c];
             ident = lazy;
@@ -5636,6 +5733,7 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
         v.restarts[r] = restarts;
         if (frozen) v.frozen[r] = 1.0;
         if (reset) { ident = true; pend = false; hs = 1.0; }
+        v.hk[r] = reset ? 0.0 : v.hk[r] + (hist_add ? 1.0 : 0.0);
         v.ident[r] = ident ? 1.0 : 0.0;
         v.pend[r] = pend ? 1.0 : 0.0;
         v.hscale[r] = hs;

@@ -200,12 +200,16 @@ class _Packing(object):
 
 
 def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=None, verbose=False,
-                           reduce=None, lag=None, init_scaling=False, max_trials=100, hessian_bytes=None):
+                           reduce=None, lag=None, init_scaling=False, max_trials=100, hessian_bytes=None, hessian=None):
     """In-place MAP fit of x['glms'][n_lo:n_hi]; returns (nlp (M,), iterations, evaluations).
 
     The dense inverse Hessians take M * P^2 doubles (C3: 0.4 GB; 512 neurons of a standard_glm: 27 GB; 2 048: 1.7 TB).
     When they would exceed `hessian_bytes` (default: 40 % of the free device memory) the shard is fitted in consecutive
     groups of neurons that fit -- the fits are independent, so the result is the same -- and the statistics are merged.
+
+    `hessian`: 'dense' (M, P, P) matrices, one read-modify-write pass per accepted iteration; 'implicit' the history of
+    update vectors, 4 k P numbers per product after k updates; None: implicit when that is never more than the dense
+    pass (3 maxiter <= P: the C5 stress shape, wide populations), else dense.
 
     Everything runs on one dedicated torch stream that the device handles are switched to
     (pgl_set_stream): trial points, the fused ll+grad launches, priors, the line-search steps and the
@@ -241,7 +245,11 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     dev = torch.device('cuda', population.device)
     # groups of neurons whose inverse Hessians fit the memory budget
     Pp = _Packing(population, torch).Pp
-    per_neuron = 8.0 * Pp * (Pp + (Pp & 1))
+    if hessian is None:
+        hessian = 'implicit' if 3 * maxiter <= Pp else 'dense'
+    if hessian not in ('dense', 'implicit'):
+        raise ValueError("hessian: 'dense', 'implicit' or None")
+    per_neuron = 8.0 * Pp * (Pp + (Pp & 1)) if hessian == 'dense' else 8.0 * (2.0 * Pp + 4.0) * maxiter
     if hessian_bytes is None:
         hessian_bytes = 0.4 * torch.cuda.mem_get_info(dev)[0]
     group = M if hessian_bytes >= per_neuron * M else max(1, int(hessian_bytes / per_neuron))
@@ -250,7 +258,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
         for lo in range(n_lo, n_hi, group):
             hi = min(n_hi, lo + group)
             f_, it_, ev_ = fit_glms_batched_torch(population, x, maxiter, gtol, lo, hi, verbose, reduce, lag, init_scaling,
-                                                  max_trials, hessian_bytes=float('inf'))
+                                                  max_trials, hessian_bytes=float('inf'), hessian=hessian)
             nlps.append(f_)
             its, evs = max(its, it_), evs + ev_
             st = population.last_fit_stats
@@ -277,7 +285,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     try:
         with torch.cuda.stream(stream):
             out = _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M,
-                                 verbose, reduce, 1 if lag is None else max(0, int(lag)), init_scaling, max_trials)
+                                 verbose, reduce, 1 if lag is None else max(0, int(lag)), init_scaling, max_trials, hessian)
             stream.synchronize()
     finally:
         # also on the error path: kernels still queued on `stream` read the optimizer state and the handles' scratch;
@@ -292,7 +300,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
 
 
 def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce,
-                   lag, init_scaling, max_trials):
+                   lag, init_scaling, max_trials, hessian='dense'):
     pk = _Packing(population, torch, handles, (n_lo, n_hi))
     h0 = handles[0]
     P = pk.Pp                                                 # length of an optimisation row
@@ -304,8 +312,16 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
     X, g = st[0:MP].view(M, P), st[MP:2 * MP].view(M, P)
     sc = st[15 * MP:].view(-1, M)
     f, iters, active, frozen, nfev = sc[0], sc[6], sc[8], sc[9], sc[16]
-    # dense inverse Hessians: touched by pgl_bfgs_hmul_dev only, written before they are read
-    H = torch.empty((M, P, ld), dtype=torch.float64, device=dev)
+    if hessian == 'dense':
+        # dense inverse Hessians: touched by pgl_bfgs_hmul_dev only, written before they are read
+        H = torch.empty((M, P, ld), dtype=torch.float64, device=dev)
+        hist = coef = cb = None
+    else:
+        # the update history (s_j, H y_j) [M][maxiter][2][P] and its scalars (written by pgl_bfgs_update_dev before read)
+        H = None
+        hist = torch.empty((M, maxiter, 2, P), dtype=torch.float64, device=dev)
+        coef = torch.empty((M, maxiter, 2), dtype=torch.float64, device=dev)
+        cb = torch.empty((M, maxiter, 2), dtype=torch.float64, device=dev)
     X.copy_(torch.tensor(pk.pack(x, n_lo, n_hi), dtype=torch.float64, device=dev))
     Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
     prm = pk.prior_params() if pk.identity else None
@@ -387,8 +403,12 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
         h0.bfgs_trial_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr())
         ft, gt = evaluate(Xt, rows32, idx32, L)
         h0.bfgs_linesearch_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr(), ft.data_ptr(), gt.data_ptr(), max_trials)
-        h0.bfgs_hmul_dev(st.data_ptr(), M, P, rp, L, H.data_ptr(), ld)       # rows that moved: H += U V^T, t = H g
-        h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling)
+        if H is not None:
+            h0.bfgs_hmul_dev(st.data_ptr(), M, P, rp, L, H.data_ptr(), ld)   # rows that moved: H += U V^T, t = H g
+            h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling)
+        else:
+            h0.bfgs_hmul_hist_dev(st.data_ptr(), M, P, rp, L, hist.data_ptr(), coef.data_ptr(), maxiter, cb.data_ptr())
+            h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling, hist.data_ptr(), coef.data_ptr(), maxiter)
         publish(launches)
     it = int(iters.max())
     gmax = g.abs().amax(1)
@@ -403,7 +423,7 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
                                  'maxiter': M - n_conv - n_frozen,
                                  'bookkeeping': 'hip row kernels' + ('' if pk.identity else ' (priors / chain rule: torch)'),
                                  'line_search': "More'-Thuente strong Wolfe (scipy's DCSRCH constants)",
-                                 'lag': lag, 'init_scaling': bool(init_scaling),
+                                 'lag': lag, 'init_scaling': bool(init_scaling), 'inverse_hessian': hessian,
                                  'per_neuron': {'iterations': [int(v) for v in iters.cpu().numpy()],
                                                 'line_search_steps': [int(v) for v in nfev.cpu().numpy()]}}
     return f.cpu().numpy(), it, n_evals[0]
