@@ -190,7 +190,7 @@ int pgl_bfgs_linesearch_dev(pgl_handle h, double* d_state, int M, int P, const i
 int pgl_bfgs_hmul_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, double* d_H, int ld);
 /* hmul with the inverse Hessians kept implicit: H = hscale I + sum_j U_j V_j^T over the update history that
  * pgl_bfgs_update_dev appends to -- d_hist [M][Kmax][2][P] (s_j, H y_j), d_coef [M][Kmax][2] -- Kmax >= maxiter;
- * d_ab: scratch [M][Kmax][2].  Reads 4 hk P numbers per row instead of 2 P^2: the cheaper form whenever 3 maxiter <= P,
+ * d_ab: scratch [M][Kmax][2].  Reads 4 hk P numbers per row instead of 2 P^2: the cheaper form while hk <= P / 2,
  * and no P^2 memory. */
 int pgl_bfgs_hmul_hist_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_hist,
                            const double* d_coef, int Kmax, double* d_ab);

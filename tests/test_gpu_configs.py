@@ -729,7 +729,7 @@ def test_map_lockstep_in_groups_when_the_inverse_hessians_do_not_fit():
 
 def test_map_lockstep_implicit_inverse_hessian_equals_dense():
     """The two forms of the inverse Hessian -- the dense matrices updated in place, and the history of rank-3 factors
-    applied to the gradient (hessian='implicit': what the wide problems use, 3 maxiter <= P) -- are the same algebra:
+    applied to the gradient (hessian='implicit': the default unless maxiter > 2 P) -- are the same algebra:
     same iterates up to rounding (the sums run in another order), same iteration and evaluation counts, on a
     standard_glm shard and on a spatiotemporal one whose default form is the implicit one."""
     from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
@@ -754,7 +754,7 @@ def test_map_lockstep_implicit_inverse_hessian_equals_dense():
         fit_glms_batched_torch(popn, copy.deepcopy(x0), hessian='lbfgs')
     popn.release_data()
 
-    # 400 pixels (identity spatial basis): P = 1 + 3 + 400 + 3 * 8 > 3 * 40
+    # 400 pixels (identity spatial basis): P = 1 + 3 + 400 + 3 * 8
     from theano_pyglm_amd.models import templates
     N, T, D = 8, 20.0, 400
     tmpl = templates.spatiotemporal_glm()

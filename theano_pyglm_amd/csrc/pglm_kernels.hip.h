@@ -5552,9 +5552,9 @@ __global__ __launch_bounds__(256) void k_bfgs_hmul(const BfgsView v, const int* 
 // The rank-3 factors share two vectors -- U_j = (c0 s, -rho Hy, -rho s), V_j = (s, s, Hy) -- so the history holds (s_j, Hy_j)
 // [row][j][2][P] and (c0_j, rho_j) [row][j][2] (k_bfgs_update appends them), and
 //   U_j V_j^T g = (c0 a - rho b) s_j + (-rho a) Hy_j,   a = s_j . g,  b = Hy_j . g.
-// 4 hk P numbers per row and product instead of the 2 P^2 of the dense form -- less traffic as long as hk <= P / 2 (the
-// driver picks this form when 3 maxiter <= P: at the C5 stress shape, P = 1220, the fit's 225 iterations read 5 x less on
-// average), and no P^2 memory (wide populations).  Two kernels:
+// 4 hk P numbers per row and product instead of the 2 P^2 of the dense form -- less traffic while hk <= P / 2, which is
+// where fits live (C3 converges in 22 iterations; at the C5 stress shape, P = 1220, all 225 iterations read 5 x less on
+// average), and no P^2 memory (wide populations).  The driver's default.  Two kernels:
 //   k_bfgs_hdots: ab[row][j] = the two coefficients, one wave per (row, j), fixed-order wave reduction;
 //   k_bfgs_hcomb: t = hscale g + sum_j ab[j][0] s_j + ab[j][1] Hy_j for 64 components per block; wave w of 8 takes
 //                 j = w, w + 8, ..., the eight partial sums are added in wave order.
