@@ -151,10 +151,14 @@ def map_wall_clock(S, N, dt):
             "line_search_steps": stats.get('line_search_steps'), "neuron_iterations": stats.get('neuron_iterations'),
             "optimizer": "lock-step batched BFGS = scipy's algorithm for every neuron at once (H0 = I, More'-Thuente "
                          "strong-Wolfe search with scipy's constants and first trial step; one fused ll+grad launch per pending "
-                         "trial step of the listed neurons; bookkeeping: %s, one read-modify-write pass over the dense inverse "
-                         "Hessians per accepted iteration; active set read back %s launch(es) late: no host sync per launch), "
+                         "trial step of the listed neurons; bookkeeping: %s, inverse Hessians %s; active set read back %s "
+                         "launch(es) late: no host sync per launch), "
                          "initial inverse-Hessian scaling %s, maxiter 225, gtol 1e-5, GPU-resident state on one stream"
-                         % (stats.get('bookkeeping', 'n/a'), stats.get('lag', 'n/a'),
+                         % (stats.get('bookkeeping', 'n/a'),
+                            {'implicit': "implicit (the history of update vectors applied to the gradient, 4 k P numbers per "
+                                         "product after k updates)",
+                             'dense': "dense (one read-modify-write pass of 2 P^2 numbers per accepted iteration)"}
+                            .get(stats.get('inverse_hessian'), 'n/a'), stats.get('lag', 'n/a'),
                             's.y/y.y' if stats.get('init_scaling') else 'none (identity)')}
 
 
