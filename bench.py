@@ -330,9 +330,10 @@ def _stim_record(v):
             "identity spatial basis Bx=1024, Bt=3, dt_stim=0.1 s, N=64, T=300 s (nT=300000), exp nonlinearity",
             "value": ms, "unit": "ms per ll+grad (queued back to back, whole evaluation)", "evals_per_s": 1e3 / ms,
             "stim_path": int(info['stim_path']), "kernel_version": int(info['kernel_version']),
-            "path": "k_gemm_kc (z = stim.w_x at the frame rate) + k_fused7<12,4,2> (impulse columns on resident tiles; the "
-                    "stimulus current as five more k-steps of the forward contraction; residuals out) + k_sepf_bwd + "
-                    "k_sepf_finish + k_gemm_kc + k_finalize",
+            "path": "k_gemm_kc (z = stim.w_x at the frame rate) + k_fused7<12,4,3> (impulse columns on resident tiles; the "
+                    "stimulus current as five more k-steps of the forward contraction, its backward as eight more MFMAs "
+                    "per tile on the residuals in registers) + k_sepf_finish_d + k_gemm_kc + k_finalize",
+            "map_sweep": "coord_descent(maxiter=1) as the reference runs it: STA warm start, then all 64 BFGS fits in lock step",
             "tap_rate_kernels_ms": ms_tap,
             "max_rel_ll_diff_vs_tap_rate": float(np.max(np.abs(ll - ll_tap) / np.abs(ll_tap))),
             "impulse_contraction_flops": flops_imp,
