@@ -861,3 +861,52 @@ def test_wide_population_on_resident_tiles():
     llo, go = p.oracle_ll_grad(0, 2)
     assert np.allclose(ll[:2], llo, rtol=LL_RTOL) and H.rel_err(g[:2], go) < G_RTOL
     d.close()
+
+
+def test_narrow_shard_block_ring_kernel():
+    """One post tile (a shard of <= 16 neurons: north star's neuron split of C3 at 8 GPUs) against a feature row of 25 .. 40
+    k-tiles: k_fused8 -- K split over eight waves, every wave streaming its own slice of block-form images through a private
+    LDS ring.  Against the in-kernel-feature K-split path (PGL_OPT_KERNEL = 2) to 1e-12 and the oracle: neuron ranges of 16,
+    9 and 1 neurons (padding lanes), a neuron list, a time range off the tile grid (the masked epilogue, short chunks), ll
+    only, an exp nonlinearity, low rates (the general regime of the epilogue) and rows of 25, 32 and 40 k-tiles."""
+    import torch
+    from theano_pyglm_amd import _lib
+    for N, nT, nlin, bias in ((128, 5000, 'explinear', 20.0), (100, 3000, 'exp', -3.0), (80, 2000, 'explinear', -1.0),
+                              (128, 333, 'explinear', 5.0)):
+        p = H.Problem(N, nT, H.std_ibasis(), kind=nlin, seed=N + nT, w_scale=0.3 if nlin == 'explinear' else 0.02,
+                      bias_mu=bias, weighted=(N == 100))
+        d = p.device()
+        d2 = p.device()
+        d2.set_option(_lib.OPT_KERNEL, 2)
+        for lo, hi in ((32, 48), (N - 9, N), (5, 6)):
+            names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], nT=nT, n_lo=lo, count=hi - lo)
+            assert names == ['k_fused8<5, 8>'], names
+            assert d.info(lo, hi)['kernel_version'] == 6 and d2.info(lo, hi)['kernel_version'] == 2
+            ll, g = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+            ll2, g2 = d2.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+            assert np.allclose(ll, ll2, rtol=1e-12) and H.rel_err(g, g2) < 1e-11, (N, lo, hi)
+            llo, go = p.oracle_ll_grad(lo, min(hi, lo + 2))
+            assert np.allclose(ll[:len(llo)], llo, rtol=LL_RTOL) and H.rel_err(g[:len(llo)], go) < G_RTOL
+            ll_only, _ = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi, want_grad=False)
+            assert np.array_equal(ll_only, ll)
+        # a list of 16 neurons in arbitrary order
+        idx = np.random.RandomState(N).permutation(N)[:16].astype(np.int32)
+        d_idx = torch.from_numpy(idx).cuda()
+        d_th = torch.from_numpy(np.ascontiguousarray(p.theta[idx])).cuda()
+        d_W = torch.from_numpy(np.ascontiguousarray(p.Weff)).cuda()
+        d_ll = torch.zeros(len(idx), dtype=torch.float64, device='cuda')
+        d_g = torch.zeros((len(idx), p.P), dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        d.ll_grad_list_dev(d_idx.data_ptr(), len(idx), d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+        d.sync()
+        llf, gf = d2.ll_grad(p.theta, p.Weff)
+        assert np.allclose(d_ll.cpu().numpy(), llf[idx], rtol=1e-12) and H.rel_err(d_g.cpu().numpy(), gf[idx]) < 1e-11
+        # a time range off the tile grid
+        t0, t1 = 32, nT - 37
+        d.set_time_range(t0, t1)
+        d2.set_time_range(t0, t1)
+        llt, gt = d.ll_grad(p.theta[32:48], p.Weff, 32, 48)
+        llt2, gt2 = d2.ll_grad(p.theta[32:48], p.Weff, 32, 48)
+        assert np.allclose(llt, llt2, rtol=1e-12) and H.rel_err(gt, gt2) < 1e-11
+        d.close()
+        d2.close()

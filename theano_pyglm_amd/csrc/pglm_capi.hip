@@ -150,7 +150,8 @@ struct Plan {
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
     int mt;                             // version 6: 16-bin tiles per step
     int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
-    int sb6 = 0;                        // version 6: one image buffer per workgroup (k_fused6 DB = 0)
+    int sb6 = 0;                        // version 6: 1 = one image buffer per workgroup (k_fused6 DB = 0), 2 = per-wave block
+                                        // rings on block-form images (k_fused8)
     int nw7, wg7;                       // version 7: waves per workgroup (1, 2, 4), workgroups per CU
     size_t lds7x = 0;                   // version 7: extra LDS of the separable-stimulus forms
     size_t lds;
@@ -207,6 +208,11 @@ static bool pick_pair(int need, int& ktl, int& kth)
     return false;
 }
 static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(ktl) + pgl_img_bytes(kth); }
+// one-part images (k_fused6 / 7), padded rows or the block form of k_fused8: slot key and bytes per tile
+static int img_key6(int kt, bool blk) { return (blk ? 0x8000 : 0) | kt << 8; }
+static size_t img_bytes6(int kt, bool blk) { return blk ? (size_t)kt * 2048 : (size_t)pgl_img_bytes(kt); }
+static constexpr int kRing8 = 8;            // k_fused8<5, kRing8>: blocks per wave
+static size_t lds_fused8(int ring) { return (size_t)8 * ring * 2048 + (size_t)(8 * 256 + 256 + 32 + 8 * 48) * 8; }
 
 static int fused6_wg_per_cu(const Plan& pl);
 
@@ -330,22 +336,24 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             }
             pl.sb6 = 0;
             if (mt6 == 0 && pl.nPT <= 2 && h->opt_sb6 != 2) {
-                // the row does not fit twice (K = 640: 81 KB per tile): 8-wave form with ONE image buffer, the only
-                // instantiations being <5,1> (one post tile, K split 8 ways) and <10,2> (two post tiles, 4 ways)
+                // the row does not fit twice (K = 640: 81 KB per tile): two post tiles -> 8-wave form with ONE image buffer
+                // (<10,2>: 4-way K split); one post tile -> 8-way K split with a private block ring per wave (k_fused8<5, 8>)
                 nw6 = 8; ptw6 = pl.nPT;
                 const int needw8 = (need + 8 / ptw6 - 1) / (8 / ptw6);
                 ktw6 = (ptw6 == 1) ? 5 : 10;
                 const size_t lds1 = (size_t)pgl_img_bytes(ktw6 * (8 / ptw6)) + (size_t)8 * 2048 + 256 + (size_t)8 * 384;
                 if (needw8 <= ktw6 && needw8 > ktw6 / 2 && lds1 <= 160 * 1024) {
                     mt6 = 1;
-                    pl.sb6 = 1;
+                    // one post tile: every wave streams its own K slice through a private block ring (k_fused8) -- the
+                    // HBM stream never stops for the fragment read-out (0.615 against 0.665 ms for a 16-neuron shard of C3)
+                    pl.sb6 = (ptw6 == 1) ? 2 : 1;
                 }
             }
             if (mt6 > 0) {
                 const int ktall = ktw6 * (nw6 / ptw6);
                 bool ok = true;
-                if (h->opt_kernel == 0 && find_img(h, ktall << 8, pl.tile0, pl.nTiles) < 0)
-                    ok = img_room(h, (size_t)pl.nTiles * pgl_img_bytes(ktall));
+                if (h->opt_kernel == 0 && find_img(h, img_key6(ktall, pl.sb6 == 2), pl.tile0, pl.nTiles) < 0)
+                    ok = img_room(h, (size_t)pl.nTiles * img_bytes6(ktall, pl.sb6 == 2));
                 if (!ok) pl.sb6 = 0;
                 if (ok) {
                     pl.version = 6;
@@ -398,7 +406,8 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     if (pl.version == 6) {
         // as many workgroups per CU as registers and LDS allow (4-wave form at C2: three)
         pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
-        wgPerCU = fused6_wg_per_cu(pl);
+        if (pl.sb6 == 2) pl.lds = lds_fused8(kRing8);
+        wgPerCU = (pl.sb6 == 2) ? 1 : fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
     target = std::min(target, pl.nTiles);
@@ -425,6 +434,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     }
     if (pl.version == 6) {
         pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
+        if (pl.sb6 == 2) pl.lds = lds_fused8(kRing8);
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -721,8 +731,16 @@ static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream
         }
         return hipErrorInvalidValue;
     }
-    if (pl.sb6) {                                  // one image buffer: 640-column rows for one or two post tiles
-        if (pl.mt == 1 && pl.PTW == 1 && pl.KTW == 5) return launch_fused6_t<5, 1, 1, 8, 0>(pl, fp, s, occ);
+    if (pl.sb6 == 2) {                             // one post tile of a 25 .. 40 k-tile row: per-wave block rings
+        if (pl.mt != 1 || pl.PTW != 1 || pl.KTW != 5 || occ) return hipErrorInvalidValue;
+        auto kern = k_fused8<5, kRing8>;
+        if (dry_record("k_fused8", {5, kRing8})) return hipSuccess;
+        hipError_t e = ensure_dyn_lds(kern, pl.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+        return hipGetLastError();
+    }
+    if (pl.sb6) {                                  // one image buffer: 640-column rows for two post tiles
         if (pl.mt == 1 && pl.PTW == 2 && pl.KTW == 10) return launch_fused6_t<10, 2, 1, 8, 0>(pl, fp, s, occ);
         return hipErrorInvalidValue;
     }
@@ -997,7 +1015,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
     case 93: h->opt_slice_cols = value; return PGL_OK;      // dev: feature columns per slice of the 3-phase path (0 = 640)
     case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels, 3 = stimulus current through the slab, 4 = residual slab + k_sepf_bwd (no fused backward)
-    case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer form of k_fused6
+    case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer / block-ring forms
     case PGL_OPT_KERNEL: h->opt_kernel = value; return PGL_OK;
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
     case PGL_OPT_EPI_F64: h->opt_epi64 = value ? 1 : 0; return PGL_OK;
@@ -1693,11 +1711,11 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
 // features / time range.  A time-sharded rank (pgl_set_time_range) therefore builds and keeps only its
 // own 1/G of the recording.
 static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles, const Slice* sl = nullptr,
-                                 int slice_no = 0)
+                                 int slice_no = 0, bool blk = false)
 {
-    // kth == 0: one image per tile holding all ktl k-tiles (k_fused6); else the L / H pair of k_fused5
-    // sl: the images of ONE column slice of a wide population (key carries the slice number)
-    const int key = (sl ? (slice_no + 1) << 16 : 0) | ktl << 8 | kth;
+    // kth == 0: one image per tile holding all ktl k-tiles (k_fused6; blk: as 2 KB blocks, k_fused8); else the L / H pair
+    // of k_fused5.  sl: the images of ONE column slice of a wide population (key carries the slice number)
+    const int key = (sl ? (slice_no + 1) << 16 : 0) | (blk ? img_key6(ktl, true) : ktl << 8 | kth);
     int slot = find_img(h, key, tile0, ntiles);
     if (slot >= 0) {
         h->img_cur = slot;
@@ -1711,7 +1729,7 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
         else if (h->imgs[i].stamp < h->imgs[slot].stamp) slot = i;
     pgl_context::ImgSlot& im = h->imgs[slot];
     im.key = 0;
-    const size_t bytes = (size_t)ntiles * (kth ? img_pair_bytes(ktl, kth) : (size_t)pgl_img_bytes(ktl));
+    const size_t bytes = (size_t)ntiles * (kth ? img_pair_bytes(ktl, kth) : img_bytes6(ktl, blk));
     if (bytes > im.buf.cap) {
         // make room before allocating: the other slots' stale buffers go first
         for (int i = 0; i < pgl_context::NIMG; ++i)
@@ -1723,7 +1741,7 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, sl ? sl->Ns : h->N, h->B,
                        h->Rk, sl ? sl->Ds : (h->sep ? 0 : h->Dstim), ktl, kth, tile0, (unsigned char*)im.buf.p,
-                       h->N, sl ? sl->np0 : 0, h->Dstim, sl ? sl->ds0 : 0);
+                       h->N, sl ? sl->np0 : 0, h->Dstim, sl ? sl->ds0 : 0, blk ? 1 : 0);
     HIPCHK(hipGetLastError());
     im.key = key;
     im.tile0 = tile0;
@@ -1843,7 +1861,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         if (rc) return rc;
         ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
         rc = (pl.version == 5) ? ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles)
-                               : ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
+                               : ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, pl.version == 6 && pl.sb6 == 2);
         if (rc) return rc;
         if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepfParams sp;
@@ -1921,7 +1939,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (rc) return rc;
         }
         if (pl.version == 6 || pl.version == 7) {
-            rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles);
+            rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, pl.version == 6 && pl.sb6 == 2);
             if (rc) return rc;
         }
         FusedParams fp;
@@ -2369,7 +2387,7 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     v[12] = stim_path;
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
     v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth)
-            : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)pgl_img_bytes(pl.KT) : 0.0;   // resident feature bytes
+            : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)img_bytes6(pl.KT, pl.version == 6 && pl.sb6 == 2) : 0.0;   // resident feature bytes
     // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
     // pass 1 and the H part again in pass 2, residual slab written and read)
     v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0

@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
                                                     const double* __restrict__ fstim, long long nT,
                                                     int N, int B, int R, int Dstim, int ktl, int kth,
                                                     int tile0, unsigned char* __restrict__ Fimg,
-                                                    int Nall, int np0, int DsAll, int ds0)
+                                                    int Nall, int np0, int DsAll, int ds0, int blk = 0)
 {
     // N presynaptic neurons from np0 on and Dstim stimulus columns from ds0 on: the whole feature row, or one column slice of
     // a wide population (Nall / DsAll = the strides of the window tables and of fstim)
@@ -1643,6 +1643,25 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
     for (int i = threadIdx.x; i < B * R; i += blockDim.x) phiS[i] = phi[i];
     __syncthreads();
     const int tile = tile0 + blockIdx.x, part = blockIdx.y;
+    if (blk) {
+        // block form (k_fused8): ktl blocks of [16 bins][16 columns] per tile, columns XOR-swizzled (pgl_blk_off), no padding
+        double* dstb = reinterpret_cast<double*>(Fimg + (size_t)blockIdx.x * ktl * 2048);
+        const int Kimpb = N * B;
+        for (int i = threadIdx.x; i < ktl * 256; i += blockDim.x) {
+            const int kb = i >> 8, t = (i >> 4) & 15, pc = i & 15;
+            const int col = kb * 16 + (pc ^ (2 * (t >> 1)));
+            const long long tg = (long long)tile * 16 + t;
+            double v = 0.0;
+            if (col < Kimpb) {
+                const int np = col / B, b = col - np * B;
+                v = conv_one(spk, wlo[(size_t)tile * Nall + np0 + np], whi[(size_t)tile * Nall + np0 + np], (int)tg, R, phiS + b * R);
+            } else if (col < Kimpb + Dstim) {
+                v = (tg < nT) ? fstim[tg * DsAll + ds0 + (col - Kimpb)] : 0.0;
+            }
+            dstb[i] = v;
+        }
+        return;
+    }
     const int kt = part ? kth : ktl;
     const int rsh = pgl_img_rsh(kt), cw = kt * 16, cbeg = part ? ktl * 16 : 0, Kimp = N * B;
     const size_t imgl = (size_t)pgl_img_bytes(ktl), imgh = (gridDim.y > 1) ? (size_t)pgl_img_bytes(kth) : 0;
@@ -2460,6 +2479,254 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
         }
     }
     PGL_PROF_EXIT;
+}
+
+// ---------------------------------------------------------------------------
+// Fused ll + grad kernel, version 8: ONE post tile (a shard of <= 16 neurons: north star's neuron split at 8 GPUs) against
+// a long feature row (25 .. 40 k-tiles), K split over the 8 waves of the one workgroup a CU holds -- the HBM-bound corner:
+// 3.07 GB of resident features per C3 evaluation for 1/8 of the MFMA work.  k_fused6<5,1,1,8,0> has one image buffer there
+// (two 81 KB images do not fit the LDS), so the stream stops while the fragments are read out of it.  Here every wave
+// owns its K slice of the image END TO END: the images are stored as 2 KB blocks (one k-tile x 16 bins, XOR-swizzled
+// columns: conflict-free for both MFMA operand patterns without padding -- pgl_blk_off), a wave requests ITS blocks into a
+// private ring of RING blocks (LDS-DMA), waits for them with s_waitcnt alone -- no workgroup barrier on the data path --,
+// copies the forward and backward fragments of the tile to registers and hands the slots straight back to the DMA: RING - KTW
+// blocks per wave (48 KB per CU) are always in flight.  Two barriers per tile remain (partial currents, residuals).
+// Same partial layout as k_fused6.
+// ---------------------------------------------------------------------------
+// element (time row t, column c) of a 16 x 16 block, in doubles
+__host__ __device__ constexpr int pgl_blk_off(int t, int c) { return t * 16 + (c ^ (2 * (t >> 1))); }
+
+#ifndef PGL_F8_ABL
+#define PGL_F8_ABL 0
+#endif
+#define F8A(bit) ((PGL_F8_ABL & (bit)) != 0)
+template <int KTW, int RING>
+__global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
+{
+    constexpr int TT = 16, NW = 8, KSPLIT = 8;
+    constexpr int KSW = KTW * 4, KT_ALL = KTW * KSPLIT;
+    constexpr int BLK = 2048;
+    constexpr size_t IMG = (size_t)KT_ALL * BLK;
+    static_assert(RING > KTW && RING <= 2 * KTW && 2 * (RING - KTW) < 16, "ring: more than a tile, waitcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ksl = wave;
+    const int pt = blockIdx.x % p.nPT;
+    const int chunk = blockIdx.x / p.nPT;
+    unsigned char* const ring = smem + (size_t)wave * RING * BLK;            // this wave's blocks
+    double* Xp = reinterpret_cast<double*>(smem + (size_t)NW * RING * BLK); // [NW][4][64] partial currents
+    double* Rb = Xp + NW * 256;                                             // [4][64] residuals
+    double* Cs = Rb + 256;                                                  // [32] math constants
+    double* const wscratch = Cs + 32 + wave * 48;                           // per wave: spike compaction of the epilogue
+    if (tid < 32) Cs[tid] = PGL_C[tid];
+
+    d4_t G[KTW];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double ll_acc = 0.0, gb_acc = 0.0;
+
+    const int col = lane & 15;
+    const int grp = lane >> 4;
+    const int nloc = pt * 16 + col;
+    const bool valid_n = nloc < p.npost;
+    const int nglob = p.pidx ? p.pidx[valid_n ? nloc : 0] : p.n_lo + (valid_n ? nloc : 0);
+    const double bias_l = valid_n ? (p.theta ? p.theta[(size_t)nloc * p.P] : p.bias[nloc]) : (p.nlin == 1 ? 30.0 : 0.0);
+    // epilogue: waves 0-3 (one per SIMD) own one accumulator register of the tile each, all 64 lanes -- the fixed-order
+    // fast path of the other kernels (pgl_rate_fx: 9 instructions per element in standard_glm's regime, spike terms
+    // compacted) instead of eight half-empty waves on the general path: the rate chain of ONE element per lane is
+    // latency-bound, ~2 000 cycles between the two barriers of every tile with no MFMA to hide behind
+    const int er = wave & 3;
+    const bool emine = wave < 4;
+
+    const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
+    int tile_end = tile_beg + p.tilesPerChunk;
+    if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
+    const int total = (tile_end > tile_beg) ? (tile_end - tile_beg) * KTW : 0;       // blocks of this wave in the chunk
+    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG + (size_t)ksl * KTW * BLK;
+
+    // this wave's slice of Wmat stays in registers for the whole chunk
+    double wreg[KSW];
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) wreg[s] = 0.0;
+    if (p.theta) {
+        pgl_wfrag_direct<KSW>(p, ksl * KSW, grp, nloc, nglob, valid_n, wreg);
+    } else {
+        const pgl_d2* wr2 = reinterpret_cast<const pgl_d2*>(p.Wfrag + ((size_t)pt * (KSW * KSPLIT) + (size_t)ksl * KSW) * 64);
+#pragma unroll
+        for (int s2 = 0; s2 < KSW / 2; ++s2) {
+            const pgl_d2 v = wr2[s2 * 64 + lane];
+            wreg[2 * s2] = v.x;
+            wreg[2 * s2 + 1] = v.y;
+        }
+    }
+    // post-synaptic counts of the element this wave owns in the epilogue, requested one tile ahead
+    const int last_tile = p.nT16 - 1;
+    const uint8_t* cptr = p.S + ((size_t)(tile_beg < last_tile ? tile_beg : last_tile) * TT + grp + 4 * er) * p.Nall + nglob;
+    const size_t ctile = (size_t)TT * p.Nall;
+    unsigned scn = cptr[0];
+
+    // block n of the wave (tile tile_beg + n / KTW, k-tile n % KTW of its slice) lives in ring slot n % RING
+    // (behind the chunk's last block the requests go on, to its last block again: the number of loads in flight behind a
+    //  tile's blocks is then the same in every iteration -- one s_waitcnt immediate, and the compiler's own waits for
+    //  the spike counts stay partial; 16 KB per wave and chunk of extra traffic)
+    int n_issued = 0, is_tile = tile_beg, is_kt = 0, is_slot = 0;
+    auto issue_half = [&](const int half) {               // half 0 / 1 of the next block; the block advances behind half 1
+        const unsigned char* gs = fimg + (size_t)is_tile * IMG + (size_t)is_kt * BLK + half * 1024;
+        asm volatile("" : "+s"(gs));
+        unsigned char* dst = ring + is_slot * BLK + half * 1024;
+        if (!(F8A(16) && n_issued >= RING)) __builtin_amdgcn_global_load_lds((gvoid*)(gs + lane * 16), (lvoid*)dst, 16, 0, 0);
+        if (half) {
+            ++n_issued;
+            if (n_issued < total) {
+                if (++is_kt == KTW) { is_kt = 0; ++is_tile; }
+            }
+            if (++is_slot == RING) is_slot = 0;
+        }
+    };
+    auto issue = [&](const int count) {
+#pragma unroll
+        for (int j = 0; j < count; ++j) {
+            issue_half(0);
+            issue_half(1);
+        }
+    };
+    if (total == 0) return;                               // (never: a chunk has a tile)
+    issue(RING);
+    // workgroup barrier for LDS traffic only: __syncthreads() also waits for vmcnt(0) -- the blocks in flight
+    // (timing ablation, -DPGL_ABLATE builds only: 1 no MFMAs, 2 no rate epilogue, 4 no barriers, 8 no fragment reads)
+    auto lds_barrier = [&] { if (!F8A(4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    lds_barrier();                                        // the constants
+
+    // fragment offsets inside a block (bytes): forward -- time row col, columns 4 ks + grp; backward -- time row 4 q + grp,
+    // column col
+    int offa[4], offb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        offa[q] = pgl_blk_off(col, 4 * q + grp) * 8;
+        offb[q] = pgl_blk_off(4 * q + grp, col) * 8;
+    }
+    double fareg[KSW], fbreg[KSW];
+    int slot0 = 0;                                        // ring slot of the tile's first block
+    for (int tile = tile_beg, li = 0; tile < tile_end; ++tile, ++li) {
+        // the KTW blocks of this tile have landed when at most the RING - KTW blocks requested behind them are in flight
+        // (loads return in order)
+        __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (RING - KTW)));
+        const unsigned scu = scn;
+        cptr += (tile + 1 < tile_end && tile + 1 <= last_tile) ? ctile : 0;
+        if (!F8A(32)) scn = cptr[0];                      // (requested BEFORE the blocks below: it is back before them)
+        // k-tile by k-tile: the forward and backward fragments of block kt + 1 are read into registers while the four forward
+        // MFMAs of block kt run; behind them block kt's slot goes back to the DMA.  A request waits for room in the CU's miss
+        // queue and holds its wave meanwhile -- the SIMD's other wave has MFMAs to run then (all five requests in front of
+        // the MFMAs: 0.662 ms; one per four MFMAs: 0.619; spread over the backward loop as well: 0.644)
+        auto read_frags = [&](const int kt) {
+            int sl = slot0 + kt;
+            sl = (sl >= RING) ? sl - RING : sl;
+            const unsigned char* blk = ring + sl * BLK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (F8A(8)) { fareg[4 * kt + q] = 1.0; fbreg[q * KTW + kt] = 1.0; continue; }
+                fareg[4 * kt + q] = pgl_lds_f64(reinterpret_cast<const double*>(blk + offa[q]));
+                fbreg[q * KTW + kt] = pgl_lds_f64(reinterpret_cast<const double*>(blk + offb[q]));
+            }
+        };
+        read_frags(0);
+        // ---- forward over this wave's K slice ----
+        d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
+        d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) {
+            if (kt + 1 < KTW) read_frags(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 4 * kt + q;
+                if (F8A(1)) { acc0[0] += fareg[s]; continue; }
+                if (s & 1)
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fareg[s], wreg[s], acc1, 0, 0, 0);
+                else
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fareg[s], wreg[s], acc0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the fragments of blocks kt and kt + 1 are in registers
+            issue(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot0 += KTW;
+        slot0 = (slot0 >= RING) ? slot0 - RING : slot0;
+        double* xw = Xp + (size_t)wave * 256 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xw[r * 64] = acc0[r] + acc1[r];
+        lds_barrier();
+        // ---- epilogue: sum of the eight partials + bias -> ll term, residual, for the elements this wave owns ----
+        if (emine) {
+            double xe[1], sc[1], rese[1], terme[1];
+            unsigned scv[1];
+            double x = bias_l;
+#pragma unroll
+            for (int k2 = 0; k2 < KSPLIT; ++k2) x += Xp[(size_t)k2 * 256 + er * 64 + lane];
+            xe[0] = x;
+            scv[0] = scu;
+            sc[0] = (double)scu;
+            bool done = false;
+            if ((long long)(tile + 1) * TT <= p.t_hi && !F8A(2)) {     // whole tile inside the evaluated range
+                const double* cg = PGL_C;
+                asm volatile("" : "+s"(cg));               // keeps the scalar loads inside the tile loop
+                double termx = 0.0;
+#ifdef PGL_PROF
+                long long pgl_prof_dummy_acc[12] = {0};
+                long long pgl_prof_dummy_t = 0;
+#endif
+                done = pgl_rate_fx<1, 16>(xe, scv, p.nlin | p.epi64, p.dt, (pgl_k_cdp)cg, wscratch, lane, termx, rese PGL_PROF_DUMMY);
+                if (done) {
+                    ll_acc += termx;                       // lanes of padding neurons are never read back
+                    gb_acc += rese[0];
+                    Rb[er * 64 + lane] = rese[0];
+                }
+            }
+            if (!done) {
+                const long long tg = (long long)tile * TT + grp + 4 * er;
+                const bool vt = valid_n && (tg < p.t_hi);
+                pgl_lds_cdp Cl = (pgl_lds_cdp)Cs;
+                asm volatile("" : "+v"(Cl));
+                if (F8A(2)) { terme[0] = xe[0]; rese[0] = sc[0]; }
+                else pgl_rate_terms_n<1>(xe, sc, p.nlin | p.epi64, p.dt, terme, rese, Cl);
+                const double res = vt ? rese[0] : 0.0;
+                ll_acc += vt ? terme[0] : 0.0;
+                gb_acc += res;
+                Rb[er * 64 + lane] = res;
+            }
+        }
+        lds_barrier();
+        // ---- backward on this wave's K slice ----
+        if (p.want_grad) {
+            double rr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr[r] = Rb[r * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < KSW; ++s) {
+                if (F8A(1)) { G[s % KTW][0] += fbreg[s] * rr[s / KTW]; continue; }
+                G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(fbreg[s], rr[s / KTW], G[s % KTW], 0, 0, 0);
+            }
+        }
+    }
+
+    const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
+    p.llpart[slot * 64 + lane] = ll_acc;
+    p.gbpart[slot * 64 + lane] = gb_acc;
+    if (p.want_grad) {
+        double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
+        const size_t gcs = (size_t)p.nChunks * 64;
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -9,7 +9,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from theano_pyglm_amd import _lib
 
-FUSED = ('k_fused2<', 'k_fused3<', 'k_fused5<', 'k_fused6<', 'k_fused7<', 'k_fused<')
+FUSED = ('k_fused2<', 'k_fused3<', 'k_fused5<', 'k_fused6<', 'k_fused7<', 'k_fused8<', 'k_fused<')
 
 
 def shapes():
