@@ -58,7 +58,7 @@ python3 tools/shape_sweep.py 300 16 32 48 64 80 96 128 160 200 256 384 512 2>&1 
 fi
 if has shards; then
 echo "== time shards and neuron shards on one GPU"
-(echo "# HIP events around every evaluation"; python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G="; echo "# no events (the product path)"; TIMING=0 python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G=") | tee $R/r05_shard_steps.txt
+(echo "# HIP events around every evaluation"; python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G="; echo "# no events (the product path)"; TIMING=0 python3 tools/shard_step_bench.py 1 2 4 8 2>&1 | grep "^G="; echo "# neuron shards (north star's split): 64 / 32 / 16 neurons of C3 against the whole feature row"; python3 tools/narrow_shard.py 64 32 16 2>&1 | grep "^T=600" | cut -c1-200) | tee $R/r05_shard_steps.txt
 fi
 if has ranks; then
 echo "== bench.py --gpus N starting its own ranks on the one GPU (gloo)"
