@@ -39,7 +39,7 @@ def run(T, K, check_full):
         n_lo = 32
         d_theta = torch.from_numpy(theta[n_lo:n_lo + M]).cuda()
         res = {}
-        for name in ("k_fused8 (block rings)",):
+        for name in (" + ".join(_lib.plan_kernels(N, B=B, R=R, nT=nT, n_lo=n_lo, count=M)),):
             d_out = torch.zeros(M * (1 + P), dtype=torch.float64, device='cuda')
             info = dev.info(n_lo, n_lo + M)
             for _ in range(5):
