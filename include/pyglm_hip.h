@@ -72,7 +72,8 @@ typedef struct pgl_context* pgl_handle;
                                 * switch the events off */
 
 /* Development switches (not part of the drop-in surface; results stay valid unless stated): 95 = 2 keeps the narrow post
- * blocks of a wide population off the one-image-buffer form of k_fused6 (they run on k_fused2); 97 = waves per block of
+ * blocks of a wide population off the one-image-buffer form of k_fused6 and the block-ring kernel k_fused8 (they run on
+ * k_fused2); 97 = waves per block of
  * the partial reduction; 98 = post tiles per workgroup of the K-split kernels; 99 = kernel-internal ablation bits of the
  * fused / Gibbs kernels (!= 0 invalidates the results, except bit 0x1000: event-window pair currents although all columns
  * share the presynaptic neuron, and bits 8-11: forced sub-block count of k_gibbs_rate_cols). */
@@ -310,7 +311,9 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
  * [4]=LDS bytes, [5]=rows per time tile, [6]=algorithmic flops (4*nT*Ktot*npost),
  * [7]=algorithmic bytes, [8]=number of spike events (nonzero bins), [9]=kernel the call would use
  * (1 4-wave, 2 K-split, 3 K-split with f32 features, 4 two-pass, 5 two-pass on resident feature
- * tiles, 6 K-split on resident feature tiles, 7 single pass without K split on resident tiles), [10]=bytes of resident feature tiles (0 unless [9]==5), [11]=HBM bytes the hot kernels
+ * tiles, 6 K-split on resident feature tiles -- incl. the block-ring form k_fused8 for one post tile of a 25..40 k-tile
+ * row --, 7 single pass without K split on resident tiles), [10]=bytes of resident feature tiles (0 unless [9] >= 5),
+ * [11]=HBM bytes the hot kernels
  * stream per evaluation on top of the algorithmic ones (feature tiles, residual slab), [12]=stimulus path of the
  * call: 0 none / dense feature columns, 1 separable by the tap-rate kernels, 2 separable at the frame rate.
  * (For a separable stimulus [6] counts the impulse contraction only and [7] the projected stimulus at its frame
