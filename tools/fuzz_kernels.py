@@ -11,7 +11,7 @@ nbad = 0
 ncmp = {}
 nnf = 0
 for trial in range(40):
-    N = int(rng.choice([3, 9, 17, 30, 33, 48, 64, 80, 128, 130, 160, 200, 257, 300]))   # (> 128: column slices on resident tiles)
+    N = int(rng.choice([3, 9, 17, 30, 33, 48, 64, 80, 100, 128, 130, 160, 200, 257, 300]))   # (> 128: column slices on resident tiles)
     kind = str(rng.choice(['explinear', 'exp']))
     nT = int(rng.choice([700, 2500, 6000]))
     Dstim = int(rng.choice([0, 0, 3]))
@@ -61,4 +61,24 @@ for trial in range(40):
                 r = np.abs(g[gb] - g0[gb]).max(1) / scale
                 bad = np.where(gb)[0][r > 1e-8]
                 print("    worst grad rows", bad[:8].tolist(), "rel", np.round(r[r > 1e-8][:8], 12).tolist(), "theta0", np.round(th[bad[:8], 0], 1).tolist())
+    # a narrow shard (one post tile against a row of 25 .. 40 k-tiles: k_fused8, block-form images through per-wave rings)
+    if 78 <= N <= 128 and Dstim == 0:
+        cnt = int(rng.randint(1, 17))
+        lo = int(rng.randint(0, N - cnt + 1))
+        d = p.device()
+        names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], nT=nT, n_lo=lo, count=cnt)
+        ll, g = d.ll_grad(th[lo:lo + cnt], p.Weff, lo, lo + cnt)
+        d.close()
+        l0, gg0 = ll0[lo:lo + cnt], g0[lo:lo + cnt]
+        ncmp[names[0][:8]] = ncmp.get(names[0][:8], 0) + 1
+        f0, f1 = np.isfinite(l0), np.isfinite(ll)
+        gf0, gf1 = np.isfinite(gg0).all(1), np.isfinite(g).all(1)
+        both, gb = f0 & f1, gf0 & gf1
+        scale = np.abs(gg0[gb]).max() if gb.any() else 1.0
+        ok = np.allclose(ll[both], l0[both], rtol=1e-9, atol=0) and np.allclose(g[gb], gg0[gb], rtol=1e-8, atol=1e-9 * scale)
+        pat = (f0 != f1).sum() + (gf0 != gf1).sum()
+        if not ok or pat:
+            nbad += 1
+            print("trial %d N=%d %s nT=%d shard [%d, %d) %s: values ok %s, finite-pattern diffs %d"
+                  % (trial, N, kind, nT, lo, lo + cnt, names, ok, pat))
 print("fuzz done, %d discrepancies; comparisons per kernel version %s; non-finite gradient rows seen %d" % (nbad, ncmp, nnf))
