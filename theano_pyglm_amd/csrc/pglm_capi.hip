@@ -233,12 +233,13 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     pl.version = pl.f32 ? 3 : 2;
     if (pl.version == 2 && single_slice && need >= 2) {
         if (h->opt_kernel == 3) pl.version = 4;
-        // two-pass kernel on resident tiles from 5 post tiles on; from 4 when the feature row is too long for
-        // the resident K-split kernel (measured at K = 640: 64 neurons 2.05 ms against 2.33 ms of k_fused2)
+        // two-pass kernel on resident tiles from 5 post tiles on; from 3 when the feature row is too long for
+        // the resident K-split kernel (measured at K = 640: 64 neurons 2.05 ms against 2.33 ms of k_fused2; a 48-neuron
+        // list of a lock-step sweep at C3: 2.36 ms on k_fused2)
         // (force7 with a feature row too long for k_fused7 (> 16 k-tiles: its G no longer fits the registers beside the
         // epilogue) -- e.g. a short neuron list of a wide separable-stimulus population: the slab-input form of the two-pass
         // kernel, whatever the number of post tiles)
-        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT == 4 && need > 20))) ||
+        else if (h->opt_kernel == 4 || (h->opt_kernel == 0 && (pl.nPT >= 5 || (pl.nPT >= 3 && need > 20))) ||
                  (force7 && need > 16 && (h->opt_kernel == 0 || h->opt_kernel == 7)))
             pl.version = 5;
     }
