@@ -333,3 +333,21 @@ def test_packed_layout_matches_reference_golden():
     assert g['standard_glm']['unpacked']['bias']['bias'] == [0.0]
     st = g['spatiotemporal_glm']['unpacked']
     assert st['bkgd']['w_t'] == [1.0, 2.0, 3.0] and st['bkgd']['w_x'] == [4.0, 5.0, 6.0]      # 'w_t' < 'w_x'
+
+
+def test_block_image_swizzle_is_conflict_free_for_both_mfma_operand_patterns():
+    """The block-form feature images of k_fused8 (csrc/pglm_kernels.hip.h: pgl_blk_off) store element (time row t, column c)
+    of a 16 x 16 f64 block at t * 16 + (c ^ (2 * (t >> 1))).  A ds_read_b64 serves 32 lanes per pass over 64 banks of
+    4 bytes, i.e. 32 slots of 8 bytes: both MFMA operand patterns -- forward A (lane = time row i, k-step columns 4 ks +
+    grp) and backward A = F^T (lane = column i, time rows 4 q + grp) -- must put the 32 lanes of each pass into 32
+    different slots, without the row padding the other kernels' images use (k_build_fimg writes the same permutation)."""
+    def off(t, c):
+        return t * 16 + (c ^ (2 * (t >> 1)))
+
+    # a permutation of the block
+    assert sorted(off(t, c) for t in range(16) for c in range(16)) == list(range(256))
+    for half in (0, 1):                                   # lanes 0-31 / 32-63: grp in {0, 1} / {2, 3}
+        for s in range(4):                                # k-step (forward) resp. time quarter (backward)
+            fwd = {off(i, 4 * s + grp) % 32 for i in range(16) for grp in (2 * half, 2 * half + 1)}
+            bwd = {off(4 * s + grp, i) % 32 for i in range(16) for grp in (2 * half, 2 * half + 1)}
+            assert len(fwd) == 32 and len(bwd) == 32, (half, s)
