@@ -752,6 +752,21 @@ def test_map_lockstep_implicit_inverse_hessian_equals_dense():
         assert np.allclose(xa['glms'][n]['imp']['w_ir'], xb['glms'][n]['imp']['w_ir'], rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         fit_glms_batched_torch(popn, copy.deepcopy(x0), hessian='lbfgs')
+    # the same holds with the initial scaling of the identity (the scaled identity is the history's base term) ...
+    xc, xd = copy.deepcopy(x0), copy.deepcopy(x0)
+    fc, _, _ = fit_glms_batched_torch(popn, xc, hessian='dense', init_scaling=True)
+    sc = popn.last_fit_stats
+    fd, _, _ = fit_glms_batched_torch(popn, xd, hessian='implicit', init_scaling=True)
+    sd = popn.last_fit_stats
+    assert sc['init_scaling'] and sd['init_scaling'] and np.allclose(fc, fd, rtol=1e-10, atol=0)
+    assert np.max(np.abs(np.array(sc['per_neuron']['iterations']) - np.array(sd['per_neuron']['iterations']))) <= 1
+    assert np.allclose(fc, fa, rtol=1e-6, atol=0)                   # (both scalings end at the same optimum)
+    # ... and when the history of only 5 neurons fits the memory budget: consecutive groups, same fits
+    P = popn.glm.P
+    xe = copy.deepcopy(x0)
+    fe, _, _ = fit_glms_batched_torch(popn, xe, hessian='implicit', hessian_bytes=5.5 * 8 * (2 * P + 4) * 225)
+    se = popn.last_fit_stats
+    assert se['groups'] == 3 and se['inverse_hessian'] == 'implicit' and np.allclose(fe, fb, rtol=1e-10, atol=0)
     popn.release_data()
 
     # 400 pixels (identity spatial basis): P = 1 + 3 + 400 + 3 * 8
