@@ -70,6 +70,9 @@ typedef struct pgl_context* pgl_handle;
                                 * (default), n > 1 = a sample, 0 = none.  An event between two kernels of a stream costs ~6 us of
                                 * GPU idle time; loops that queue evaluations back to back (optimisers, bench.py) sample or
                                 * switch the events off */
+#define PGL_OPT_BFGS_MERGE 7   /* pgl_bfgs_step_dev: a whole optimiser iteration is ONE row kernel while hk_bound * P <= value
+                                * (doubles of update history per row that one workgroup walks; default 65536), else the split
+                                * form with the multi-workgroup history kernels; 0 = always split */
 
 /* Development switches (not part of the drop-in surface; results stay valid unless stated): 95 = 2 keeps the narrow post
  * blocks of a wide population off the one-image-buffer form of k_fused6 and the block-ring kernel k_fused8 (they run on
@@ -198,6 +201,21 @@ int pgl_bfgs_hmul_hist_dev(pgl_handle h, double* d_state, int M, int P, const in
 /* d_hist / d_coef NULL: dense form (pgl_bfgs_hmul_dev) */
 int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol, int maxiter, int init_scaling, double* d_hist,
                         double* d_coef, int Kmax);
+/* Everything an evaluation of the L listed rows is followed by, as ONE call (and, while the update history is short, ONE
+ * row kernel -- one workgroup per row -- instead of objective | linesearch | hmul | update | trial): priors and NaN rules on
+ * (d_ll_f, d_grad_g) in place (prior_kind >= 0; < 0: they already hold f and g), the line-search step, t = H g for the rows
+ * that took a step (update history d_hist / d_coef / d_ab as for pgl_bfgs_hmul_hist_dev, or dense d_H / ld as for
+ * pgl_bfgs_hmul_dev -- exactly one of the two), the update, and the NEXT trial point of every listed row:
+ *   d_Xt_next[d_pos_next[r]] = X[r] + alpha[r] p[r]   (d_pos_next (M) int32: position of row r in the next launch's list, < 0
+ *   = not listed any more; NULL = same positions as this launch; d_Xt_next NULL = no trial points).
+ * flags_out (NULL or M doubles of PINNED host memory): active flag of every listed row, written by the kernel itself -- the
+ * driver polls it behind an event, no copy kernel.  hk_bound: upper bound on the updates in any row's history (launches so
+ * far), selects the one-kernel or the split form (PGL_OPT_BFGS_MERGE).  coord_descent.py:161-204 is the unit replaced. */
+int pgl_bfgs_step_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt, double* d_ll_f,
+                      double* d_grad_g, int prior_kind, double mu_b, double sg_b, double stim_sigma, double mu, double sigma,
+                      double lam, int max_trials, double gtol, int maxiter, int init_scaling, double* d_hist, double* d_coef,
+                      int Kmax, double* d_ab, int hk_bound, double* d_H, int ld, const int* d_pos_next, double* d_Xt_next,
+                      double* flags_out);
 
 /* convolve_with_basis(S, ibasis) (basis.py:201-236 via impulse.py:114-130):
  * fS_out (nT,N,B) row-major, float64. */

@@ -797,6 +797,50 @@ def test_map_lockstep_implicit_inverse_hessian_equals_dense():
     popn.release_data()
 
 
+def test_map_lockstep_one_kernel_iteration_equals_split_form():
+    """pgl_bfgs_step_dev: the whole iteration behind an evaluation as ONE row kernel (k_bfgs_step<1024>, the default while
+    the update history is short) computes the same numbers as the split form (line search | k_bfgs_hdots | k_bfgs_hcomb |
+    update; PGL_OPT_BFGS_MERGE = 0): same sums in the same order -- the fits agree bit for bit, on a standard_glm shard
+    (group lasso) and on a separable-stimulus model whose rows are long (P = 1 + 3 + 400 + 3 N)."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    from theano_pyglm_amd.models import templates
+    N, nT = 24, 30000                                        # (P = 121: 2 P >= maxiter, the implicit form is the default)
+    rng = np.random.default_rng(77)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn = Population(make_model('standard_glm', N=N, dt=0.001))
+    data = {'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1}
+    popn.add_data(data)
+    x0 = popn.sample(np.random.RandomState(16))
+    D = 400
+    tmpl = templates.spatiotemporal_glm()
+    tmpl['bkgd']['D_stim'] = D
+    tmpl['bkgd']['spatial_basis'] = {'type': 'identity', 'n_eye': D}
+    pst = Population(make_model(tmpl, N=8, dt=0.001))
+    S8 = np.minimum(rng.poisson(25.0 * 0.001, size=(20000, 8)), 10).astype(np.uint8)
+    dst = {'S': S8, 'N': 8, 'dt': 0.001, 'T': 20.0, 'stim': rng.standard_normal((200, D)), 'dt_stim': 0.1}
+    pst.add_data(dst)
+    xs = pst.sample(np.random.RandomState(3))
+    for g in xs['glms']:
+        g['bkgd']['w_x'] = np.asarray(g['bkgd']['w_x']) * (0.4 / np.sqrt(D))
+    for pp, dd, xx, kw in ((popn, data, x0, {}), (pst, dst, xs, {'maxiter': 40})):
+        h = pp._handle(pp.data_sequences[-1])
+        xa, xb = copy.deepcopy(xx), copy.deepcopy(xx)
+        fa, ita, eva = fit_glms_batched_torch(pp, xa, **kw)
+        sa = pp.last_fit_stats
+        h.set_option(_lib.OPT_BFGS_MERGE, 0)
+        try:
+            fb, itb, evb = fit_glms_batched_torch(pp, xb, **kw)
+        finally:
+            h.set_option(_lib.OPT_BFGS_MERGE, 65536)
+        sb = pp.last_fit_stats
+        assert sa['bookkeeping'] == 'hip row kernels' and sa['inverse_hessian'] == 'implicit'
+        assert np.array_equal(fa, fb) and (ita, eva) == (itb, evb)
+        assert sa['per_neuron'] == sb['per_neuron']
+        for n in range(pp.N):
+            assert np.array_equal(pp.glm.theta_row(xa['glms'][n]), pp.glm.theta_row(xb['glms'][n]))
+        pp.release_data()
+
+
 def test_map_lockstep_matches_sequential_c2():
     """C2 (N=32, T=300 s): every neuron's lock-step optimum equals the sequential scipy fit."""
     st = _map_compare(32, 300000, range(32), 1234 + 2)

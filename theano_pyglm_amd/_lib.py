@@ -21,6 +21,7 @@ OPT_KERNEL = 3
 OPT_GIBBS_KERNEL = 4
 OPT_EPI_F64 = 5
 OPT_TIMING = 6
+OPT_BFGS_MERGE = 7
 
 # every symbol include/pyglm_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -32,7 +33,7 @@ SYMBOLS = [
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
     'pgl_bfgs_state_doubles', 'pgl_bfgs_init_dev', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
-    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_hmul_hist_dev', 'pgl_bfgs_update_dev', 'pgl_plan_kernels',
+    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_hmul_hist_dev', 'pgl_bfgs_update_dev', 'pgl_bfgs_step_dev', 'pgl_plan_kernels',
 ]
 
 
@@ -126,6 +127,10 @@ def load():
         lib.pgl_bfgs_hmul_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         lib.pgl_bfgs_update_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, C.c_int]
         lib.pgl_bfgs_hmul_hist_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    if hasattr(lib, 'pgl_bfgs_step_dev'):
+        lib.pgl_bfgs_step_dev.argtypes = ([vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int] + [C.c_double] * 6 +
+                                          [C.c_int, C.c_double, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int,
+                                           vp, vp, vp])
     lib.pgl_features.argtypes = [vp, vp]
     lib.pgl_impulse_currents.argtypes = [vp, vp, vp]
     lib.pgl_state.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
@@ -364,6 +369,19 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_bfgs_update_dev(self.h, C.c_void_p(d_state), int(M), int(P), float(gtol), int(maxiter),
                                           1 if init_scaling else 0, C.c_void_p(d_hist) if d_hist else None,
                                           C.c_void_p(d_coef) if d_coef else None, int(Kmax)))
+
+    def bfgs_step_dev(self, d_state, M, P, d_rows, L, d_Xt, d_f, d_g, prior=None, max_trials=100, gtol=1e-5, maxiter=225,
+                      init_scaling=False, d_hist=0, d_coef=0, Kmax=0, d_ab=0, hk_bound=0, d_H=0, ld=0, d_pos_next=0,
+                      d_Xt_next=0, flags_out=0):
+        """One whole optimiser iteration behind an evaluation (pgl_bfgs_step_dev).  prior: the tuple of
+        bfgs_objective_dev's prior arguments, or None when d_f / d_g already hold the objective and its gradient."""
+        vp = lambda a: C.c_void_p(a) if a else None
+        pr = (-1, 0.0, 1.0, 1.0, 0.0, 1.0, 0.0) if prior is None else prior
+        _chk(self.lib.pgl_bfgs_step_dev(self.h, C.c_void_p(d_state), int(M), int(P), vp(d_rows), int(L), C.c_void_p(d_Xt),
+                                        C.c_void_p(d_f), C.c_void_p(d_g), int(pr[0]), *[float(z) for z in pr[1:]],
+                                        int(max_trials), float(gtol), int(maxiter), 1 if init_scaling else 0, vp(d_hist),
+                                        vp(d_coef), int(Kmax), vp(d_ab), int(hk_bound), vp(d_H), int(ld), vp(d_pos_next),
+                                        vp(d_Xt_next), vp(flags_out)))
 
     def sync(self):
         _chk(self.lib.pgl_sync(self.h))

@@ -93,6 +93,12 @@ struct pgl_context {
     long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
+    // lock-step optimiser: the pinned flag buffer of pgl_bfgs_step_dev and its device address (looked up once);
+    // history size (hk_bound * P doubles per row) up to which a whole iteration is ONE row kernel (PGL_OPT_BFGS_MERGE)
+    double* flags_host[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* flags_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int flags_next = 0;
+    int opt_bfgs_merge = 65536;
 };
 
 static int ensure(DevBuf& b, size_t bytes)
@@ -1021,6 +1027,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case PGL_OPT_GIBBS_KERNEL: h->opt_gibbs = value; return PGL_OK;
     case PGL_OPT_EPI_F64: h->opt_epi64 = value ? 1 : 0; return PGL_OK;
     case PGL_OPT_TIMING: if (value < 0) return fail(PGL_ERR_ARG, "timing interval < 0"); h->opt_timing = value; h->call_no = 0; return PGL_OK;
+    case PGL_OPT_BFGS_MERGE: if (value < 0) return fail(PGL_ERR_ARG, "merge threshold < 0"); h->opt_bfgs_merge = value; return PGL_OK;
     case PGL_OPT_NCHUNKS: if (value < 0) return fail(PGL_ERR_ARG, "nchunks < 0"); h->opt_nchunks = value; return PGL_OK;
     }
     return fail(PGL_ERR_ARG, "unknown option");
@@ -2157,14 +2164,25 @@ int pgl_bfgs_init_dev(pgl_handle h, double* d_state, int M, int P, double gtol)
     return PGL_OK;
 }
 
+static BfgsStepArgs bfgs_step_args(int phases)
+{
+    BfgsStepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.phases = phases;
+    a.max_trials = 100;
+    return a;
+}
+
 int pgl_bfgs_linesearch_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt,
                             const double* d_f, const double* d_g, int max_trials)
 {
     if (!h || !d_state || !d_Xt || !d_f || !d_g || M <= 0 || P <= 0 || L <= 0 || L > M || max_trials <= 0)
         return fail(PGL_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_bfgs_linesearch, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), d_rows, d_Xt,
-                       d_f, d_g, max_trials);
+    BfgsStepArgs a = bfgs_step_args(PGL_STEP_LS);            // f, g arrive final: no prior phase
+    a.rows = d_rows; a.Xt = d_Xt; a.ft = const_cast<double*>(d_f); a.gt = const_cast<double*>(d_g);
+    a.max_trials = max_trials;
+    hipLaunchKernelGGL(k_bfgs_step<256>, dim3(L), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), a);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }
@@ -2205,8 +2223,82 @@ int pgl_bfgs_update_dev(pgl_handle h, double* d_state, int M, int P, double gtol
     if ((d_hist != nullptr) != (d_coef != nullptr) || (d_hist && Kmax < maxiter))
         return fail(PGL_ERR_ARG, "history buffers: both or none, room for maxiter updates");
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_bfgs_update, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), gtol, maxiter,
-                       init_scaling, d_hist, d_coef, Kmax);
+    BfgsStepArgs a = bfgs_step_args(PGL_STEP_UPDATE);        // every row of the shard, no trial points
+    a.gtol = gtol; a.maxiter = maxiter; a.init_scaling = init_scaling; a.Wh = d_hist; a.cs = d_coef; a.Kmax = Kmax;
+    hipLaunchKernelGGL(k_bfgs_step<256>, dim3(M), dim3(256), 0, h->stream, pgl_bfgs_view(d_state, M, P), a);
+    HIPCHK(hipGetLastError());
+    return PGL_OK;
+}
+
+// One whole iteration behind an evaluation (see k_bfgs_step): in ONE launch while the update history of a row is short
+// (hk_bound * P numbers, PGL_OPT_BFGS_MERGE), else as line search | k_bfgs_hdots | k_bfgs_hcomb | update (dense inverse
+// Hessians: line search | k_bfgs_hmul | update).
+int pgl_bfgs_step_dev(pgl_handle h, double* d_state, int M, int P, const int* d_rows, int L, const double* d_Xt, double* d_ll_f,
+                      double* d_grad_g, int prior_kind, double mu_b, double sg_b, double stim_sigma, double mu, double sigma,
+                      double lam, int max_trials, double gtol, int maxiter, int init_scaling, double* d_hist, double* d_coef,
+                      int Kmax, double* d_ab, int hk_bound, double* d_H, int ld, const int* d_pos_next, double* d_Xt_next,
+                      double* flags_out)
+{
+    if (!h || !d_state || !d_Xt || !d_ll_f || !d_grad_g || M <= 0 || P <= 0 || L <= 0 || L > M || max_trials <= 0)
+        return fail(PGL_ERR_ARG, "bad argument");
+    if (prior_kind > 1) return fail(PGL_ERR_ARG, "prior kind: 0 Gaussian, 1 group lasso, < 0: f and g arrive final");
+    if (prior_kind >= 0 && P != 1 + h->Dstim + h->Kimp) return fail(PGL_ERR_ARG, "rows must be theta rows [bias, w_stim, w_ir]");
+    if ((d_hist != nullptr) != (d_coef != nullptr) || (d_hist && (Kmax < maxiter || !d_ab)))
+        return fail(PGL_ERR_ARG, "history buffers: all or none, room for maxiter updates");
+    if ((d_hist != nullptr) == (d_H != nullptr)) return fail(PGL_ERR_ARG, "either the update history or dense inverse Hessians");
+    if (d_H && (ld < P || (ld & 1) || (reinterpret_cast<uintptr_t>(d_H) & 15)))
+        return fail(PGL_ERR_ARG, "H: leading dimension even and >= P, base 16-byte aligned");
+    HIPCHK(hipSetDevice(h->device));
+    double* flags_dev = nullptr;
+    if (flags_out) {                                         // pinned host memory: the address the device uses for it
+        for (int i = 0; i < 4 && !flags_dev; ++i)
+            if (h->flags_host[i] == flags_out) flags_dev = h->flags_dev[i];
+        if (!flags_dev) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, flags_out, 0) != hipSuccess || !dp) {
+                (void)hipGetLastError();
+                return fail(PGL_ERR_ARG, "flags_out must be pinned (page-locked, device-mapped) host memory");
+            }
+            flags_dev = (double*)dp;
+            h->flags_host[h->flags_next] = flags_out;
+            h->flags_dev[h->flags_next] = flags_dev;
+            h->flags_next = (h->flags_next + 1) & 3;
+        }
+    }
+    const BfgsView v = pgl_bfgs_view(d_state, M, P);
+    BfgsStepArgs a = bfgs_step_args(0);
+    a.rows = d_rows; a.Xt = d_Xt; a.ft = d_ll_f; a.gt = d_grad_g;
+    a.have_prior = prior_kind >= 0 ? 1 : 0;
+    a.q.N = h->N; a.q.B = h->B; a.q.Dstim = h->Dstim; a.q.kind = prior_kind;
+    a.q.mu_b = mu_b; a.q.sg_b = sg_b; a.q.stim_sigma = stim_sigma; a.q.mu = mu; a.q.sigma = sigma; a.q.lam = lam;
+    a.max_trials = max_trials; a.gtol = gtol; a.maxiter = maxiter; a.init_scaling = init_scaling;
+    a.Wh = d_hist; a.cs = d_coef; a.Kmax = Kmax; a.ab = d_ab;
+    a.pos_next = d_pos_next; a.Xt_next = d_Xt_next; a.flags_out = flags_dev;
+    const bool merged = d_hist && (long long)std::max(hk_bound, 0) * P <= (long long)h->opt_bfgs_merge;
+    if (merged) {
+        a.phases = PGL_STEP_LS | PGL_STEP_HIST | PGL_STEP_UPDATE;
+        hipLaunchKernelGGL(k_bfgs_step<1024>, dim3(L), dim3(1024), 0, h->stream, v, a);
+        HIPCHK(hipGetLastError());
+        return PGL_OK;
+    }
+    a.phases = PGL_STEP_LS;
+    hipLaunchKernelGGL(k_bfgs_step<256>, dim3(L), dim3(256), 0, h->stream, v, a);
+    HIPCHK(hipGetLastError());
+    if (d_hist) {
+        const int Kb = std::min(Kmax, std::max(hk_bound, 1));       // no row holds more than hk_bound updates
+        hipLaunchKernelGGL(k_bfgs_hdots, dim3((unsigned)((Kb + 3) / 4), (unsigned)L), dim3(256), 0, h->stream, v, d_rows,
+                           (const double*)d_hist, (const double*)d_coef, Kmax, d_ab);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_bfgs_hcomb, dim3((unsigned)((P + 63) / 64), (unsigned)L), dim3(512), 0, h->stream, v, d_rows,
+                           (const double*)d_hist, Kmax, (const double*)d_ab);
+        HIPCHK(hipGetLastError());
+    } else {
+        const unsigned bx = (unsigned)((P + 4 * PGL_HM_ROWS - 1) / (4 * PGL_HM_ROWS));
+        hipLaunchKernelGGL(k_bfgs_hmul, dim3(bx, (unsigned)L), dim3(256), 0, h->stream, v, d_rows, d_H, ld);
+        HIPCHK(hipGetLastError());
+    }
+    a.phases = PGL_STEP_UPDATE;
+    hipLaunchKernelGGL(k_bfgs_step<256>, dim3(L), dim3(256), 0, h->stream, v, a);
     HIPCHK(hipGetLastError());
     return PGL_OK;
 }

@@ -5536,11 +5536,14 @@ __device__ __forceinline__ void pgl_ls_store(const BfgsView& v, int r, const Pgl
 }
 
 // sum / max over the 256 threads of a block, result in every thread (fixed order)
+// (blocks of more than 256 threads -- the one-launch iteration k_bfgs_step<1024> -- run their row loops on the first 256
+//  threads only, so a row's sums are the same numbers whichever kernel computes them; the other threads pass through the
+//  barriers with nothing to add)
 __device__ __forceinline__ double pgl_blk_sum(double v, double* red)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
@@ -5548,10 +5551,12 @@ __device__ __forceinline__ double pgl_blk_max(double v, double* red)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
+// first column of a thread's stride-256 walk over a row of P numbers (threads beyond the first 256: none)
+__device__ __forceinline__ int pgl_row_c0(const int tid, const int P) { return tid < 256 ? tid : P; }
 
 // start of a fit: X, f, g of every row are in place; H = I (not materialised), steepest-descent direction, scipy's
 // first trial step min(1, 1.01 / |g|) (its old_old_fval = f + |g| / 2), rows with max|g| <= gtol never start
@@ -5599,17 +5604,12 @@ struct BfgsPrior {
     double mu_b, sg_b, stim_sigma, mu, sigma, lam;
 };
 
-// f = -(ll + log prior), g = -(grad ll + grad log prior) of the listed trial rows [bias, w_stim, w_ir] (the packing
-// that IS the device's theta row); fit_glm's NaN rules: f NaN -> 1e16, any NaN in a gradient row -> zero row
-// (coord_descent.py:170-182).  In place: ll -> f, grad -> g.
-__global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const double* __restrict__ Xt,
-                                                        double* __restrict__ ll, double* __restrict__ grad,
-                                                        const BfgsPrior q)
+// f = -(ll + log prior), g = -(grad ll + grad log prior) of one trial row x = [bias, w_stim, w_ir] (the packing that IS the
+// device's theta row); fit_glm's NaN rules: f NaN -> 1e16, any NaN in a gradient row -> zero row
+// (coord_descent.py:170-182).  In place: *llj -> f, g (grad) -> g.  Whole block; row loops on its first 256 threads.
+__device__ __forceinline__ void pgl_bfgs_objective_row(const int P, const double* __restrict__ x, double* __restrict__ g,
+                                                       double* __restrict__ llj, const BfgsPrior& q, double* red, const int tid)
 {
-    __shared__ double red[4];
-    const int j = blockIdx.x, tid = threadIdx.x;
-    const double* x = Xt + (size_t)j * P;
-    double* g = grad + (size_t)j * P;
     double lp = 0.0;
     bool bad = false;
     if (tid == 0) {                                                            // bias.py:33
@@ -5619,7 +5619,7 @@ __global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const doubl
         bad = bad || (gv != gv);
         g[0] = gv;
     }
-    for (int c = 1 + tid; c < 1 + q.Dstim; c += 256) {                         // bkgd.py:76
+    for (int c = 1 + pgl_row_c0(tid, q.Dstim); c < 1 + q.Dstim; c += 256) {    // bkgd.py:76
         const double w = x[c], is2 = 1.0 / (q.stim_sigma * q.stim_sigma);
         lp += -0.5 * is2 * w * w;
         const double gv = -(g[c] - w * is2);
@@ -5627,7 +5627,7 @@ __global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const doubl
         g[c] = gv;
     }
     const int o = 1 + q.Dstim;
-    for (int n = tid; n < q.N; n += 256) {                                     // one presynaptic group per thread
+    for (int n = pgl_row_c0(tid, q.N); n < q.N; n += 256) {                    // one presynaptic group per thread
         const double* w = x + o + n * q.B;
         double* gw = g + o + n * q.B;
         if (q.kind == 1) {                                                     // priors.py:202
@@ -5657,29 +5657,39 @@ __global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const doubl
     const double lpt = pgl_blk_sum(lp, red);
     const bool anybad = pgl_blk_max(bad ? 1.0 : 0.0, red) > 0.0;
     if (tid == 0) {
-        const double fv = -(ll[j] + lpt);
-        ll[j] = (fv != fv) ? 1e16 : fv;
+        const double fv = -(*llj + lpt);
+        *llj = (fv != fv) ? 1e16 : fv;
     }
     if (anybad)
-        for (int c = tid; c < P; c += 256) g[c] = 0.0;
+        for (int c = pgl_row_c0(tid, P); c < P; c += 256) g[c] = 0.0;
 }
 
-// One line-search step of every listed row whose search is running: phi'(alpha) = g_trial . p, then the More'-Thuente
-// state machine.  Outcomes: another trial step (alpha[r]); the trial satisfies the strong Wolfe conditions and the row
-// takes it (X, f, g; s, y, rho left behind, acc = 1); or the search cannot make progress -- then the best
-// sufficient-decrease point of this search is taken if there is one (the trial itself or the saved best step, Xb / gb),
-// else stall = 1 (k_bfgs_update restarts or freezes the row).
-__global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const int* __restrict__ rows,
-                                                         const double* __restrict__ Xt, const double* __restrict__ ft,
-                                                         const double* __restrict__ gt, const int max_trials)
+// (pgl_bfgs_objective_dev: the objective of rows that are not in a search -- the starting point of a fit)
+__global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const double* __restrict__ Xt,
+                                                        double* __restrict__ ll, double* __restrict__ grad,
+                                                        const BfgsPrior q)
 {
     __shared__ double red[4];
-    __shared__ int dec[3];
-    const int j = blockIdx.x, r = rows ? rows[j] : j, tid = threadIdx.x, P = v.P;
+    const int j = blockIdx.x;
+    pgl_bfgs_objective_row(P, Xt + (size_t)j * P, grad + (size_t)j * P, ll + j, q, red, (int)threadIdx.x);
+}
+
+// One line-search step of a row whose search is running (r: its row of the state, xt / ftj / gt: the evaluated trial):
+// phi'(alpha) = g_trial . p, then the More'-Thuente state machine.  Outcomes: another trial step (alpha[r]); the trial
+// satisfies the strong Wolfe conditions and the row takes it (X, f, g; s, y, rho left behind, acc = 1); or the search cannot
+// make progress -- scipy stops there ("precision loss"; identical iterates up to that first warning only) -- then the best
+// sufficient-decrease point of this search is taken if there is one (the trial itself, or the best step saved so far, Xb / gb
+// -- judged by ITS step length, also when the search is cut off by max_trials on a call in which the trial became the best
+// step), else stall = 1 (the update phase restarts or freezes the row).
+__device__ __forceinline__ void pgl_bfgs_linesearch_row(const BfgsView& v, const int r, const double* __restrict__ xt,
+                                                        const double* __restrict__ ftj, const double* __restrict__ gt,
+                                                        const int max_trials, double* red, int* dec, const int tid)
+{
+    const int P = v.P;
     if (v.active[r] == 0.0) return;
-    const size_t o = (size_t)r * P, ot = (size_t)j * P;
+    const size_t o = (size_t)r * P;
     double dp = 0.0;
-    for (int c = tid; c < P; c += 256) dp = fma(gt[ot + c], v.p[o + c], dp);
+    for (int c = pgl_row_c0(tid, P); c < P; c += 256) dp = fma(gt[c], v.p[o + c], dp);
     dp = pgl_blk_sum(dp, red);
     if (tid == 0) {
         // (the state machine is wave-uniform scalar code; routed through a vector register index so that its ~40 doubles
@@ -5689,8 +5699,8 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
         const int r = rv;
         PglLs s;
         pgl_ls_load(v, r, &s);
-        const double stp = s.stp;
-        const double f = ft[j];
+        const double stp = s.stp, stx_prev = s.stx;
+        const double f = *ftj;
         // an infinite objective or slope ends the search like scipy's ("WARN": its fallback search fails on inf as well);
         // NaN never arrives here (fit_glm's rule: 1e16 and a zero gradient, applied by the objective)
         int rc = PGL_LS_WARNING;
@@ -5702,8 +5712,10 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
         const int moved = s.moved != 0.0;
         if (rc == PGL_LS_CONVERGED) src = 1;
         else if (rc == PGL_LS_WARNING) {
+            // (Xb / gb / fb still hold the best step BEFORE this call -- they are only overwritten on EVALUATE -- and
+            //  stx_prev is its step length: s.stx is the trial's when it has just become the best step)
             const bool okT = stp > 0.0 && f <= s.finit + stp * s.gtest && f < s.finit;
-            const bool okB = !moved && s.stx > 0.0 && v.fb[r] <= s.finit + s.stx * s.gtest && v.fb[r] < s.finit;
+            const bool okB = stx_prev > 0.0 && v.fb[r] <= s.finit + stx_prev * s.gtest && v.fb[r] < s.finit;
             if (okT && (!okB || f <= v.fb[r])) src = 1;
             else if (okB) src = 2;
             if (src == 0) v.stall[r] = 1.0;
@@ -5719,17 +5731,17 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
     const int rc = dec[0], src = dec[1];
     if (rc == PGL_LS_EVALUATE) {
         if (dec[2])                                          // the trial is the best step so far: keep its point and gradient
-            for (int c = tid; c < P; c += 256) {
-                v.Xb[o + c] = Xt[ot + c];
-                v.gb[o + c] = gt[ot + c];
+            for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
+                v.Xb[o + c] = xt[c];
+                v.gb[o + c] = gt[c];
             }
         return;
     }
     if (src == 0) return;
-    const double* xs = src == 1 ? Xt + ot : v.Xb + o;
-    const double* gs = src == 1 ? gt + ot : v.gb + o;
+    const double* xs = src == 1 ? xt : v.Xb + o;
+    const double* gs = src == 1 ? gt : v.gb + o;
     double sy = 0.0;
-    for (int c = tid; c < P; c += 256) {
+    for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
         const double xn = xs[c], gn = gs[c];
         const double s = xn - v.X[o + c], y = gn - v.g[o + c];
         v.s[o + c] = s;
@@ -5740,7 +5752,7 @@ __global__ __launch_bounds__(256) void k_bfgs_linesearch(const BfgsView v, const
     }
     sy = pgl_blk_sum(sy, red);
     if (tid == 0) {
-        const double fn = src == 1 ? ft[j] : v.fb[r];
+        const double fn = src == 1 ? *ftj : v.fb[r];
         v.fprev[r] = v.f[r];
         v.f[r] = fn;
         v.acc[r] = 1.0;
@@ -5903,12 +5915,11 @@ __global__ __launch_bounds__(512) void k_bfgs_hcomb(const BfgsView v, const int*
 // update  H_new = (I - rho s y^T) H (I - rho y s^T) + rho s s^T = H + U V^T,  H_new g_new, the next direction and the
 // start of its line search, restart / freeze of stalled rows, convergence flags.  init_scaling != 0: the first update
 // after a (re)start is preceded by H <- (s.y / y.y) I (Nocedal & Wright (6.20); not scipy's behaviour).
-__global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const double gtol, const int maxiter,
-                                                     const int init_scaling, double* __restrict__ Wh = nullptr,
-                                                     double* __restrict__ cs = nullptr, const int Kmax = 0)
+__device__ __forceinline__ void pgl_bfgs_update_row(const BfgsView& v, const int r, const double gtol, const int maxiter,
+                                                    const int init_scaling, double* __restrict__ Wh,
+                                                    double* __restrict__ cs, const int Kmax, double* red, const int tid)
 {
-    __shared__ double red[4];
-    const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
+    const int P = v.P;
     const size_t o = (size_t)r * P;
     const bool act = v.active[r] != 0.0, a = v.acc[r] != 0.0, u = v.upd[r] != 0.0, st = v.stall[r] != 0.0;
     if (!act || (!a && !st)) return;                         // finished, or in the middle of a line search
@@ -5927,13 +5938,13 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
             double sc = 1.0;
             if (init_scaling && lazy) {                      // H <- (s.y / y.y) I before the first update
                 double yy = 0.0;
-                for (int c = tid; c < P; c += 256) yy = fma(v.y[o + c], v.y[o + c], yy);
+                for (int c = pgl_row_c0(tid, P); c < P; c += 256) yy = fma(v.y[o + c], v.y[o + c], yy);
                 yy = pgl_blk_sum(yy, red);
                 const double gam = (1.0 / rho) / yy;
                 if (gam > 0.0 && gam - gam == 0.0) { sc = gam / hs; hs = gam; }
             }
             double yHy = 0.0, vg0 = 0.0, vg2 = 0.0;
-            for (int c = tid; c < P; c += 256) {
+            for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
                 const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
                 const double Hy = tc - sc * v.Hg[o + c];
                 yHy = fma(v.y[o + c], Hy, yHy);
@@ -5944,7 +5955,7 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
             vg0 = pgl_blk_sum(vg0, red);
             vg2 = pgl_blk_sum(vg2, red);
             const double c0 = (1.0 + rho * yHy) * rho;
-            for (int c = tid; c < P; c += 256) {
+            for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
                 const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
                 const double s = v.s[o + c], Hy = tc - sc * v.Hg[o + c];
                 const double u0 = c0 * s, u1 = -rho * Hy, u2 = -rho * s;
@@ -5967,7 +5978,7 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
             pend = Wh ? false : true;
             hist_add = Wh != nullptr;
         } else {
-            for (int c = tid; c < P; c += 256) v.Hg[o + c] = lazy ? hs * v.g[o + c] : v.t[o + c];
+            for (int c = pgl_row_c0(tid, P); c < P; c += 256) v.Hg[o + c] = lazy ? hs * v.g[o + c] : v.t[o + c];
             ident = lazy;
             pend = false;
         }
@@ -5978,7 +5989,7 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
         else frozen = true;
     }
     double sl = 0.0, gg = 0.0, gmax = 0.0;
-    for (int c = tid; c < P; c += 256) {
+    for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
         const double gc = v.g[o + c];
         sl = fma(-v.Hg[o + c], gc, sl);
         gg = fma(gc, gc, gg);
@@ -5990,7 +6001,7 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
     const bool newls = a || again;
     const bool reset = newls && (again || !(sl < 0.0));      // restart / not a descent direction: H = I
     if (newls)
-        for (int c = tid; c < P; c += 256) {
+        for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
             const double gc = v.g[o + c];
             if (reset) v.Hg[o + c] = gc;
             v.p[o + c] = reset ? -gc : -v.Hg[o + c];
@@ -6022,5 +6033,150 @@ __global__ __launch_bounds__(256) void k_bfgs_update(const BfgsView v, const dou
         v.acc[r] = 0.0;                                      // cleared for the next launch
         v.upd[r] = 0.0;
         v.stall[r] = 0.0;
+    }
+}
+
+// t = H g of ONE row from its update history inside a block of NT threads (NT / 64 waves): the two kernels above in one
+// workgroup -- wave w takes the dots of the updates j = w, w + NT / 64, ... exactly as a wave of k_bfgs_hdots does, then
+// NT / 512 groups of eight waves each combine 64 components exactly as a block of k_bfgs_hcomb does: the same numbers.
+// The merged iteration kernel uses it while the history of a row is short (4 hk P numbers through one workgroup).
+template <int NT>
+__device__ __forceinline__ void pgl_bfgs_hist_row(const BfgsView& v, const int r, const double* __restrict__ Wh,
+                                                  const double* __restrict__ cs, const int Kmax, double* __restrict__ ab,
+                                                  double (*part)[64], const int tid)
+{
+    if (v.acc[r] == 0.0) return;
+    const int P = v.P, K = (int)v.hk[r];
+    if (K == 0) return;                                      // (no history: the update uses t = hscale g)
+    const int lane = tid & 63, wv = tid >> 6;
+    const double* __restrict__ g = v.g + (size_t)r * P;
+    for (int j = wv; j < K; j += NT / 64) {
+        const double* __restrict__ W = Wh + ((size_t)r * Kmax + j) * 2 * P;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        int i = lane;
+        for (; i + 64 < P; i += 128) {
+            const double g0 = g[i], g1 = g[i + 64];
+            const double s0 = W[i], s1 = W[i + 64], h0 = W[P + i], h1 = W[P + i + 64];
+            a0 = fma(s0, g0, a0);
+            a1 = fma(s1, g1, a1);
+            b0 = fma(h0, g0, b0);
+            b1 = fma(h1, g1, b1);
+        }
+        if (i < P) {
+            a0 = fma(W[i], g[i], a0);
+            b0 = fma(W[P + i], g[i], b0);
+        }
+        double a = a0 + a1, b = b0 + b1;
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (lane == 0) {
+            const size_t q = ((size_t)r * Kmax + j) * 2;
+            const double c0 = cs[q], rho = cs[q + 1];
+            ab[q] = c0 * a - rho * b;
+            ab[q + 1] = -rho * a;
+        }
+    }
+    __syncthreads();                                         // the coefficients are in memory for the whole workgroup
+    constexpr int NVB = (NT >= 512) ? NT / 512 : 1;          // groups of eight waves
+    constexpr int WPG = (NT >= 512) ? 8 : NT / 64;           // (a 256-thread block: one group of four -- not used)
+    static_assert(NT >= 512 && NT % 512 == 0, "pgl_bfgs_hist_row: whole groups of eight waves");
+    const int vb = wv / WPG, w = wv % WPG;
+    const int nblk = (P + 63) / 64;
+    const double* __restrict__ c = ab + (size_t)r * Kmax * 2;
+    for (int b0 = 0; b0 < nblk; b0 += NVB) {
+        const int blk = b0 + vb;
+        const int i = blk * 64 + lane;
+        const bool in = blk < nblk && i < P;
+        const double* __restrict__ W = Wh + (size_t)r * Kmax * 2 * P + (in ? i : 0);
+        double acc0 = 0.0, acc1 = 0.0;
+        int j = w;
+        for (; j + 8 < K; j += 16) {
+            const double* u0 = W + (size_t)j * 2 * P;
+            const double* u1 = W + (size_t)(j + 8) * 2 * P;
+            const double s0 = u0[0], h0 = u0[P], s1 = u1[0], h1 = u1[P];
+            acc0 = fma(s0, c[2 * j], acc0);
+            acc0 = fma(h0, c[2 * j + 1], acc0);
+            acc1 = fma(s1, c[2 * j + 16], acc1);
+            acc1 = fma(h1, c[2 * j + 17], acc1);
+        }
+        if (j < K) {
+            const double* u0 = W + (size_t)j * 2 * P;
+            acc0 = fma(u0[0], c[2 * j], acc0);
+            acc0 = fma(u0[P], c[2 * j + 1], acc0);
+        }
+        part[wv][lane] = acc0 + acc1;
+        __syncthreads();
+        if (w == 0 && in) {
+            double t = v.hscale[r] * v.g[(size_t)r * P + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += part[vb * 8 + q][lane];
+            v.t[(size_t)r * P + i] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// One iteration of the lock-step optimiser for the listed rows, one workgroup per row: the phases an evaluation is followed
+// by, selected by `phases` so that the same code serves the one-launch form and the split form around the multi-workgroup
+// inverse-Hessian kernels (k_bfgs_hdots + k_bfgs_hcomb for long histories, k_bfgs_hmul for dense matrices):
+//   PGL_STEP_LS     priors + NaN rules on the evaluation's (ll, grad) (have_prior; else f, g arrive final), line-search step
+//   PGL_STEP_HIST   t = H g from the update history of a row that has just taken a step (NT >= 512)
+//   PGL_STEP_UPDATE BFGS update / restart / freeze / convergence, next direction and first step; then the row's next trial
+//                   point into Xt_next[pos_next[r]] (the list of the NEXT launch: pos_next null = same positions) and its
+//                   active flag into flags_out[r] (host-visible memory: the driver reads it without a copy kernel)
+// The rows are the evaluation's list (rows[j], null: j); Xt / ft / gt are indexed by list position.
+#define PGL_STEP_LS 1
+#define PGL_STEP_HIST 2
+#define PGL_STEP_UPDATE 4
+struct BfgsStepArgs {
+    const int* rows;
+    const double* Xt;
+    double* ft;
+    double* gt;
+    BfgsPrior q;
+    int have_prior, max_trials, maxiter, init_scaling, Kmax, phases;
+    double gtol;
+    double* Wh;
+    double* cs;
+    double* ab;
+    const int* pos_next;
+    double* Xt_next;
+    double* flags_out;
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bfgs_step(const BfgsView v, const BfgsStepArgs a)
+{
+    __shared__ double red[4];
+    __shared__ int dec[3];
+    __shared__ double part[(NT >= 512) ? NT / 64 : 1][64];
+    const int j = blockIdx.x, r = a.rows ? a.rows[j] : j, tid = threadIdx.x, P = v.P;
+    if (a.phases & PGL_STEP_LS) {
+        if (a.have_prior && v.active[r] != 0.0)
+            pgl_bfgs_objective_row(P, a.Xt + (size_t)j * P, a.gt + (size_t)j * P, a.ft + j, a.q, red, tid);
+        __syncthreads();                                     // f, g of the trial are in memory for the whole workgroup
+        pgl_bfgs_linesearch_row(v, r, a.Xt + (size_t)j * P, a.ft + j, a.gt + (size_t)j * P, a.max_trials, red, dec, tid);
+        __syncthreads();
+    }
+    if constexpr (NT >= 512) {
+        if ((a.phases & PGL_STEP_HIST) && a.Wh) {
+            pgl_bfgs_hist_row<NT>(v, r, a.Wh, a.cs, a.Kmax, a.ab, part, tid);
+            __syncthreads();
+        }
+    }
+    if (a.phases & PGL_STEP_UPDATE) {
+        pgl_bfgs_update_row(v, r, a.gtol, a.maxiter, a.init_scaling, a.Wh, a.cs, a.Kmax, red, tid);
+        __syncthreads();
+        if (a.Xt_next) {
+            const int jn = a.pos_next ? a.pos_next[r] : j;
+            if (jn >= 0) {
+                const double al = v.alpha[r];
+                for (int c = pgl_row_c0(tid, P); c < P; c += 256)
+                    a.Xt_next[(size_t)jn * P + c] = fma(al, v.p[(size_t)r * P + c], v.X[(size_t)r * P + c]);
+            }
+        }
+        if (a.flags_out && tid == 0)
+            __hip_atomic_store(a.flags_out + r, v.active[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -7,8 +7,8 @@ runs as one batched BFGS: per trial step one fused ll+grad launch on device poin
 optimizer itself as HIP row kernels (pgl_bfgs_*: one workgroup per neuron) -- the algorithm scipy runs for
 the reference (BFGS from H = I, More'-Thuente strong-Wolfe line search with scipy's constants and first
 trial step, csrc/pglm_linesearch.h), so a neuron's iterates are those of its sequential scipy fit up to
-rounding; the dense inverse Hessians (M x P x P) are read and written once per accepted iteration
-(pgl_bfgs_hmul_dev).  Nothing but the active flags crosses PCIe.  PyTorch is plumbing here (device memory,
+rounding until a line search reports a warning (scipy stops there; see fit_glms_batched_torch); the inverse
+Hessians stay implicit (update history) or, for tiny problems, dense (M x P x P, one pass per accepted iteration).  Nothing but the active flags crosses PCIe.  PyTorch is plumbing here (device memory,
 and the chain rules / priors of the packings whose rows are not the device's own theta rows).
 
 Every packing of coord_descent's per-neuron vector that the scoped models produce is served
@@ -214,20 +214,23 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     the history could outgrow the matrix several times over), then dense.
 
     Everything runs on one dedicated torch stream that the device handles are switched to
-    (pgl_set_stream): trial points, the fused ll+grad launches, priors, the line-search steps and the
-    inverse-Hessian passes are ordered by the stream, and the host never waits for the launch it has
-    just queued.  What steers the loop -- which neurons are still active -- reaches the host `lag`
-    launches late (default 1) through pinned memory: the active set only ever shrinks, so a launch over the
-    stale (larger) list evaluates a few rows whose results the row kernels ignore, and the host keeps
-    queueing while the GPU is busy with the previous evaluations.  Neurons that have converged
-    drop out of the launch list (pgl_ll_grad_list_dev evaluates an arbitrary list of neurons), so late,
-    poorly conditioned neurons do not pay for the whole population.
+    (pgl_set_stream).  One trial step of all unfinished neurons is TWO host calls: the fused ll+grad evaluation of the
+    listed neurons (pgl_ll_grad_list_dev), and pgl_bfgs_step_dev for everything behind it -- priors and NaN rules,
+    the line-search step, t = H g for the rows that took a step, the BFGS update, the next direction and the trial
+    points of the next launch -- as ONE row kernel while the update history is short (k_bfgs_step<1024>; long histories:
+    line search | k_bfgs_hdots | k_bfgs_hcomb | update).  The host never waits for the launch it has just queued: which
+    neurons are still active reaches it through pinned memory the row kernel writes itself, read after the evaluation
+    of the NEXT launch has been queued (`lag` more launches late if > 0; default 0): the active set only ever
+    shrinks, so a launch over the stale (larger) list evaluates a few rows whose results the row kernels ignore.
+    Neurons that have converged drop out of the launch list (pgl_ll_grad_list_dev evaluates an arbitrary list of
+    neurons), so late, poorly conditioned neurons do not pay for the whole population.
 
     Every neuron runs its own state machine -- "line search at step alpha along p" -- and every launch
     evaluates the pending trial step of the listed neurons, whichever iteration each of them is in: a neuron
-    whose step is accepted moves on without waiting for the others.  Where scipy's BFGS gives up on a line
-    search ("precision loss", coord_descent.py:194-199) the neuron takes the best sufficient-decrease step of
-    that search if there is one, else restarts once from steepest descent, then is frozen.
+    whose step is accepted moves on without waiting for the others.  Up to the first line-search warning a neuron's
+    iterates are scipy's (up to rounding); where scipy's BFGS gives up on a line search ("precision loss",
+    coord_descent.py:194-199) the neuron takes the best sufficient-decrease step of that search if there is one,
+    else restarts once from steepest descent, then is frozen.
 
     `init_scaling`: scale the identity of a (re)started inverse Hessian by s.y / y.y before the first update
     (Nocedal & Wright 6.20).  Off by default, like scipy's BFGS.
@@ -255,6 +258,11 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     if hessian_bytes is None:
         hessian_bytes = 0.4 * torch.cuda.mem_get_info(dev)[0]
     group = M if hessian_bytes >= per_neuron * M else max(1, int(hessian_bytes / per_neuron))
+    if reduce is not None:
+        # a time-sharded fit: every rank must run the identical sequence of launches with identically sized
+        # all-reduces, but the free memory the default budget is taken from differs between ranks
+        from theano_pyglm_amd import parallel as PL
+        group = PL.allreduce_min_int(group, dev)
     if group < M:
         nlps, its, evs, stats = [], 0, 0, None
         for lo in range(n_lo, n_hi, group):
@@ -268,7 +276,7 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
                 stats = dict(st, per_neuron={k: list(v) for k, v in st['per_neuron'].items()}, groups=1)
             else:
                 for k in ('evaluations', 'neuron_evaluations', 'line_search_steps', 'neuron_iterations', 'converged_gtol',
-                          'stalled', 'maxiter'):
+                          'stalled', 'maxiter', 'launch_cap'):
                     stats[k] += st[k]
                 stats['iterations'] = max(stats['iterations'], st['iterations'])
                 for k in stats['per_neuron']:
@@ -280,14 +288,18 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     for data in population.data_sequences:
         population.set_data(data)
         handles.append(population._handle(data))
-    stream = torch.cuda.Stream(dev)
+    # the optimiser's stream: one per device, kept between fits (a fresh stream costs its first wait ~6 ms: the hardware
+    # queue behind it is created on first use)
+    stream = _STREAMS.get(dev.index)
+    if stream is None:
+        stream = _STREAMS[dev.index] = torch.cuda.Stream(dev)
     stream.wait_stream(torch.cuda.current_stream(dev))        # whatever the caller queued comes first
     for h in handles:
         h.set_stream(stream.cuda_stream)
     try:
         with torch.cuda.stream(stream):
             out = _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M,
-                                 verbose, reduce, 1 if lag is None else max(0, int(lag)), init_scaling, max_trials, hessian)
+                                 verbose, reduce, 0 if lag is None else max(0, int(lag)), init_scaling, max_trials, hessian)
             stream.synchronize()
     finally:
         # also on the error path: kernels still queued on `stream` read the optimizer state and the handles' scratch;
@@ -301,8 +313,31 @@ def fit_glms_batched_torch(population, x, maxiter=225, gtol=1e-5, n_lo=0, n_hi=N
     return out
 
 
+_HOST_BUFFERS = {}
+_STREAMS = {}
+
+
+def _host_buffers(torch, M, nring):
+    """Pinned flag buffers, events and list staging of a fit, kept between fits (a pinned allocation costs a driver call
+    of ~0.1 ms, and coord_descent runs one fit per sweep): {(M, nring): (flags, events, staging)}."""
+    key = (int(M), int(nring))
+    hb = _HOST_BUFFERS.get(key)
+    if hb is None:
+        if len(_HOST_BUFFERS) > 16:
+            _HOST_BUFFERS.clear()
+        hb = ([torch.ones(M, dtype=torch.float64).pin_memory() for _ in range(nring)],
+              [torch.cuda.Event() for _ in range(nring)],
+              [torch.empty(3 * M, dtype=torch.int32).pin_memory() for _ in range(nring + 2)])
+        _HOST_BUFFERS[key] = hb
+    return hb
+
+
 def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_lo, n_hi, M, verbose, reduce,
                    lag, init_scaling, max_trials, hessian='dense'):
+    """The launch loop.  Per trial step: the fused ll+grad evaluation of the listed neurons on every data sequence
+    (+ `reduce`), then ONE call -- pgl_bfgs_step_dev -- for everything behind it: priors, line-search step, t = H g,
+    update, and the trial points of the next launch's list (one row kernel while the update history is short)."""
+    from theano_pyglm_amd._lib import PglError
     pk = _Packing(population, torch, handles, (n_lo, n_hi))
     h0 = handles[0]
     P = pk.Pp                                                 # length of an optimisation row
@@ -315,11 +350,11 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
     sc = st[15 * MP:].view(-1, M)
     f, iters, active, frozen, nfev = sc[0], sc[6], sc[8], sc[9], sc[16]
     if hessian == 'dense':
-        # dense inverse Hessians: touched by pgl_bfgs_hmul_dev only, written before they are read
+        # dense inverse Hessians: touched by k_bfgs_hmul only, written before they are read
         H = torch.empty((M, P, ld), dtype=torch.float64, device=dev)
         hist = coef = cb = None
     else:
-        # the update history (s_j, H y_j) [M][maxiter][2][P] and its scalars (written by pgl_bfgs_update_dev before read)
+        # the update history (s_j, H y_j) [M][maxiter][2][P] and its scalars (appended by the update phase before read)
         H = None
         hist = torch.empty((M, maxiter, 2, P), dtype=torch.float64, device=dev)
         coef = torch.empty((M, maxiter, 2), dtype=torch.float64, device=dev)
@@ -328,20 +363,23 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
     Weff = torch.tensor(population.W_eff(x), dtype=torch.float64, device=dev)
     prm = pk.prior_params() if pk.identity else None
     n_evals, neuron_evals = [0], [0]
+    # per data sequence one [ll | grad] block, reused by every launch (everything is ordered by the stream)
+    bufs = [torch.empty(M * (1 + Pth), dtype=torch.float64, device=dev) for _ in handles]
 
     def evaluate(Xt, rows32, idx32, L):
-        """f = -(log prior + sum_data ll) and its gradient (fit_glm's NaN rules applied) at the L rows Xt of the
-        neurons idx32 (None: the whole shard); returned as (L,), (L, P) contiguous tensors."""
+        """The evaluation of the L rows Xt of the neurons idx32 (None: the whole shard).  Returns (f, g, prior): rows that
+        ARE theta rows come back as the summed (ll, grad) of the data sequences with prior = the parameters the row
+        kernel adds them with; other packings as f = -(log prior + ll) and its gradient (fit_glm's NaN rules applied), prior None."""
         scatter = idx32 is not None and not pk.list_launch
         if scatter:
             # no neuron lists on this device path: the whole shard with the trial rows scattered into the current point
             Xe = X.index_copy(0, rows32.long(), Xt)
-            th, ecnt, eidx = pk.theta(Xe), M, None
+            th, ecnt, eidx = (Xe if pk.identity else pk.theta(Xe)), M, None
         else:
             th, ecnt, eidx = (Xt if pk.identity else pk.theta(Xt)), L, idx32
         tot = None
-        for h in handles:
-            buf = torch.empty(ecnt * (1 + Pth), dtype=torch.float64, device=dev)      # [ll | grad]: one all-reduce
+        for h, full in zip(handles, bufs):
+            buf = full[:ecnt * (1 + Pth)]                      # [ll | grad]: one all-reduce
             if eidx is None:
                 h.ll_grad_dev(th.data_ptr(), Weff.data_ptr(), buf.data_ptr(), buf[ecnt:].data_ptr(), n_lo, n_hi)
             else:
@@ -352,80 +390,110 @@ def _lockstep_bfgs(population, torch, dev, stream, handles, x, maxiter, gtol, n_
             tot = buf if tot is None else tot.add_(buf)
         n_evals[0] += 1
         neuron_evals[0] += ecnt
-        if pk.identity:                                       # rows are theta rows: priors + NaN rules in one row kernel
-            h0.bfgs_objective_dev(L, P, Xt.data_ptr(), tot.data_ptr(), tot[L:].data_ptr(), *prm)
-            return tot[:L], tot[L:].view(L, P)
         llt, Gth = tot[:ecnt], tot[ecnt:].view(ecnt, Pth)
         if scatter:
-            llt, Gth = llt[rows32.long()], Gth[rows32.long()]
+            llt, Gth = llt[rows32.long()].contiguous(), Gth[rows32.long()].contiguous()
+        if pk.identity:                                       # priors + NaN rules: the row kernel's first phase
+            return llt, Gth, prm
         lp, G = pk.prior(Xt)
         fv = -(lp + llt)
         gv = -(G + pk.chain(Xt, Gth))
         fv = torch.where(torch.isnan(fv), torch.full_like(fv, 1e16), fv)
         gv = torch.where(torch.isnan(gv).any(1)[:, None], torch.zeros_like(gv), gv)
-        return fv.contiguous(), gv.contiguous()
+        return fv.contiguous(), gv.contiguous(), None
 
-    f0, g0 = evaluate(X, None, None, M)
+    def evaluate_list(Xt, rows32, idx32, L):
+        try:
+            return evaluate(Xt, rows32, idx32, L)
+        except PglError:
+            # a list length whose launch plan the device path does not serve (probed in _Packing for the whole shard and
+            # a single neuron only): from here on the whole shard with the trial rows scattered into the current point
+            if idx32 is None or not pk.list_launch:
+                raise
+            pk.list_launch = False
+            return evaluate(Xt, rows32, idx32, L)
+
+    f0, g0, pr0 = evaluate(X, None, None, M)
+    if pr0 is not None:
+        h0.bfgs_objective_dev(M, P, X.data_ptr(), f0.data_ptr(), g0.data_ptr(), *pr0)
     f.copy_(f0)
     g.copy_(g0)
     h0.bfgs_init_dev(st.data_ptr(), M, P, gtol)
-    max_launches = maxiter * 20 + 2
-    ring = [torch.empty(M, dtype=torch.float64).pin_memory() for _ in range(lag + 1)]
-    pending = []
-
-    def publish(k):
-        hb = ring[k % (lag + 1)]
-        hb.copy_(active, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        pending.append((hb, ev))
-
-    publish(0)
+    Xts = [torch.empty((M, P), dtype=torch.float64, device=dev) for _ in range(2)]
+    h0.bfgs_trial_dev(st.data_ptr(), M, P, 0, M, Xts[0].data_ptr())
+    # a search takes at most max_trials steps, an iteration one search (+ one launch for a restart)
+    max_launches = maxiter * (max_trials + 1) + 2
+    nring = lag + 2
+    ring, events, stage = _host_buffers(torch, M, nring)
+    for fl in ring:
+        fl.fill_(1.0)
+    # a new launch list travels as ONE copy of [position of every row in it | its rows | its neurons] (int32)
+    lists = torch.empty((2, 3 * M), dtype=torch.int32, device=dev)
+    nlist = 0
+    pending = {}                                              # launch -> (flags, event, rows of its list)
+    rows_h = np.arange(M, dtype=np.int32)
     rows32, idx32, L = None, None, M
-    launches = 0
-    while launches < max_launches:
-        if len(pending) > lag:
-            hb, ev = pending.pop(0)
-            ev.synchronize()                                    # a launch `lag` back: normally long done
-            act_h = hb.numpy() != 0.0
-            n_act = int(act_h.sum())
-            if n_act == 0:
-                break
-            if n_act < L:
-                idx_h = np.nonzero(act_h)[0].astype(np.int32)
-                L = n_act
-                rows32 = torch.from_numpy(idx_h).to(dev, non_blocking=True)
-                idx32 = rows32 + n_lo
-            if verbose:
-                print("batched BFGS launch %d: %d neurons active %d launches ago, list of %d"
-                      % (launches, n_act, lag, L))
+    launches, cut = 0, False
+    while True:
+        if launches >= max_launches:
+            cut = True
+            break
         launches += 1
-        Xt = torch.empty((L, P), dtype=torch.float64, device=dev)
-        rp = rows32.data_ptr() if rows32 is not None else 0
-        h0.bfgs_trial_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr())
-        ft, gt = evaluate(Xt, rows32, idx32, L)
-        h0.bfgs_linesearch_dev(st.data_ptr(), M, P, rp, L, Xt.data_ptr(), ft.data_ptr(), gt.data_ptr(), max_trials)
-        if H is not None:
-            h0.bfgs_hmul_dev(st.data_ptr(), M, P, rp, L, H.data_ptr(), ld)   # rows that moved: H += U V^T, t = H g
-            h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling)
-        else:
-            h0.bfgs_hmul_hist_dev(st.data_ptr(), M, P, rp, L, hist.data_ptr(), coef.data_ptr(), maxiter, cb.data_ptr())
-            h0.bfgs_update_dev(st.data_ptr(), M, P, gtol, maxiter, init_scaling, hist.data_ptr(), coef.data_ptr(), maxiter)
-        publish(launches)
-    it = int(iters.max())
-    gmax = g.abs().amax(1)
+        cur, nxt = Xts[(launches - 1) & 1], Xts[launches & 1]
+        ft, gt, prior = evaluate_list(cur[:L], rows32, idx32, L)
+        # the next launch's list, from the flags the step `lag` + 1 launches back has written (normally long done:
+        # the host queues this launch's step while the GPU is busy with its evaluation)
+        nrows32, nidx32, nL, nrows_h, pos = rows32, idx32, L, rows_h, None
+        k = launches - 1 - lag
+        if k in pending:
+            fl, ev, lrows = pending.pop(k)
+            ev.synchronize()
+            alive = lrows[fl.numpy()[lrows] != 0.0]
+            if alive.size == 0:
+                break
+            if alive.size < L:
+                nrows_h, nL = alive, int(alive.size)
+                sg = stage[nlist % len(stage)].numpy()         # (a slot is reused nring list changes later: long copied)
+                sg[:M] = -1
+                sg[alive] = np.arange(nL, dtype=np.int32)
+                sg[M:M + nL] = alive
+                sg[2 * M:2 * M + nL] = alive + n_lo
+                dl = lists[nlist & 1]
+                dl.copy_(stage[nlist % len(stage)], non_blocking=True)
+                nlist += 1
+                pos, nrows32, nidx32 = dl[:M], dl[M:M + nL], dl[2 * M:2 * M + nL]
+            if verbose:
+                print("batched BFGS launch %d: %d neurons active after launch %d, next list %d" % (launches, alive.size, k, nL))
+        slot = launches % nring
+        h0.bfgs_step_dev(st.data_ptr(), M, P, rows32.data_ptr() if rows32 is not None else 0, L, cur.data_ptr(),
+                         ft.data_ptr(), gt.data_ptr(), prior, max_trials, gtol, maxiter, init_scaling,
+                         hist.data_ptr() if hist is not None else 0, coef.data_ptr() if coef is not None else 0,
+                         maxiter if hist is not None else 0, cb.data_ptr() if cb is not None else 0, launches - 1,
+                         H.data_ptr() if H is not None else 0, ld if H is not None else 0,
+                         pos.data_ptr() if pos is not None else 0, nxt.data_ptr(), ring[slot].data_ptr())
+        events[slot].record(stream)
+        pending[launches] = (ring[slot], events[slot], rows_h)
+        rows32, idx32, L, rows_h = nrows32, nidx32, nL, nrows_h
+    # one copy of the state's head (X, g) and one of its scalars; the statistics are host arithmetic
+    Xg = st[:2 * MP].cpu().numpy()
+    sch = sc.cpu().numpy()
+    Xh, gh = Xg[:MP].reshape(M, P), Xg[MP:].reshape(M, P)
+    fh, itv, acth, frozh, nfevh = sch[0], sch[6], sch[8], sch[9], sch[16]
+    it = int(itv.max())
+    gmax = np.abs(gh).max(axis=1)
     n_conv = int((gmax <= gtol).sum())
-    n_frozen = int(((frozen != 0) & (gmax > gtol)).sum())
-    pk.unpack(x, X.cpu().numpy(), n_lo, n_hi)
+    n_frozen = int(((frozh != 0) & (gmax > gtol)).sum())
+    n_cut = int((acth != 0).sum()) if cut else 0              # rows the launch cap cut off in the middle of a search
+    pk.unpack(x, Xh, n_lo, n_hi)
     population.last_fit_stats = {'iterations': it, 'evaluations': n_evals[0],
                                  'neuron_evaluations': neuron_evals[0],
-                                 'line_search_steps': int(nfev.sum()),
-                                 'neuron_iterations': int(iters.sum()),
+                                 'line_search_steps': int(nfevh.sum()),
+                                 'neuron_iterations': int(itv.sum()),
                                  'converged_gtol': n_conv, 'stalled': n_frozen,
-                                 'maxiter': M - n_conv - n_frozen,
+                                 'maxiter': M - n_conv - n_frozen - n_cut, 'launch_cap': n_cut,
                                  'bookkeeping': 'hip row kernels' + ('' if pk.identity else ' (priors / chain rule: torch)'),
                                  'line_search': "More'-Thuente strong Wolfe (scipy's DCSRCH constants)",
                                  'lag': lag, 'init_scaling': bool(init_scaling), 'inverse_hessian': hessian,
-                                 'per_neuron': {'iterations': [int(v) for v in iters.cpu().numpy()],
-                                                'line_search_steps': [int(v) for v in nfev.cpu().numpy()]}}
-    return f.cpu().numpy(), it, n_evals[0]
+                                 'per_neuron': {'iterations': [int(v) for v in itv],
+                                                'line_search_steps': [int(v) for v in nfevh]}}
+    return fh.copy(), it, n_evals[0]

@@ -140,6 +140,19 @@ def allreduce_sum_t(t):
     return t
 
 
+def allreduce_min_int(value, device=None):
+    """The minimum of a host integer over all ranks (itself without a process group): how every rank of a time-sharded
+    fit arrives at the SAME neuron-group size although the free device memory differs from rank to rank."""
+    import torch
+    dist = _dist()
+    if alone():
+        return int(value)
+    on_dev = dist.get_backend() != 'gloo' and device is not None
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_dev else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t[0])
+
+
 def allreduce_sum(local, device=None):
     """numpy front end of allreduce_sum_t (float64)."""
     import torch

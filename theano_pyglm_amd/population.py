@@ -188,13 +188,19 @@ class Population(object):
     def W_eff(self, vars):
         return self.network.W_eff(vars['net'])
 
-    def _check_vars(self, vars, n):
-        """Mirror of seval's binding check (theano_func_wrapper.py:69-105)."""
-        syms = self.get_variables()
-        nv = self.extract_vars(vars, n)
-        check_bound({'net': syms['net']}, nv)
-        glm_syms = dict((k, v) for k, v in syms['glm'].items() if k != 'n')
-        check_bound(glm_syms, nv['glm'])
+    def _check_vars(self, vars, n=None):
+        """Mirror of seval's binding check (theano_func_wrapper.py:69-105): every symbol of the network and of the listed
+        neuron's GLM (n None: of every neuron) must have a value.  The symbol tables are those of the model and do not
+        change: built once."""
+        cache = getattr(self, '_bound_syms', None)
+        if cache is None:
+            syms = self.get_variables()
+            cache = ({'net': syms['net']}, dict((k, v) for k, v in syms['glm'].items() if k != 'n'))
+            self._bound_syms = cache
+        net_syms, glm_syms = cache
+        check_bound(net_syms, vars)
+        for m in (range(self.N) if n is None else (n,)):
+            check_bound(glm_syms, vars['glms'][m])
 
     # -- log probability ---------------------------------------------------------------
     def compute_log_prior(self, vars):
@@ -202,8 +208,8 @@ class Population(object):
         lp = 0.0
         lp += self.latent.log_p(vars.get('latent', {}))
         lp += self.network.log_p(vars['net'])
+        self._check_vars(vars)
         for n in range(self.N):
-            self._check_vars(vars, n)
             lp += self.glm.log_prior(vars['glms'][n])
         return lp
 
@@ -219,8 +225,7 @@ class Population(object):
 
     def compute_ll(self, vars):
         """population.py:71-86: sum over neurons of glm.ll on the current data."""
-        for n in range(self.N):
-            self._check_vars(vars, n)
+        self._check_vars(vars)
         return float(np.sum(self.compute_ll_vector(vars)))
 
     def compute_log_p(self, vars):
