@@ -43,7 +43,11 @@ typedef struct pgl_context* pgl_handle;
 #define PGL_NLIN_EXPLINEAR 1   /* nlin.py:43 */
 
 /* flags for pgl_set_option */
-#define PGL_OPT_FEATURE_F32 1  /* 1: stage the feature tile in LDS as f32 (default 0 = f64) */
+#define PGL_OPT_FEATURE_F32 1  /* 0 (default): f64 features.  1: the in-kernel-feature kernels stage the feature tile in LDS as f32.
+                                * 2: reduced-traffic mode for narrow shards -- the RESIDENT feature blocks of the one-post-tile
+                                * kernel (a shard of <= 16 neurons against a 400..640-column row: north star's neuron split at
+                                * 8 GPUs) are STORED as f32 and widened to f64 on their way into LDS; every arithmetic operation
+                                * stays f64, only the stored feature is rounded (2^-24 relative).  Other shapes ignore it. */
 #define PGL_OPT_NCHUNKS 2      /* override the number of time chunks (0 = auto) */
 #define PGL_OPT_KERNEL 3       /* 0 = auto: two-pass kernel on resident tiles for >= 65 post-synaptic neurons per call;
                                 * below that the K-split kernel, on resident feature tiles (6) when the

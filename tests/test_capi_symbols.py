@@ -92,9 +92,9 @@ def test_dispatched_kernels_exist_and_use_no_scratch():
     assert not spill, "kernels with scratch / spilled VGPRs: %s" % spill
     # the named configurations dispatch to the kernels DESIGN.md names
     from theano_pyglm_amd import _lib
-    assert _lib.plan_kernels(128, B=5, R=200, nT=600000) == ['k_fused5<18, 22, 1, 0, 0>', 'k_fused5<18, 22, 2, 0, 0>']
+    assert _lib.plan_kernels(128, B=5, R=200, nT=600000) == ['k_fused5<18, 22, 1, 0, 0, 0>', 'k_fused5<18, 22, 2, 0, 0, 0>']
     # (north star's neuron split at 8 GPUs: a 16-neuron shard of C3 -- one post tile against the 640-column row)
-    assert _lib.plan_kernels(128, B=5, R=200, nT=600000, n_lo=32, count=16) == ['k_fused8<5, 8>']
+    assert _lib.plan_kernels(128, B=5, R=200, nT=600000, n_lo=32, count=16) == ['k_fused8<5, 8, 0>']
     assert _lib.plan_kernels(32, B=5, R=200, nT=300000) == ['k_fused6<5, 2, 1, 4, 1>']
     assert _lib.plan_kernels(64, B=3, R=300, Dstim=9, nT=300000) == ['k_fused7<13, 4, 0>']
     assert _lib.plan_kernels(64, B=3, R=300, Dstim=3 + 1024, nT=300000, stim=2) == ['k_fused7<12, 4, 3>']

@@ -1033,7 +1033,7 @@ def test_long_recording_offsets_beyond_2_31_elements():
     assert np.allclose(ll_s, ll, rtol=1e-13) and H.rel_err(g_s, g) < 1e-13
     # a 16-neuron shard of the whole recording: block-form images (23 GB, byte offsets beyond 2^34) through k_fused8
     big.set_time_range(0, nT)
-    assert _lib.plan_kernels(N, B=B, R=R, nT=nT, n_lo=48, count=16) == ['k_fused8<5, 8>']
+    assert _lib.plan_kernels(N, B=B, R=R, nT=nT, n_lo=48, count=16) == ['k_fused8<5, 8, 0>']
     a, b = big.ll_grad(theta[48:64], Weff, 48, 64)
     assert np.allclose(a, ll[48:64], rtol=1e-12) and H.rel_err(b, g[48:64]) < 1e-12
     for lo in (0, nT - L):

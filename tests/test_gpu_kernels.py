@@ -444,6 +444,45 @@ def test_two_pass_kernel_shapes_and_agreement():
     d2.close()
 
 
+def test_two_pass_kernel_helper_waves():
+    """k_fused5<.., HLP = 1>: in a block of five or six post tiles (N = 65 .. 96) the waves without a tile take over the
+    second half of the forward k-steps (pass 1) and of the k-tiles (pass 2) of two tiles.  Against the oracle, and against
+    the same launch without helpers (dev option 92): tiles without a helper agree bit for bit, helped tiles to rounding
+    (their currents are the sum of two partial sums); list launches of 70 / 90 neurons (a lock-step sweep's shapes) and a
+    time range off the chunk grid included."""
+    from theano_pyglm_amd import _lib
+    for N, seed, kw in ((80, 90, {}), (96, 91, {}), (72, 92, {'weighted': True}), (88, 93, {'Dstim': 7})):
+        p = H.Problem(N, 4000, H.std_ibasis(), seed=seed, w_scale=0.5, **kw)
+        ll0, g0 = p.oracle_ll_grad()
+        d = p.device()
+        assert d.info()['kernel_version'] == 5
+        names = _lib.plan_kernels(N, B=p.B, R=p.R, Dstim=p.Dstim, nT=p.nT)
+        assert any(n.startswith('k_fused5<') and n.endswith(', 1>') for n in names), names
+        ll, g = d.ll_grad(p.theta, p.Weff)
+        assert np.allclose(ll, ll0, rtol=LL_RTOL) and H.rel_err(g, g0) < G_RTOL
+        d.set_option(92, 1)
+        lln, gn = d.ll_grad(p.theta, p.Weff)
+        d.set_option(92, 0)
+        nb = -(-N // 16)
+        helped = (0, 4) if nb == 5 else (0, 1)
+        for t in range(nb):
+            sl = slice(16 * t, min(16 * t + 16, N))
+            if t in helped:
+                assert np.allclose(ll[sl], lln[sl], rtol=1e-12) and H.rel_err(g[sl], gn[sl]) < 1e-12
+                assert not np.array_equal(g[sl], gn[sl])       # (the helper really took part)
+            else:
+                assert np.array_equal(ll[sl], lln[sl]) and np.array_equal(g[sl], gn[sl])
+        # ll only; a sub-range of the recording
+        llo, _ = d.ll_grad(p.theta, p.Weff, want_grad=False)
+        assert np.array_equal(llo, ll)
+        d.set_time_range(1008, 3001)
+        lla, ga = d.ll_grad(p.theta, p.Weff)
+        d.set_option(92, 1)
+        llb, gb = d.ll_grad(p.theta, p.Weff)
+        assert np.allclose(lla, llb, rtol=1e-12) and H.rel_err(ga, gb) < 1e-12
+        d.close()
+
+
 def test_forced_kernels_on_tiny_shapes():
     """Forcing the two-pass kernels on tiny problems (one k-tile per half, a single time tile, one
     neuron) must either run correctly or fall back to the K-split kernel -- never misbehave."""
@@ -880,7 +919,7 @@ def test_narrow_shard_block_ring_kernel():
         d2.set_option(_lib.OPT_KERNEL, 2)
         for lo, hi in ((32, 48), (N - 9, N), (5, 6)):
             names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], nT=nT, n_lo=lo, count=hi - lo)
-            assert names == ['k_fused8<5, 8>'], names
+            assert names == ['k_fused8<5, 8, 0>'], names
             assert d.info(lo, hi)['kernel_version'] == 6 and d2.info(lo, hi)['kernel_version'] == 2
             ll, g = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
             ll2, g2 = d2.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
@@ -910,3 +949,58 @@ def test_narrow_shard_block_ring_kernel():
         assert np.allclose(llt, llt2, rtol=1e-12) and H.rel_err(gt, gt2) < 1e-11
         d.close()
         d2.close()
+
+
+def test_narrow_shard_f32_resident_blocks():
+    """PGL_OPT_FEATURE_F32 = 2 (opt-in reduced-traffic mode, SURVEY §7 "Precision": f32 storage of features, f64
+    accumulation): the one-post-tile kernel streams f32 blocks (half the HBM bytes) and widens them to f64 on the way into
+    LDS -- k_fused8<5, 8, 1>.  Every arithmetic operation is f64; only the stored feature is rounded (2^-24 relative), so
+    the result sits ~1e-8 from the f64 path -- far inside north star's rtol 1e-5, far outside the 1e-10 of the default path,
+    which is why it is never the default.  Ranges, padding lanes, a neuron list, a time range off the tile grid, ll only,
+    both nonlinearities; other shapes ignore the option."""
+    import torch
+    from theano_pyglm_amd import _lib
+    worst_ll = worst_g = 0.0
+    for N, nT, nlin, bias in ((128, 5000, 'explinear', 20.0), (100, 3000, 'exp', -3.0), (80, 2100, 'explinear', -1.0)):
+        p = H.Problem(N, nT, H.std_ibasis(), kind=nlin, seed=N + nT, w_scale=0.3 if nlin == 'explinear' else 0.02,
+                      bias_mu=bias, weighted=(N == 100))
+        d = p.device()
+        d.set_option(_lib.OPT_FEATURE_F32, 2)
+        d0 = p.device()
+        for lo, hi in ((32, 48), (N - 9, N), (5, 6)):
+            names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], nT=nT, n_lo=lo, count=hi - lo, opt_f32=2)
+            assert names == ['k_fused8<5, 8, 1>'], names
+            i32, i64 = d.info(lo, hi), d0.info(lo, hi)
+            assert i32['kernel_version'] == 6 and abs(i32['resident_feature_bytes'] * 2 - i64['resident_feature_bytes']) < 1
+            ll, g = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+            ll0, g0 = d0.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+            assert not np.array_equal(g, g0)                       # (another path)
+            worst_ll = max(worst_ll, float(np.max(np.abs(ll - ll0) / np.abs(ll0))))
+            worst_g = max(worst_g, H.rel_err(g, g0))
+            assert np.allclose(ll, ll0, rtol=1e-6) and H.rel_err(g, g0) < 1e-6, (N, lo, hi)
+            ll_only, _ = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi, want_grad=False)
+            assert np.array_equal(ll_only, ll)
+        # the whole population (eight post tiles: the two-pass kernel) ignores the option: f64 images, same bits
+        llw, gw = d.ll_grad(p.theta, p.Weff)
+        llw0, gw0 = d0.ll_grad(p.theta, p.Weff)
+        assert np.array_equal(llw, llw0) and np.array_equal(gw, gw0)
+        # a list of 16 neurons in arbitrary order; a time range off the tile grid
+        idx = np.random.RandomState(N).permutation(N)[:16].astype(np.int32)
+        d_idx = torch.from_numpy(idx).cuda()
+        d_th = torch.from_numpy(np.ascontiguousarray(p.theta[idx])).cuda()
+        d_W = torch.from_numpy(np.ascontiguousarray(p.Weff)).cuda()
+        d_ll = torch.zeros(len(idx), dtype=torch.float64, device='cuda')
+        d_g = torch.zeros((len(idx), p.P), dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        d.ll_grad_list_dev(d_idx.data_ptr(), len(idx), d_th.data_ptr(), d_W.data_ptr(), d_ll.data_ptr(), d_g.data_ptr())
+        d.sync()
+        assert np.allclose(d_ll.cpu().numpy(), llw0[idx], rtol=1e-6) and H.rel_err(d_g.cpu().numpy(), gw0[idx]) < 1e-6
+        d.set_time_range(32, nT - 37)
+        d0.set_time_range(32, nT - 37)
+        llt, gt = d.ll_grad(p.theta[32:48], p.Weff, 32, 48)
+        llt0, gt0 = d0.ll_grad(p.theta[32:48], p.Weff, 32, 48)
+        assert np.allclose(llt, llt0, rtol=1e-6) and H.rel_err(gt, gt0) < 1e-6
+        d.close()
+        d0.close()
+    print("f32 resident blocks: worst relative deviation from the f64 path  ll %.1e  grad %.1e" % (worst_ll, worst_g))
+    assert worst_ll < 1e-6 and worst_g < 1e-6

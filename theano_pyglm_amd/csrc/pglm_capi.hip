@@ -89,7 +89,8 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1, opt_slice_cols = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1, opt_slice_cols = 0, opt_hlp = 0;
+    int opt_img32 = 0;                   // PGL_OPT_FEATURE_F32 = 2: f32 resident blocks for the narrow-shard kernel (k_fused8<.., 1>)
     long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
     bool timing_valid = false;
@@ -154,10 +155,12 @@ struct Plan {
     int tile0;
     int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
+    int hlp = 0;                        // version 5: 1 = idle waves of a 5- or 6-tile block help (k_fused5<.., HLP = 1>)
     int mt;                             // version 6: 16-bin tiles per step
     int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
     int sb6 = 0;                        // version 6: 1 = one image buffer per workgroup (k_fused6 DB = 0), 2 = per-wave block
                                         // rings on block-form images (k_fused8)
+    int img32 = 0;                      // ... whose blocks are stored as f32 (PGL_OPT_FEATURE_F32 = 2)
     int nw7, wg7;                       // version 7: waves per workgroup (1, 2, 4), workgroups per CU
     size_t lds7x = 0;                   // version 7: extra LDS of the separable-stimulus forms
     size_t lds;
@@ -215,16 +218,18 @@ static bool pick_pair(int need, int& ktl, int& kth)
 }
 static size_t img_pair_bytes(int ktl, int kth) { return (size_t)pgl_img_bytes(ktl) + pgl_img_bytes(kth); }
 // one-part images (k_fused6 / 7), padded rows or the block form of k_fused8: slot key and bytes per tile
-static int img_key6(int kt, bool blk) { return (blk ? 0x8000 : 0) | kt << 8; }
-static size_t img_bytes6(int kt, bool blk) { return blk ? (size_t)kt * 2048 : (size_t)pgl_img_bytes(kt); }
+// (blk: 0 padded rows, 1 blocks of 2 KB, 2 the same blocks stored as f32)
+static int img_key6(int kt, int blk) { return (blk ? 0x8000 : 0) | (blk == 2 ? 0x4000 : 0) | kt << 8; }
+static size_t img_bytes6(int kt, int blk) { return blk ? (size_t)kt * (blk == 2 ? 1024 : 2048) : (size_t)pgl_img_bytes(kt); }
 static constexpr int kRing8 = 8;            // k_fused8<5, kRing8>: blocks per wave
-static size_t lds_fused8(int ring) { return (size_t)8 * ring * 2048 + (size_t)(8 * 256 + 256 + 32 + 8 * 48) * 8; }
+static size_t lds_fused8(int slots) { return (size_t)8 * slots * 2048 + (size_t)(8 * 256 + 256 + 32 + 8 * 48) * 8; }
 
 static int fused6_wg_per_cu(const Plan& pl);
 
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
                      bool single_slice = true, bool force7 = false, bool wide = false)
 {
+    const bool hlp_ok = single_slice && !force7 && !wide;      // (the slab-input and column-slice forms have no helper variant)
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
     pl.nPT = (pl.npost + 15) / 16;
@@ -359,9 +364,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             if (mt6 > 0) {
                 const int ktall = ktw6 * (nw6 / ptw6);
                 bool ok = true;
-                if (h->opt_kernel == 0 && find_img(h, img_key6(ktall, pl.sb6 == 2), pl.tile0, pl.nTiles) < 0)
-                    ok = img_room(h, (size_t)pl.nTiles * img_bytes6(ktall, pl.sb6 == 2));
-                if (!ok) pl.sb6 = 0;
+                pl.img32 = (pl.sb6 == 2 && h->opt_img32) ? 1 : 0;
+                const int blk6 = (pl.sb6 == 2) ? 1 + pl.img32 : 0;
+                if (h->opt_kernel == 0 && find_img(h, img_key6(ktall, blk6), pl.tile0, pl.nTiles) < 0)
+                    ok = img_room(h, (size_t)pl.nTiles * img_bytes6(ktall, blk6));
+                if (!ok) pl.sb6 = pl.img32 = 0;
                 if (ok) {
                     pl.version = 6;
                     pl.mt = mt6; pl.nw6 = nw6; pl.PTW = ptw6; pl.KTW = ktw6; pl.KSPLIT = nw6 / ptw6;
@@ -413,7 +420,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     if (pl.version == 6) {
         // as many workgroups per CU as registers and LDS allow (4-wave form at C2: three)
         pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
-        if (pl.sb6 == 2) pl.lds = lds_fused8(kRing8);
+        if (pl.sb6 == 2) pl.lds = lds_fused8(pl.img32 ? 5 : kRing8);
         wgPerCU = (pl.sb6 == 2) ? 1 : fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
@@ -432,6 +439,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
     if (pl.version == 5) {
         pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8;   // + per-wave spike scratch
+        // the last block holds five or six post tiles: its idle waves help (plain two-pass form, rows from 10 k-tiles on;
+        // PGL_OPT_KERNEL 4 / dev option 92 = 1: never)
+        const int nb = pl.nPT % 8;
+        pl.hlp = (hlp_ok && (nb == 5 || nb == 6) && pl.ktl >= 5 && h->opt_hlp != 1) ? 1 : 0;
+        if (pl.hlp) pl.lds += 2 * 256 * 8;                                                         // + the helpers' partial currents
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }
@@ -441,7 +453,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     }
     if (pl.version == 6) {
         pl.lds = (size_t)(pl.sb6 ? 1 : 2) * pl.mt * pgl_img_bytes(pl.KT) + (size_t)pl.mt * pl.nw6 * 2048 + 256 + (size_t)pl.nw6 * 384;
-        if (pl.sb6 == 2) pl.lds = lds_fused8(kRing8);
+        if (pl.sb6 == 2) pl.lds = lds_fused8(pl.img32 ? 5 : kRing8);
         // chunks are whole steps of mt tiles
         pl.tilesPerChunk = (pl.tilesPerChunk + pl.mt - 1) / pl.mt * pl.mt;
         pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
@@ -574,16 +586,16 @@ static hipError_t launch_fused3(const Plan& pl, const FusedParams& fp, hipStream
 }
 
 // passes: 1, 2, or 0 = both back to back
-template <int KTL, int KTH, int XIN = 0>
+template <int KTL, int KTH, int XIN = 0, int HLP = 0>
 static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass)
 {
     if (g_dry) {
-        if (pass != 2) dry_record("k_fused5", {KTL, KTH, 1, XIN, 0});
-        if (pass != 1 && fp.want_grad) dry_record("k_fused5", {KTL, KTH, 2, 0, 0});
+        if (pass != 2) dry_record("k_fused5", {KTL, KTH, 1, XIN, 0, HLP});
+        if (pass != 1 && fp.want_grad) dry_record("k_fused5", {KTL, KTH, 2, 0, 0, HLP});
         return hipSuccess;
     }
-    auto k1 = k_fused5<KTL, KTH, 1, XIN>;
-    auto k2 = k_fused5<KTL, KTH, 2>;
+    auto k1 = k_fused5<KTL, KTH, 1, XIN, 0, HLP>;
+    auto k2 = k_fused5<KTL, KTH, 2, 0, 0, HLP>;
     const size_t lds2 = (size_t)2 * pgl_img_bytes(KTH) + 256;
     hipError_t e = ensure_dyn_lds(k1, pl.lds);
     if (e == hipSuccess) e = ensure_dyn_lds(k2, lds2);
@@ -602,6 +614,17 @@ static hipError_t launch_fused5_t(const Plan& pl, const FusedParams& fp, hipStre
 
 static hipError_t launch_fused5(const Plan& pl, const FusedParams& fp, hipStream_t s, int pass = 0)
 {
+    if (pl.hlp) {                                // blocks of five or six post tiles: the idle waves help (make_plan)
+        switch (pl.ktl << 8 | pl.kth) {
+        case 5 << 8 | 5: return launch_fused5_t<5, 5, 0, 1>(pl, fp, s, pass);
+        case 7 << 8 | 7: return launch_fused5_t<7, 7, 0, 1>(pl, fp, s, pass);
+        case 9 << 8 | 11: return launch_fused5_t<9, 11, 0, 1>(pl, fp, s, pass);
+        case 12 << 8 | 14: return launch_fused5_t<12, 14, 0, 1>(pl, fp, s, pass);
+        case 14 << 8 | 18: return launch_fused5_t<14, 18, 0, 1>(pl, fp, s, pass);
+        case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L, 0, 1>(pl, fp, s, pass);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.ktl << 8 | pl.kth) {
     case 1 << 8 | 1: return launch_fused5_t<1, 1>(pl, fp, s, pass);
     case 2 << 8 | 2: return launch_fused5_t<2, 2>(pl, fp, s, pass);
@@ -639,9 +662,9 @@ static hipError_t launch_fused5_wide_t(const Plan& pl, const FusedParams& fp, hi
 {
     const size_t lds2h = (size_t)2 * pgl_img_bytes(KTH) + 256, lds2l = (size_t)2 * pgl_img_bytes(KTL) + 256;
     if (g_dry) {
-        if (mode <= 1) dry_record("k_fused5", {KTL, KTH, 1, mode == 0 ? 2 : 3, 0});
-        else if (mode == 2) dry_record("k_fused5", {KTL, KTH, 1, 1, 0});
-        else dry_record("k_fused5", {KTL, KTH, 2, 0, mode == 4 ? 1 : 0});
+        if (mode <= 1) dry_record("k_fused5", {KTL, KTH, 1, mode == 0 ? 2 : 3, 0, 0});
+        else if (mode == 2) dry_record("k_fused5", {KTL, KTH, 1, 1, 0, 0});
+        else dry_record("k_fused5", {KTL, KTH, 2, 0, mode == 4 ? 1 : 0, 0});
         return hipSuccess;
     }
     hipError_t e = hipSuccess;
@@ -740,8 +763,15 @@ static hipError_t launch_fused6(const Plan& pl, const FusedParams& fp, hipStream
     }
     if (pl.sb6 == 2) {                             // one post tile of a 25 .. 40 k-tile row: per-wave block rings
         if (pl.mt != 1 || pl.PTW != 1 || pl.KTW != 5 || occ) return hipErrorInvalidValue;
-        auto kern = k_fused8<5, kRing8>;
-        if (dry_record("k_fused8", {5, kRing8})) return hipSuccess;
+        if (dry_record("k_fused8", {5, kRing8, pl.img32})) return hipSuccess;
+        if (pl.img32) {
+            auto kern = k_fused8<5, kRing8, 1>;
+            hipError_t e = ensure_dyn_lds(kern, pl.lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
+            return hipGetLastError();
+        }
+        auto kern = k_fused8<5, kRing8, 0>;
         hipError_t e = ensure_dyn_lds(kern, pl.lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
@@ -1016,10 +1046,11 @@ int pgl_set_option(pgl_handle h, int option, int value)
 {
     if (!h) return fail(PGL_ERR_ARG, "null handle");
     switch (option) {
-    case PGL_OPT_FEATURE_F32: h->opt_f32 = value ? 1 : 0; return PGL_OK;
+    case PGL_OPT_FEATURE_F32: h->opt_f32 = (value == 1) ? 1 : 0; h->opt_img32 = (value == 2) ? 1 : 0; return PGL_OK;
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
+    case 92: h->opt_hlp = value; return PGL_OK;              // dev: 1 = no helper waves in the two-pass kernel (A/B)
     case 93: h->opt_slice_cols = value; return PGL_OK;      // dev: feature columns per slice of the 3-phase path (0 = 640)
     case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels, 3 = stimulus current through the slab, 4 = residual slab + k_sepf_bwd (no fused backward)
     case 95: h->opt_sb6 = value; return PGL_OK;              // dev: 2 = never the one-buffer / block-ring forms
@@ -1719,11 +1750,11 @@ static hipError_t launch_any(const Plan& pl, const FusedParams& fp, hipStream_t 
 // features / time range.  A time-sharded rank (pgl_set_time_range) therefore builds and keeps only its
 // own 1/G of the recording.
 static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int ntiles, const Slice* sl = nullptr,
-                                 int slice_no = 0, bool blk = false)
+                                 int slice_no = 0, int blk = 0)
 {
     // kth == 0: one image per tile holding all ktl k-tiles (k_fused6; blk: as 2 KB blocks, k_fused8); else the L / H pair
     // of k_fused5.  sl: the images of ONE column slice of a wide population (key carries the slice number)
-    const int key = (sl ? (slice_no + 1) << 16 : 0) | (blk ? img_key6(ktl, true) : ktl << 8 | kth);
+    const int key = (sl ? (slice_no + 1) << 16 : 0) | (blk ? img_key6(ktl, blk) : ktl << 8 | kth);
     int slot = find_img(h, key, tile0, ntiles);
     if (slot >= 0) {
         h->img_cur = slot;
@@ -1749,7 +1780,7 @@ static int ensure_feature_images(pgl_handle h, int ktl, int kth, int tile0, int 
                        (const int2*)h->spk.p, (const int*)h->wlo.p, (const int*)h->whi.p,
                        (const double*)h->phi.p, (const double*)h->fstim.p, (long long)h->nT, sl ? sl->Ns : h->N, h->B,
                        h->Rk, sl ? sl->Ds : (h->sep ? 0 : h->Dstim), ktl, kth, tile0, (unsigned char*)im.buf.p,
-                       h->N, sl ? sl->np0 : 0, h->Dstim, sl ? sl->ds0 : 0, blk ? 1 : 0);
+                       h->N, sl ? sl->np0 : 0, h->Dstim, sl ? sl->ds0 : 0, blk);
     HIPCHK(hipGetLastError());
     im.key = key;
     im.tile0 = tile0;
@@ -1869,7 +1900,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
         if (rc) return rc;
         ENSURE(h->Xbuf, (size_t)pl.nTiles * pl.nPT * 256 * 8);
         rc = (pl.version == 5) ? ensure_feature_images(h, pl.ktl, pl.kth, pl.tile0, pl.nTiles)
-                               : ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, pl.version == 6 && pl.sb6 == 2);
+                               : ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, (pl.version == 6 && pl.sb6 == 2) ? 1 + pl.img32 : 0);
         if (rc) return rc;
         if (rec) HIPCHK(hipEventRecord(h->ev[1], h->stream));
         SepfParams sp;
@@ -1947,7 +1978,7 @@ static int enqueue_ll_grad(pgl_handle h, int n_lo, int n_hi, const double* d_the
             if (rc) return rc;
         }
         if (pl.version == 6 || pl.version == 7) {
-            rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, pl.version == 6 && pl.sb6 == 2);
+            rc = ensure_feature_images(h, pl.KT, 0, pl.tile0, pl.nTiles, nullptr, 0, (pl.version == 6 && pl.sb6 == 2) ? 1 + pl.img32 : 0);
             if (rc) return rc;
         }
         FusedParams fp;
@@ -2400,7 +2431,7 @@ int pgl_plan_kernels(int N, int B, int R, int Dstim, long long nT, int stim, int
     c.nT16 = (int)((nT + 15) / 16); c.t_lo = 0; c.t_hi = nT; c.numCU = 256;
     c.sep = stim >= 1; c.sepf = stim >= 2; c.sepA_ok = stim == 2; c.opt_sepf = 0;
     c.Ktot = c.Kimp + (c.sep ? 0 : Dstim);
-    c.opt_kernel = opt_kernel; c.opt_f32 = opt_f32;
+    c.opt_kernel = opt_kernel; c.opt_f32 = (opt_f32 == 1) ? 1 : 0; c.opt_img32 = (opt_f32 == 2) ? 1 : 0;
     std::vector<std::string> names;
     g_dry = &names;
     int rc = PGL_OK;
@@ -2480,7 +2511,7 @@ int pgl_info(pgl_handle h, int n_lo, int n_hi, double* info, int n_info)
     v[12] = stim_path;
     v[9] = pl.version;                       // 1 4-wave, 2 K-split, 3 K-split f32, 4 two-pass, 5 two-pass on resident feature tiles
     v[10] = (pl.version == 5) ? (double)pl.nTiles * (double)img_pair_bytes(pl.ktl, pl.kth)
-            : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)img_bytes6(pl.KT, pl.version == 6 && pl.sb6 == 2) : 0.0;   // resident feature bytes
+            : (pl.version == 6 || pl.version == 7) ? (double)pl.nTiles * (double)img_bytes6(pl.KT, (pl.version == 6 && pl.sb6 == 2) ? 1 + pl.img32 : 0) : 0.0;   // resident feature bytes
     // HBM bytes the hot kernels stream per evaluation beyond the algorithmic ones (feature tiles read in
     // pass 1 and the H part again in pass 2, residual slab written and read)
     v[11] = (pl.version == 5) ? v[10] + (double)pl.nTiles * pgl_img_bytes(pl.kth) + 2.0 * (double)pl.nTiles * pl.nPT * 2048.0

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
@@ -1658,7 +1659,15 @@ __global__ __launch_bounds__(256) void k_build_fimg(const int2* __restrict__ spk
             } else if (col < Kimpb + Dstim) {
                 v = (tg < nT) ? fstim[tg * DsAll + ds0 + (col - Kimpb)] : 0.0;
             }
-            dstb[i] = v;
+            if (blk == 2) {
+                // f32 blocks (k_fused8<.., F32 = 1>): lane l of the reading wave holds the doubles 2l, 2l + 1, 128 + 2l,
+                // 128 + 2l + 1 of the block as one float4
+                float* dstf = reinterpret_cast<float*>(Fimg + (size_t)blockIdx.x * ktl * 1024) + kb * 256;
+                const int e = i & 255, hi2 = e >> 7, l = (e & 127) >> 1;
+                dstf[4 * l + 2 * hi2 + (e & 1)] = (float)v;
+            } else {
+                dstb[i] = v;
+            }
         }
         return;
     }
@@ -1763,9 +1772,17 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 // ---------------------------------------------------------------------------
 // XIN = 1 (pass 1): the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] -- the stimulus current of a
 // separable stimulus (k_sepf_fwd) -- which pass 1 then overwrites with the residuals as always
-template <int KTL, int KTH, int PASS, int XIN = 0, int PART = 0>
+// HLP = 1: blocks of FIVE or SIX post tiles (N = 65 .. 96 and the last block of 13 or 14 tiles) leave three or two of the
+// eight waves without a tile of their own, and two SIMDs with two tiles each: the idle waves take over part of the work of
+// the tiles of a doubly loaded SIMD -- in pass 1 the second half of a tile's forward k-steps (the partial currents reach
+// the tile's own wave through LDS, in front of the barrier that closes the forward phase anyway), in pass 2 the second half
+// of its k-tiles (own G registers, own partials).  Five tiles: waves 5 / 6 help tiles 0 / 4 (both on SIMD 0); six tiles:
+// waves 6 / 7 help tiles 0 / 1.  Per tile step the busiest SIMD then carries 1.5 forward passes instead of 2
+// (five tiles: 1 + the two L backward passes).  Tiles without a helper compute exactly what HLP = 0 computes.
+template <int KTL, int KTH, int PASS, int XIN = 0, int PART = 0, int HLP = 0>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
+    static_assert(!HLP || (XIN == 0 && PART == 0 && KTL >= 2 && KTH >= 2), "helper waves: plain two-pass form only");
     constexpr int TT = 16, NW = 8;
     constexpr int KT_ALL = KTL + KTH;
     constexpr int KS_ALL = 4 * KT_ALL;
@@ -1791,6 +1808,29 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const int chunk = blockIdx.x / nPB;
     const int pt = pb * NW + wave;
     const bool active = pt < p.nPT;
+    // role of the wave: 0 its own tile in full (or none), 1 its own tile with a helper, 2 helper of tile wpt (slot hslot of
+    // the exchange area)
+    int role = 0, wpt = pt, hslot = 0;
+    if constexpr (HLP != 0) {
+        const int nb = (p.nPT - pb * NW < NW) ? p.nPT - pb * NW : NW;
+        if (nb == 5) {
+            role = (wave == 0 || wave == 4) ? 1 : ((wave == 5 || wave == 6) ? 2 : 0);
+            wpt = pb * NW + ((wave == 5) ? 0 : ((wave == 6) ? 4 : wave));
+            hslot = (wave == 4 || wave == 6) ? 1 : 0;
+        } else if (nb == 6) {
+            role = (wave <= 1) ? 1 : ((wave >= 6) ? 2 : 0);
+            wpt = pb * NW + ((wave >= 6) ? wave - 6 : wave);
+            hslot = (wave == 1 || wave == 7) ? 1 : 0;
+        }
+        role = __builtin_amdgcn_readfirstlane(role);
+        wpt = __builtin_amdgcn_readfirstlane(wpt);
+        hslot = __builtin_amdgcn_readfirstlane(hslot);
+    }
+    const bool helper = (HLP != 0) && role == 2;
+    const bool works = active || helper;          // the wave runs MFMAs (on tile wpt)
+    // forward k-steps / pass-2 k-tiles that stay with a helped tile's own wave
+    constexpr int QS = ((4 * (KTL + KTH)) / 2 + 3) / 4 * 4;
+    constexpr int KTPH = ((PART ? KTL : KTH) + 1) / 2;
 
     // pass 1: L buffers at 0 and IMGL, H buffer behind them; pass 2: two H buffers
     unsigned char* buf0 = smem;
@@ -1799,9 +1839,6 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     double* Cs = reinterpret_cast<double*>(smem + ((PASS == 1) ? 2 * IMGL + IMGH : 2 * IMGP));
     if (tid < 32) Cs[tid] = PGL_C[tid];
 
-    d4_t G[KTG];
-#pragma unroll
-    for (int kt = 0; kt < KTG; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
     const int col = lane & 15;
     const int grp = lane >> 4;
@@ -1812,7 +1849,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const int tile_beg = p.tile0 + chunk * p.tilesPerChunk;
     int tile_end = tile_beg + p.tilesPerChunk;
     if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
-    double* const rslab = p.Xbuf + ((size_t)(active ? pt : 0)) * 256 + lane;
+    double* const rslab = p.Xbuf + ((size_t)(works ? wpt : 0)) * 256 + lane;
     const size_t rstride = (size_t)p.nPT * 256;
     // images are indexed relative to the first tile they were built for (p.img_tile0)
     const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * (IMGL + IMGH);
@@ -1823,10 +1860,14 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     constexpr int NRL = (IMGL / 1024 + 7) / 8, NRH = (IMGH / 1024 + 7) / 8;
     constexpr int NR0 = (PASS == 1 || PART) ? NRL : NRH, NR1 = (PASS == 1) ? NRH : 0;
     constexpr int RSG = (PASS == 1 || PART) ? RSL : RSH;
-    auto bwd_half = [&](const unsigned char* Fb, const double (&rq)[4], const unsigned char* g0,
-                        unsigned char* l0, const unsigned char* g1, unsigned char* l1, const bool dma) {
-        const double* fb = reinterpret_cast<const double*>(Fb) + pgl_img_brow(grp) * RSG + col;
-        constexpr int NS = 4 * KTG;
+    // (k0c, nkc, krt: the k-tiles [K0 + krt, K0 + krt + NK) of the image, accumulated in G[0 .. NK) -- all KTG of them, or
+    //  the share of a helped tile's own wave / of its helper: ONE instantiation for both, the helper's at a runtime offset)
+    auto bwd_part = [&](auto k0c, auto nkc, auto& G, const int krt, const unsigned char* Fb, const double (&rq)[4],
+                        const unsigned char* g0, unsigned char* l0, const unsigned char* g1, unsigned char* l1,
+                        const bool dma) {
+        constexpr int K0 = decltype(k0c)::value, NK = decltype(nkc)::value;
+        const double* fb = reinterpret_cast<const double*>(Fb) + pgl_img_brow(grp) * RSG + col + 16 * (K0 + krt);
+        constexpr int NS = 4 * NK;
         constexpr int PD = (NS < PGL_PD) ? NS : PGL_PD;
         constexpr int NRT = NR0 + NR1;
         constexpr int DSFULL = NS / NRT;
@@ -1834,7 +1875,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         constexpr int DSTEP = (NS >= 2 * NRT) ? ((DSFULL < DSCAP) ? DSFULL : DSCAP) : 0;   // MFMAs between rounds
         double ar[PD];
 #pragma unroll
-        for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / KTG)) * RSG + 16 * (s % KTG));
+        for (int s = 0; s < PD; ++s) ar[s] = pgl_lds_f64(fb + (2 * (s / NK)) * RSG + 16 * (s % NK));
         auto round = [&](const int j) {
             if (j < NR0) {
                 pgl_dma_round<(PASS == 1 || PART) ? KTL : KTH>(g0, l0, j, wave, lane);
@@ -1852,8 +1893,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         for (int s = 0; s < NS; ++s) {
             if (PGL_PRIO && s == NS / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
             const double a = ar[s % PD];
-            if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (2 * ((s + PD) / KTG)) * RSG + 16 * ((s + PD) % KTG));
-            G[s % KTG] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / KTG], G[s % KTG], 0, 0, 0);
+            if (s + PD < NS) ar[s % PD] = pgl_lds_f64(fb + (2 * ((s + PD) / NK)) * RSG + 16 * ((s + PD) % NK));
+            G[s % NK] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rq[s / NK], G[s % NK], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             if (DSTEP > 0) {
                 constexpr int DS = (DSTEP > 0) ? DSTEP : 1;
@@ -1866,14 +1907,18 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             }
         }
     };
-
     if constexpr (PASS == 1) {
+        d4_t G[KTL];
+#pragma unroll
+        for (int kt = 0; kt < KTL; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
         double ll_acc = 0.0, gb_acc = 0.0;
         // padding lanes (neurons >= npost) get a benign current: they must not push their wave out of
         // the epilogue's series regime; nothing they produce is ever read
         const double bias_l = valid_n ? p.bias[nloc] : (p.nlin == 1 ? 30.0 : 0.0);
-        const double* __restrict__ wrow = p.Wfrag + (size_t)(active ? pt : 0) * KS_ALL * 64;
+        const double* __restrict__ wrow = p.Wfrag + (size_t)(works ? wpt : 0) * KS_ALL * 64;
         double* const wscratch = reinterpret_cast<double*>(smem + 2 * IMGL + IMGH + 256) + wave * 192;   // spike compaction
+        // HLP: partial currents of the two helpers, [2][4][64], behind the spike scratch
+        double* const Xh = reinterpret_cast<double*>(smem + 2 * IMGL + IMGH + 256) + NW * 192 + hslot * 256 + lane;
         // prologue: L and H of the first tile
         if (tile_beg < tile_end) {
             pgl_dma_half<KTL>(fimg + (size_t)tile_beg * IMGS, buf0, wave, lane);
@@ -1907,14 +1952,16 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             // ---- forward over both parts ----
             d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0};
             d4_t acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-            constexpr int PW2 = (KS_ALL / 2 < PGL_PW / 2) ? KS_ALL / 2 : PGL_PW / 2;
-            if (active && !PGL_DBG(8)) {
+            // forward k-steps [Q0, Q1) of tile wpt: all of them, or the share of a helped tile's own wave / of its helper
+            auto forward = [&](auto q0c, auto q1c) {
+                constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value, NQ = Q1 - Q0;
+                constexpr int PW2 = (NQ / 2 < PGL_PW / 2) ? NQ / 2 : PGL_PW / 2;
+                static_assert(Q0 % 2 == 0 && NQ % 2 == 0 && NQ >= 2, "whole fragment pairs");
                 const double* faL = reinterpret_cast<const double*>(Lb) + pgl_img_row(col) * RSL + grp;
                 const double* faH = reinterpret_cast<const double*>(buf1) + pgl_img_row(col) * RSH + grp;
                 const double* wr_s = wrow;
                 asm volatile("" : "+s"(wr_s));
                 constexpr int PA = 4;
-                const pgl_glb_cd2p wr2 = (pgl_glb_cd2p)wr_s;
                 pgl_d2 wr[PW2];
                 double ar[PA];
                 auto afrag = [&](const int s) -> double {
@@ -1923,36 +1970,51 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 // scalar bases of the Wmat fragment stream, one per 4 KB (four pairs of k-steps)
                 pgl_glb_cd2p wr_base[KS_ALL / 8 + 1];
 #pragma unroll
-                for (int b4 = 0; b4 < KS_ALL / 8 + 1; ++b4) {
+                for (int b4 = Q0 / 8; b4 < (Q1 + 7) / 8; ++b4) {
                     const double* bs = wr_s + (size_t)b4 * 512;
                     asm volatile("" : "+s"(bs));
                     wr_base[b4] = (pgl_glb_cd2p)bs;
                 }
 #pragma unroll
                 for (int q = 0; q < PW2; ++q) {
-                    const int pair = q;
+                    const int pair = Q0 / 2 + q;
                     wr[q] = wr_base[pair / 4][(pair % 4) * 64 + lane];
                 }
 #pragma unroll
-                for (int q = 0; q < PA; ++q) ar[q] = afrag(q);
+                for (int q = 0; q < PA; ++q) ar[q] = afrag(Q0 + q);
                 if (PGL_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int q = 0; q < KS_ALL; ++q) {
-                    if (PGL_PRIO && q == KS_ALL / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
-                    const double a = ar[q % PA];
-                    const double b = (q & 1) ? wr[(q / 2) % PW2].y : wr[(q / 2) % PW2].x;
-                    if (q + PA < KS_ALL) ar[q % PA] = afrag(q + PA);
-                    if ((q & 1) && (q / 2 + PW2 < KS_ALL / 2)) {
+                for (int q = Q0; q < Q1; ++q) {
+                    if (PGL_PRIO && q == Q0 + NQ / 2 && wave >= 4) __builtin_amdgcn_s_setprio(0);
+                    const double a = ar[(q - Q0) % PA];
+                    const double b = (q & 1) ? wr[((q - Q0) / 2) % PW2].y : wr[((q - Q0) / 2) % PW2].x;
+                    if (q + PA < Q1) ar[(q - Q0) % PA] = afrag(q + PA);
+                    if ((q & 1) && ((q - Q0) / 2 + PW2 < NQ / 2)) {
                         // scalar base + lane offset + small immediate: the base moves on in SGPRs every four
                         // fragment pairs (4 KB), no 64-bit VALU address arithmetic
                         const int pair = q / 2 + PW2;      // compile-time (unrolled)
-                        wr[(q / 2) % PW2] = wr_base[pair / 4][(pair % 4) * 64 + lane];
+                        wr[((q - Q0) / 2) % PW2] = wr_base[pair / 4][(pair % 4) * 64 + lane];
                     }
                     if (q & 1)
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
                     else
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (((q - Q0) & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (works && !PGL_DBG(8)) {
+                if constexpr (HLP != 0) {
+                    if (role == 1) forward(std::integral_constant<int, 0>{}, std::integral_constant<int, QS>{});
+                    else if (role == 2) forward(std::integral_constant<int, QS>{}, std::integral_constant<int, KS_ALL>{});
+                    else forward(std::integral_constant<int, 0>{}, std::integral_constant<int, KS_ALL>{});
+                } else {
+                    forward(std::integral_constant<int, 0>{}, std::integral_constant<int, KS_ALL>{});
+                }
+            }
+            if constexpr (HLP != 0) {
+                if (helper) {                              // the partial currents, in front of the barrier below
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xh[r * 64] = acc0[r] + acc1[r];
                 }
             }
             PGL_PROF_MARK(0);
@@ -1967,6 +2029,11 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             // the waves up for the epilogue.
             __syncthreads();
             PGL_PROF_MARK(2);
+            double xh[(HLP != 0) ? 4 : 1];                // HLP: the helper's share of a helped tile's currents (else 0)
+            if constexpr (HLP != 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xh[r] = (role == 1) ? Xh[r * 64] : 0.0;
+            }
             // ---- epilogue on the accumulator registers ----
             double rr[4];
             if constexpr (FWO) {
@@ -1988,7 +2055,10 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                     // whole tile inside the evaluated range: four elements at a time, fixed order
                     double xs[4], term4 = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xs[r] = bias_l + (acc0[r] + acc1[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (HLP != 0) xs[r] = bias_l + ((acc0[r] + acc1[r]) + xh[r]);
+                        else xs[r] = bias_l + (acc0[r] + acc1[r]);
+                    }
                     if constexpr (XRD) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xs[r] += xin[r];
@@ -2011,7 +2081,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 #pragma unroll
                         for (int e = 0; e < ENE; ++e) {
                             const int r = ENE * h2 + e;
-                            xe[e] = bias_l + (acc0[r] + acc1[r]);
+                            if constexpr (HLP != 0) xe[e] = bias_l + ((acc0[r] + acc1[r]) + xh[r]);
+                            else xe[e] = bias_l + (acc0[r] + acc1[r]);
                             if constexpr (XRD) xe[e] += xin[r];
                             se[e] = (double)scb[r];
                             const long long tg = (long long)t0 + grp + 4 * r;
@@ -2053,8 +2124,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
                 double* rs = rslab + (size_t)(tile - p.tile0) * rstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rs[r * 64] = rr[r];
-                bwd_half(Lb, rr, fimg + (size_t)(tile + 1) * IMGS, Ln,
-                         fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, more);
+                bwd_part(std::integral_constant<int, 0>{}, std::integral_constant<int, KTL>{}, G, 0, Lb, rr,
+                         fimg + (size_t)(tile + 1) * IMGS, Ln, fimg + (size_t)(tile + 1) * IMGS + IMGL, buf1, more);
             }
             PGL_PROF_MARK(4);
             __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): L_{i+1}, H_{i+1} landed, r stored
@@ -2079,47 +2150,67 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         }
     } else {
         // =============================== pass 2 ===============================
-        double rv[4] = {0.0, 0.0, 0.0, 0.0}, rn[4] = {0.0, 0.0, 0.0, 0.0};
-        if (tile_beg < tile_end) {
-            pgl_dma_half<KTP>(fimg + (size_t)tile_beg * IMGS + OFFP, buf0, wave, lane);
-            if (active) {
+        // nkc k-tiles of the part from k-tile krt on, their G in registers: the whole part (NK = KTP), or -- HLP, a helped
+        // tile -- its first KTPH k-tiles (the tile's own wave) / its last KTPH (the helper; with an odd KTP the middle
+        // k-tile is done twice and the helper's copy, kskip = 1, dropped at the write-out).  One tile loop per form: the
+        // accumulators of the two forms are never alive together.
+        auto pass2 = [&](auto nkc, const int krt, const int kskip) {
+            constexpr int NK = decltype(nkc)::value;
+            d4_t G[NK];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
-            }
-        }
-        PGL_PROF_DECL
-        for (int tile = tile_beg; tile < tile_end; ++tile) {
-            const int par = (tile - tile_beg) & 1;
-            const unsigned char* Hb = par ? buf1 : buf0;
-            unsigned char* Hn = par ? buf0 : buf1;
-            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): H_i and r_i are here
-            PGL_PROF_MARK(0);
+            for (int kt = 0; kt < NK; ++kt) G[kt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            double rv[4] = {0.0, 0.0, 0.0, 0.0}, rn[4] = {0.0, 0.0, 0.0, 0.0};
+            if (tile_beg < tile_end) {
+                pgl_dma_half<KTP>(fimg + (size_t)tile_beg * IMGS + OFFP, buf0, wave, lane);
+                if (works) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = rn[r];
-            __syncthreads();                              // ... for every wave; H_{i-1}'s buffer is free
-            PGL_PROF_MARK(1);
-            const bool more = tile + 1 < tile_end;
-            const bool do_bwd = active && !PGL_DBG(16);
-            if (more) {
-                if (!do_bwd) pgl_dma_half<KTP>(fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn, wave, lane);
-                if (active) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
+                    for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile_beg - p.tile0) * rstride + r * 64];
                 }
             }
-            PGL_PROF_MARK(2);
-            if (do_bwd) bwd_half(Hb, rv, fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn, nullptr, nullptr, more);
-            PGL_PROF_MARK(3);
-        }
-        PGL_PROF_STORE(2);
-        if (active) {
-            double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, PART ? 0 : KTL, p.nChunks, chunk, lane);
-            const size_t gcs = (size_t)p.nChunks * 64;
+            PGL_PROF_DECL
+            for (int tile = tile_beg; tile < tile_end; ++tile) {
+                const int par = (tile - tile_beg) & 1;
+                const unsigned char* Hb = par ? buf1 : buf0;
+                unsigned char* Hn = par ? buf0 : buf1;
+                __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): H_i and r_i are here
+                PGL_PROF_MARK(0);
 #pragma unroll
-            for (int kt = 0; kt < KTP; ++kt) {
+                for (int r = 0; r < 4; ++r) rv[r] = rn[r];
+                __syncthreads();                              // ... for every wave; H_{i-1}'s buffer is free
+                PGL_PROF_MARK(1);
+                const bool more = tile + 1 < tile_end;
+                const bool do_bwd = works && !PGL_DBG(16);
+                if (more) {
+                    if (!do_bwd) pgl_dma_half<KTP>(fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn, wave, lane);
+                    if (works) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
+                        for (int r = 0; r < 4; ++r) rn[r] = rslab[(size_t)(tile + 1 - p.tile0) * rstride + r * 64];
+                    }
+                }
+                PGL_PROF_MARK(2);
+                if (do_bwd)
+                    bwd_part(std::integral_constant<int, 0>{}, nkc, G, krt, Hb, rv, fimg + (size_t)(tile + 1) * IMGS + OFFP, Hn,
+                             nullptr, nullptr, more);
+                PGL_PROF_MARK(3);
             }
+            PGL_PROF_STORE(2);
+            if (works) {
+                double* gp = pgl_gpart(p.Gpart, wpt, KT_ALL, (PART ? 0 : KTL) + krt, p.nChunks, chunk, lane);
+                const size_t gcs = (size_t)p.nChunks * 64;
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) {
+                    if (HLP == 0 || kt >= kskip) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gp[(kt * 4 + r) * gcs] = G[kt][r];
+                    }
+                }
+            }
+        };
+        if constexpr (HLP != 0) {
+            if (role != 0) pass2(std::integral_constant<int, KTPH>{}, (role == 2) ? KTP - KTPH : 0, (role == 2) ? 2 * KTPH - KTP : 0);
+            else pass2(std::integral_constant<int, KTP>{}, 0, 0);
+        } else {
+            pass2(std::integral_constant<int, KTP>{}, 0, 0);
         }
     }
     PGL_PROF_EXIT;
@@ -2500,13 +2591,21 @@ __host__ __device__ constexpr int pgl_blk_off(int t, int c) { return t * 16 + (c
 #define PGL_F8_ABL 0
 #endif
 #define F8A(bit) ((PGL_F8_ABL & (bit)) != 0)
-template <int KTW, int RING>
+// F32 = 1 (PGL_OPT_FEATURE_F32 = 2, opt-in): the resident blocks are stored as f32 -- HALF the HBM stream of this HBM-bound
+// corner -- and every arithmetic operation stays f64: a wave loads a 1 KB block with one 16-byte load per lane into a
+// register queue two tiles ahead (the compiler counts vmcnt), converts it and writes the f64 block (same swizzled layout,
+// two conflict-free ds_write_b128) into the LDS slot the block's predecessor has just been read out of; the slots are the
+// KTW blocks of one tile.  Only the STORED feature is rounded (2^-24 relative).
+typedef float pgl_f4 __attribute__((ext_vector_type(4)));
+template <int KTW, int RING, int F32 = 0>
 __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
 {
     constexpr int TT = 16, NW = 8, KSPLIT = 8;
     constexpr int KSW = KTW * 4, KT_ALL = KTW * KSPLIT;
-    constexpr int BLK = 2048;
-    constexpr size_t IMG = (size_t)KT_ALL * BLK;
+    constexpr int BLK = 2048;                               // a block in LDS (f64)
+    constexpr int GBLK = F32 ? 1024 : 2048;                 // ... and in HBM
+    constexpr int NSLOT = F32 ? KTW : RING;                 // LDS slots per wave
+    constexpr size_t IMG = (size_t)KT_ALL * GBLK;
     static_assert(RING > KTW && RING <= 2 * KTW && 2 * (RING - KTW) < 16, "ring: more than a tile, waitcnt immediate");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(1))) void gvoid;
@@ -2518,8 +2617,8 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
     const int ksl = wave;
     const int pt = blockIdx.x % p.nPT;
     const int chunk = blockIdx.x / p.nPT;
-    unsigned char* const ring = smem + (size_t)wave * RING * BLK;            // this wave's blocks
-    double* Xp = reinterpret_cast<double*>(smem + (size_t)NW * RING * BLK); // [NW][4][64] partial currents
+    unsigned char* const ring = smem + (size_t)wave * NSLOT * BLK;           // this wave's blocks
+    double* Xp = reinterpret_cast<double*>(smem + (size_t)NW * NSLOT * BLK); // [NW][4][64] partial currents
     double* Rb = Xp + NW * 256;                                             // [4][64] residuals
     double* Cs = Rb + 256;                                                  // [32] math constants
     double* const wscratch = Cs + 32 + wave * 48;                           // per wave: spike compaction of the epilogue
@@ -2547,7 +2646,7 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
     int tile_end = tile_beg + p.tilesPerChunk;
     if (tile_end > p.tile0 + p.nTiles) tile_end = p.tile0 + p.nTiles;
     const int total = (tile_end > tile_beg) ? (tile_end - tile_beg) * KTW : 0;       // blocks of this wave in the chunk
-    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG + (size_t)ksl * KTW * BLK;
+    const unsigned char* __restrict__ fimg = p.Fimg - (size_t)p.img_tile0 * IMG + (size_t)ksl * KTW * GBLK;
 
     // this wave's slice of Wmat stays in registers for the whole chunk
     double wreg[KSW];
@@ -2596,7 +2695,36 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
         }
     };
     if (total == 0) return;                               // (never: a chunk has a tile)
-    issue(RING);
+    // F32: the register queue -- set (li + 1) & 1 holds the blocks of the chunk's tile li + 1 while tile li computes
+    pgl_f4 qreg[F32 ? 2 * KTW : 1];
+    const int ntl = tile_end - tile_beg;
+    auto gload = [&](const int li, const int kt) -> pgl_f4 {      // block kt of tile li (behind the chunk: its last tile again)
+        const int lt = (li < ntl) ? li : ntl - 1;
+        const unsigned char* gs = fimg + (size_t)(tile_beg + lt) * IMG + (size_t)kt * GBLK;
+        asm volatile("" : "+s"(gs));
+        return *reinterpret_cast<const pgl_f4*>(gs + lane * 16);
+    };
+    // lane l carries the doubles 2l, 2l + 1, 128 + 2l, 128 + 2l + 1 of the block (k_build_fimg, blk = 2)
+    auto lds_put = [&](const int kt, const pgl_f4 v) {
+        typedef __attribute__((address_space(3))) pgl_d2 ld2;
+        volatile ld2* dst = (volatile ld2*)(ring + kt * BLK + lane * 16);
+        pgl_d2 lo, hi;
+        lo.x = (double)v.x; lo.y = (double)v.y; hi.x = (double)v.z; hi.y = (double)v.w;
+        dst[0] = lo;
+        dst[64] = hi;
+    };
+    if constexpr (F32 != 0) {
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) qreg[kt] = gload(0, kt);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) qreg[KTW + kt] = gload(1, kt);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) lds_put(kt, qreg[kt]);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) qreg[kt] = gload(2, kt);
+    } else {
+        issue(RING);
+    }
     // workgroup barrier for LDS traffic only: __syncthreads() also waits for vmcnt(0) -- the blocks in flight
     // (timing ablation, -DPGL_ABLATE builds only: 1 no MFMAs, 2 no rate epilogue, 4 no barriers, 8 no fragment reads)
     auto lds_barrier = [&] { if (!F8A(4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -2612,10 +2740,11 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
     }
     double fareg[KSW], fbreg[KSW];
     int slot0 = 0;                                        // ring slot of the tile's first block
-    for (int tile = tile_beg, li = 0; tile < tile_end; ++tile, ++li) {
+    auto tile_step = [&](auto parc, const int tile, const int li) {
+        constexpr int PAR = decltype(parc)::value;           // F32: parity of li (selects the register set)
         // the KTW blocks of this tile have landed when at most the RING - KTW blocks requested behind them are in flight
         // (loads return in order)
-        __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (RING - KTW)));
+        if constexpr (F32 == 0) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (RING - KTW)));
         const unsigned scu = scn;
         cptr += (tile + 1 < tile_end && tile + 1 <= last_tile) ? ctile : 0;
         if (!F8A(32)) scn = cptr[0];                      // (requested BEFORE the blocks below: it is back before them)
@@ -2626,6 +2755,7 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
         auto read_frags = [&](const int kt) {
             int sl = slot0 + kt;
             sl = (sl >= RING) ? sl - RING : sl;
+            if constexpr (F32 != 0) sl = kt;
             const unsigned char* blk = ring + sl * BLK;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -2653,7 +2783,15 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the fragments of blocks kt and kt + 1 are in registers
-            issue(1);
+            if constexpr (F32 != 0) {
+                // slot kt is free: the next tile's block kt goes in (loaded two tiles ago), its register takes the request
+                // for the block three tiles ahead
+                constexpr int QI = ((PAR + 1) & 1) * KTW;
+                lds_put(kt, qreg[QI + kt]);
+                qreg[QI + kt] = gload(li + 3, kt);
+            } else {
+                issue(1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         slot0 += KTW;
@@ -2713,6 +2851,14 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
                 G[s % KTW] = __builtin_amdgcn_mfma_f64_16x16x4f64(fbreg[s], rr[s / KTW], G[s % KTW], 0, 0, 0);
             }
         }
+    };
+    if constexpr (F32 != 0) {
+        for (int tile = tile_beg, li = 0; tile < tile_end; tile += 2, li += 2) {
+            tile_step(std::integral_constant<int, 0>{}, tile, li);
+            if (tile + 1 < tile_end) tile_step(std::integral_constant<int, 1>{}, tile + 1, li + 1);
+        }
+    } else {
+        for (int tile = tile_beg, li = 0; tile < tile_end; ++tile, ++li) tile_step(std::integral_constant<int, 0>{}, tile, li);
     }
 
     const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;

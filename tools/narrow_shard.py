@@ -1,5 +1,5 @@
 """The neuron-sharded step of an 8-GPU run on ONE GPU: ll+grad of a 16-neuron shard (one post tile) of C3 against the
-whole 640-column feature row (dev tool).   python tools/narrow_shard.py [neurons_per_shard ...]
+whole 640-column feature row (dev tool).   python tools/narrow_shard.py [--f32] [neurons_per_shard ...]
 k_fused8 (per-wave block rings); compared, on a 60 s recording, with the whole-population evaluation.  (The A/B against
 k_fused6<5,1,1,8,0>, one image buffer, that this tool ran while both existed: profiles/r05_narrow_shard_ab.txt.)"""
 import sys, time
@@ -9,7 +9,8 @@ sys.path.insert(0, '.')
 from theano_pyglm_amd import _lib
 import bench
 
-shards = [int(a) for a in sys.argv[1:]] or [16]
+shards = [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [16]
+F32 = 2 if '--f32' in sys.argv else 0                                # PGL_OPT_FEATURE_F32 = 2: f32 resident blocks (opt-in)
 N, dt = 128, 0.001
 ib = bench.standard_ibasis()
 R, B = ib.shape
@@ -25,6 +26,8 @@ def run(T, K, check_full):
     dev = _lib.DeviceGlm(N, nT, B, R, 'explinear', dt)
     dev.set_spikes(S); dev.set_basis(ib)
     dev.set_option(_lib.OPT_TIMING, 1)
+    if F32:
+        dev.set_option(_lib.OPT_FEATURE_F32, F32)
     st = torch.cuda.Stream(); torch.cuda.set_stream(st)
     dev.set_stream(st.cuda_stream)
     d_W = torch.ones((N, N), dtype=torch.float64, device='cuda')
@@ -39,7 +42,7 @@ def run(T, K, check_full):
         n_lo = 32
         d_theta = torch.from_numpy(theta[n_lo:n_lo + M]).cuda()
         res = {}
-        for name in (" + ".join(_lib.plan_kernels(N, B=B, R=R, nT=nT, n_lo=n_lo, count=M)),):
+        for name in (" + ".join(_lib.plan_kernels(N, B=B, R=R, nT=nT, n_lo=n_lo, count=M, opt_f32=F32)),):
             d_out = torch.zeros(M * (1 + P), dtype=torch.float64, device='cuda')
             info = dev.info(n_lo, n_lo + M)
             for _ in range(5):

@@ -28,7 +28,7 @@ def reachable_both():
     auto, forced = {}, {}
     for N, B, nT, stim, Ds, count in shapes():
         for ok in (0, 2, 3, 4, 6, 7):
-            for f32 in ((0, 1) if stim == 0 else (0,)):
+            for f32 in ((0, 1, 2) if stim == 0 else (0,)):           # (2: f32 resident blocks of the narrow-shard kernel)
                 for path in (0, 1, 2):
                     if path == 2 and count != N:
                         continue

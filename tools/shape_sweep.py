@@ -2,7 +2,7 @@
 kernel the dispatcher picks (make_plan) and the forced alternatives, fused-kernel and whole-evaluation time, fraction
 of the f64 MFMA peak.  Writes a markdown table (profiles/r05_shape_sweep.md via tools/r5_profiles.sh).
 
-    python tools/shape_sweep.py [T seconds = 300] [--alts] [N ...]
+    python tools/shape_sweep.py [T seconds = 300] [--alts] [--no-helpers] [N ...]
 """
 import sys
 import numpy as np
@@ -15,6 +15,7 @@ args = [a for a in sys.argv[1:] if not a.startswith('--')]
 alts = '--alts' in sys.argv
 ptw = [int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--ptw=')]
 slc = [int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--slice=')]
+nohlp = '--no-helpers' in sys.argv                                  # dev option 92: two-pass kernel without helper waves (A/B)
 T = float(args[0]) if args else 300.0
 Ns = [int(a) for a in args[1:]] or [16, 32, 48, 64, 80, 96, 128, 160, 256]
 nT = int(T * 1000)
@@ -28,6 +29,8 @@ for N in Ns:
         dev = p.device()
         try:
             dev.set_option(_lib.OPT_KERNEL, opt)
+            if nohlp:
+                dev.set_option(92, 1)
             if slc:
                 dev.set_option(93, slc[0])                      # dev: feature columns per slice of the 3-phase path
             if ptw:
