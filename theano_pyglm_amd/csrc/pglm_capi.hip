@@ -2873,11 +2873,11 @@ int pgl_gibbs_ll_cols(pgl_handle h, int ncols, const int* n_post, const int* n_p
                                h->stream, gp, n_pre[0], (double*)h->gfs.p);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(rate_kernel, dim3(nblk, ygroups), dim3(256), lds, h->stream, gp);
-        HIPCHK(hipGetLastError());
-        // (the spike terms on the side stream beside the rate kernel -- two event hops -- were measured at 1.365 ms per
-        //  launch against 1.295 in line: the rate kernel is VALU-bound and has no room to give)
-        hipLaunchKernelGGL(k_gibbs_spike_cols, dim3(sblk, ncols), dim3(256), 0, h->stream, gp);
+        // rate and spike workgroups in ONE launch, the spike workgroups (short chains of dependent loads: 87 us as a launch
+        // of their own) dispatched last: they fill the slots the rate workgroups free at the end.  (On a side stream beside
+        // the rate kernel -- two event hops -- they cost more than in line: 1.365 against 1.295 ms, round 3.)
+        gp.nblkR = nblk; gp.nygR = ygroups; gp.nblkS = sblk;
+        hipLaunchKernelGGL(rate_kernel, dim3((unsigned)(nblk * ygroups + sblk * ncols)), dim3(256), lds, h->stream, gp);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_gibbs_reduce_cols2, dim3(ncols, K), dim3(64), 0, h->stream, (const double*)gp.part, nblk,
                            (const double*)gp.partS, sblk, ncols, K, h->dt, (double*)h->pin_args);

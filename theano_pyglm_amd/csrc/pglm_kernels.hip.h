@@ -3843,6 +3843,7 @@ struct GibbsColsParams {
     const double* __restrict__ fs;
     long long fs_stride;
     int hs_region;                       // doubles of the first LDS region: max(CP * R, B * (PGL_GRB + 2) + CP * 8)
+    int nblkR, nygR, nblkS;              // k_gibbs_rate_cols' 1-D grid: nblkR x nygR rate workgroups, then nblkS x ncols spike workgroups
     int dbg;                             // dev: 1 no event loop, 2 no phase B, 4 no event staging, 8 no GX loads, 16 no band passes,
                                          // 32 no exp, 64 no merge tree (results invalid when != 0)
 };
@@ -4189,7 +4190,14 @@ __device__ __forceinline__ double pgl_softplus_tail_tab(const double a, const do
 {
     const double jd = rint(a * 8.0);
     const double v = fma(jd, C[14], -a);
+#ifdef PGL_SPT_LINEAR
+    // timing ablation only (wrong results): lane-linear, conflict-free table reads instead of the gather
+    int zl = 0;
+    asm volatile("" : "+v"(zl));
+    const double* te = TB + 2 * ((int)(threadIdx.x & 63) + zl);
+#else
     const double* te = TB + 2 * (int)jd;
+#endif
     double q = fma(v, C[0], C[1]);
 #pragma unroll
     for (int i = 2; i <= 5; ++i) q = fma(v, q, C[i]);
@@ -4313,9 +4321,8 @@ __device__ __noinline__ double pgl_gibbs_careful_tail(const double xq)
 }
 
 // (four waves per SIMD = four workgroups per CU is the operating point: the register allocator is held to 128 VGPRs)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gibbs_rate_cols(const GibbsColsParams p)
+__device__ __forceinline__ void pgl_gibbs_rate_body(const GibbsColsParams& p, const int bx, const int by, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RB = PGL_GRB, XS = RB + 2, NJ = RB / 32, NSEG = RB / 64;
     const int K = p.K, CP = p.CP, NSPLIT = p.nsplit, RPB = 256 / CP, R = p.R;
     double* HS = reinterpret_cast<double*>(smem);                   // [CP][R] impulse response of the pair
@@ -4332,29 +4339,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int* WL = reinterpret_cast<int*>(evS + (size_t)CP * PGL_GECAP_R); // [CP][PGL_GNL] first event of the sub-block's window
     unsigned short* WN = reinterpret_cast<unsigned short*>(WL + CP * PGL_GNL);   // [CP][PGL_GNL] events in the window (saturating)
     const int tid = threadIdx.x;
-    const long long tw0 = p.t_lo + (long long)blockIdx.x * RB * p.nloop;
+    const long long tw0 = p.t_lo + (long long)bx * RB * p.nloop;
     // ---- once per workgroup: impulse responses, candidate weights, event windows of every sub-block ----
     if (FSM) {
         for (int i = tid; i < CP * 8; i += 256) {
             const int ci = i >> 3, b = i & 7;
-            const int cc = blockIdx.y * CP + ci;
+            const int cc = by * CP + ci;
             BT[i] = (cc < p.ncols && b < p.B) ? p.theta[(size_t)p.cols[cc] * p.P + p.woff + p.pre[cc] * p.B + b] : 0.0;
         }
     } else {
         for (int i = tid; i < CP * R; i += 256) {
             const int ci = i / R;
-            const int cc = blockIdx.y * CP + ci;
+            const int cc = by * CP + ci;
             HS[i] = (cc < p.ncols) ? p.hs[(size_t)cc * R + (i - ci * R)] : 0.0;
         }
     }
     for (int i = tid; i < CP * PGL_KMAX; i += 256) {
-        const int cc = blockIdx.y * CP + i / PGL_KMAX, k = i % PGL_KMAX;
+        const int cc = by * CP + i / PGL_KMAX, k = i % PGL_KMAX;
         Wl[i] = (cc < p.ncols && k < K) ? p.w[(size_t)cc * K + k] : 0.0;
     }
     if (tid < 194 && tid < PGL_SPT_N) TB[tid] = (&PGL_SPT[0][0])[tid];
     for (int i = tid; i < CP * PGL_GNL; i += 256) {
         const int ci = i / PGL_GNL, sb = i % PGL_GNL;
-        const int cc = blockIdx.y * CP + ci;
+        const int cc = by * CP + ci;
         const long long tb0 = tw0 + (long long)sb * RB;
         int lo = 0, hi = 0;
         if (cc < p.ncols && sb < p.nloop && tb0 < p.t_hi && !FSM) {
@@ -4369,7 +4376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     // staging role: column ca, bins ra + j*RPB (j < NJ): eight post neurons of one bin share a 64-byte line
     const int ca = tid % CP, ra = tid / CP;
-    const int cca = blockIdx.y * CP + ca;
+    const int cca = by * CP + ca;
     const bool a_valid = (ra < RPB) && (cca < p.ncols);
     const int na = a_valid ? p.cols[cca] : 0;
     const double biasa = a_valid ? p.theta[(size_t)na * p.P] : 0.0;
@@ -4394,7 +4401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     double accV[2] = {0.0, 0.0};
     auto eval_item = [&](const int item, const int sb, const long long tb0, const int nb, double& accv) {
         const int c = item / NSPLIT, sp = item % NSPLIT;
-        const int cc = blockIdx.y * CP + c;
+        const int cc = by * CP + c;
         if (cc >= p.ncols || PGL_DBG(2)) return;
         const int tseg = sp * nseg * 64 + lane;                     // bin of segment 0 inside the sub-block
         // pair current of the lane's bins: every event of the column's window adds count * h[t - s - 1]
@@ -4597,26 +4604,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     for (int i = tid; i < CP * PGL_KMAX; i += 256) {
         const int c = i / PGL_KMAX, k = i % PGL_KMAX;
-        const int cc = blockIdx.y * CP + c;
+        const int cc = by * CP + c;
         if (cc < p.ncols && k < K) {
             double a = 0.0;
             for (int sp = 0; sp < NSPLIT; ++sp) a += PS[(c * NSPLIT + sp) * PGL_KMAX + k];
-            p.part[((size_t)blockIdx.x * p.ncols + cc) * PGL_KMAX + k] = a;
+            p.part[((size_t)bx * p.ncols + cc) * PGL_KMAX + k] = a;
         }
     }
 }
 
 // spike terms of the listed columns: sum over the events (t, count) of n_post inside the evaluated range of
 // count * log(lam_k(t)); grid = (event chunks of 256, ncols), one event per thread, f64 throughout.
-__global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams p)
+__device__ __forceinline__ void pgl_gibbs_spike_body(const GibbsColsParams& p, const int bx, const int by, unsigned char* smem)
 {
-    __shared__ double red[4][PGL_KMAX];
-    __shared__ double TB[128];                                      // log1p table (pgl_log1p_tab)
+    double (*red)[PGL_KMAX] = reinterpret_cast<double (*)[PGL_KMAX]>(smem);      // [4][PGL_KMAX]
+    double* TB = reinterpret_cast<double*>(smem) + 4 * PGL_KMAX;                  // [128] log1p table (pgl_log1p_tab)
     if (threadIdx.x < 128) TB[threadIdx.x] = (&PGL_L1PT[0][0])[threadIdx.x];
     __syncthreads();
-    const int tid = threadIdx.x, c = blockIdx.y, K = p.K;
+    const int tid = threadIdx.x, c = by, K = p.K;
     const int n = p.cols[c], np = p.pre[c];
-    const int i = p.elo[c] + blockIdx.x * 256 + tid;
+    const int i = p.elo[c] + bx * 256 + tid;
     double acc[PGL_KMAX];
 #pragma unroll
     for (int k = 0; k < PGL_KMAX; ++k) acc[k] = 0.0;
@@ -4680,8 +4687,24 @@ __global__ __launch_bounds__(256) void k_gibbs_spike_cols(const GibbsColsParams 
     }
     __syncthreads();
     if (tid < K)
-        p.partS[((size_t)blockIdx.x * p.ncols + c) * PGL_KMAX + tid] =
+        p.partS[((size_t)bx * p.ncols + c) * PGL_KMAX + tid] =
             red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// One launch for both: the rate workgroups (a 1-D grid decoded to the (time block, column group) pairs of the old 2-D grid,
+// time block fastest) and BEHIND them the spike workgroups (event chunk, column) -- short, latency-bound chains of dependent
+// loads that ran as a launch of their own for 87 us; dispatched last they fill the slots the rate workgroups leave at the
+// end of the launch.  (They share nothing but the setup kernels' outputs.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gibbs_rate_cols(const GibbsColsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, nrate = p.nblkR * p.nygR;
+    if (b < nrate) {
+        pgl_gibbs_rate_body(p, b % p.nblkR, b / p.nblkR, smem);
+    } else {
+        const int bs = b - nrate;
+        pgl_gibbs_spike_body(p, bs % p.nblkS, bs / p.nblkS, smem);
+    }
 }
 
 // out[c][k] = -dt * sum_b part[b][c][k] + sum_b partS[b][c][k] (fixed order); grid = (ncols, K), block = 64
