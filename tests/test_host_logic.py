@@ -336,7 +336,7 @@ def test_packed_layout_matches_reference_golden():
 
 
 def test_block_image_swizzle_is_conflict_free_for_both_mfma_operand_patterns():
-    """The block-form feature images of k_fused8 (csrc/pglm_kernels.hip.h: pgl_blk_off) store element (time row t, column c)
+    """The block-form feature images of k_fused8 (csrc/pglm_fused_resident.hip.h: pgl_blk_off) store element (time row t, column c)
     of a 16 x 16 f64 block at t * 16 + (c ^ (2 * (t >> 1))).  A ds_read_b64 serves 32 lanes per pass over 64 banks of
     4 bytes, i.e. 32 slots of 8 bytes: both MFMA operand patterns -- forward A (lane = time row i, k-step columns 4 ks +
     grp) and backward A = F^T (lane = column i, time rows 4 q + grp) -- must put the 32 lanes of each pass into 32

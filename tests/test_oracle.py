@@ -244,7 +244,7 @@ def test_blocked_c_baseline_matches_reference_dataflow():
 
 
 def test_softplus_tail_table_of_the_gibbs_kernel_matches_60_digit_values():
-    """The {L0, s} rows compiled into csrc/pglm_kernels.hip.h (PGL_SPT, read by k_gibbs_rate_cols for the band
+    """The {L0, s} rows compiled into csrc/pglm_gibbs.hip.h (PGL_SPT, read by k_gibbs_rate_cols for the band
     |x| < 12 of the softplus, glm.py:43-52) are the correctly rounded 60-digit values, and the table algorithm
     (tools/ubench/softplus_tail_table.py, the device code's prototype) reproduces log1p(exp(-a)) to 2e-16 absolute /
     5e-16 relative over the whole band."""
@@ -255,7 +255,7 @@ def test_softplus_tail_table_of_the_gibbs_kernel_matches_60_digit_values():
     spec = importlib.util.spec_from_file_location('spt', os.path.join(root, 'tools', 'ubench', 'softplus_tail_table.py'))
     spt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(spt)
-    src = open(os.path.join(root, 'theano_pyglm_amd', 'csrc', 'pglm_kernels.hip.h')).read()
+    src = open(os.path.join(root, 'theano_pyglm_amd', 'csrc', 'pglm_gibbs.hip.h')).read()
     body = src[src.index('PGL_SPT[97][2] = {'):]
     body = body[:body.index('};')]
     rows = re.findall(r'\{(0x[0-9a-f.]+p[+-]?\d+), (0x[0-9a-f.]+p[+-]?\d+)\}', body)

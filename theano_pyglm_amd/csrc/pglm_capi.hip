@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -1098,22 +1099,47 @@ static int upload_spikes(pgl_handle h, const uint8_t* S)
     HIPCHK(hipSetDevice(h->device));
     const int N = h->N;
     const int64_t nT = h->nT;
+    // two passes over the nT x N counts (77 MB at C3), each on up to 16 host threads over slabs of time: per-slab event
+    // counts of every neuron, a prefix over (neuron, slab) = every slab's write position in a neuron's list, then the
+    // slabs fill their own pieces -- the lists stay time-sorted (single-threaded: 0.15 s of a 0.19 s upload at C3)
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::max(1u, std::thread::hardware_concurrency())),
+                                                               nT / 65536));
+    std::vector<int64_t> t0s(nth + 1);
+    for (int i = 0; i <= nth; ++i) t0s[i] = nT * i / nth;
+    std::vector<std::vector<int>> slab((size_t)nth, std::vector<int>((size_t)N, 0));
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (int i = 1; i < nth; ++i) th.emplace_back(fn, i);
+        fn(0);
+        for (auto& t : th) t.join();
+    };
+    run([&](const int i) {
+        int* c = slab[(size_t)i].data();
+        for (int64_t t = t0s[i]; t < t0s[i + 1]; ++t) {
+            const uint8_t* row = S + t * N;
+            for (int n = 0; n < N; ++n) c[n] += row[n] != 0;
+        }
+    });
     std::vector<int> cnt(N + 1, 0);
-    for (int64_t t = 0; t < nT; ++t) {
-        const uint8_t* row = S + t * N;
-        for (int n = 0; n < N; ++n) cnt[n + 1] += row[n] != 0;
+    for (int n = 0; n < N; ++n) {
+        int tot = cnt[n];
+        for (int i = 0; i < nth; ++i) {                    // slab[i][n] becomes the slab's first position in neuron n's list
+            const int c = slab[(size_t)i][(size_t)n];
+            slab[(size_t)i][(size_t)n] = tot;
+            tot += c;
+        }
+        cnt[n + 1] = tot;
     }
-    for (int n = 0; n < N; ++n) cnt[n + 1] += cnt[n];
     const int64_t nnz = cnt[N];
     std::vector<int2> ev((size_t)std::max<int64_t>(nnz, 1));
-    {
-        std::vector<int> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t t = 0; t < nT; ++t) {
+    run([&](const int i) {
+        int* cur = slab[(size_t)i].data();
+        for (int64_t t = t0s[i]; t < t0s[i + 1]; ++t) {
             const uint8_t* row = S + t * N;
             for (int n = 0; n < N; ++n)
                 if (row[n]) ev[(size_t)cur[n]++] = make_int2((int)t, (int)row[n]);
         }
-    }
+    });
     h->h_ptr = cnt;
     h->h_ev.swap(ev);
     const std::vector<int2>& evr = h->h_ev;

@@ -15,7 +15,7 @@
 #ifndef PGLM_LINESEARCH_H
 #define PGLM_LINESEARCH_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PGL_LS_FN __host__ __device__ static inline __attribute__((always_inline))
 #else
 #define PGL_LS_FN static inline

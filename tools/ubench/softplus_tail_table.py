@@ -1,4 +1,4 @@
-"""Table and prototype of pgl_softplus_tail_tab (csrc/pglm_kernels.hip.h): log1p(exp(-a)) for a in [0, 12] in one table
+"""Table and prototype of pgl_softplus_tail_tab (csrc/pglm_gibbs.hip.h): log1p(exp(-a)) for a in [0, 12] in one table
 step.  `python3 tools/ubench/softplus_tail_table.py` prints the table rows ({L0, s} per interval, rounded from 60-digit
 values) and the error of the device algorithm (numpy f64, no fused multiply-adds) against the 60-digit function."""
 from decimal import Decimal, getcontext
