@@ -284,6 +284,12 @@ int pgl_gibbs_currents(pgl_handle h, int n_post, double* x_out);
 int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
             const int* neurons, int n_sel, double* A_out);
 
+/* Leading singular pair (u_0, sigma_0, v_0) of each of n (L x D) row-major matrices -- what initialize_stim_with_sta keeps of
+ * np.linalg.svd(STA) (smart_init.py:66-72).  Host arrays: A (n, L, D) in; U (n, L), sigma (n), V (n, D) out; the
+ * component of u_0 of largest magnitude is positive.  Device work with the library's own kernels (Gram matrix of the
+ * smaller side, repeated squaring, two alternating steps on A). */
+int pgl_leading_singular_pairs(pgl_handle h, const double* A, int n, int L, int D, double* U, double* sigma, double* V);
+
 /* Population.simulate (population.py:233-389), native host implementation (no GPU needed):
  * integrate-and-fire thinning of the conditional intensity.  Per bin t: lam = nlin(X[t,:]),
  * acc += lam*dt, a neuron spikes while acc > thr (thr ~ Exp(1), redrawn after each spike,

@@ -885,7 +885,8 @@ def test_bfgs_hmul_kernel_against_dense_algebra():
 
 
 def test_sta_factorisation_on_the_gpu_matches_lapack_svd():
-    """smart_init.leading_singular_pairs (batched Gram matrices + one batched symmetric eigensolve on the GPU) against
+    """smart_init.leading_singular_pairs (pgl_leading_singular_pairs: batched Gram matrices, repeated squaring, two alternating
+    steps -- the library's own kernels) against
     np.linalg.svd -- what the reference calls per neuron (smart_init.py:68-72): leading singular value to 1e-12, the vectors
     up to the pair's common sign, for wide (300 x 1024 STA), tall and noise-only matrices; same values as the host routine."""
     from theano_pyglm_amd.inference.smart_init import leading_singular_pairs, leading_singular_pair

@@ -33,7 +33,7 @@ SYMBOLS = [
     'pgl_timing_summary', 'pgl_set_stream',
     'pgl_set_stimulus_separable', 'pgl_ll_grad_list_dev', 'pgl_gibbs_prepare_all', 'pgl_gibbs_ll_cols', 'pgl_gibbs_update_cols', 'pgl_gibbs_currents',
     'pgl_bfgs_state_doubles', 'pgl_bfgs_init_dev', 'pgl_bfgs_trial_dev', 'pgl_bfgs_objective_dev',
-    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_hmul_hist_dev', 'pgl_bfgs_update_dev', 'pgl_bfgs_step_dev', 'pgl_plan_kernels',
+    'pgl_bfgs_linesearch_dev', 'pgl_bfgs_hmul_dev', 'pgl_bfgs_hmul_hist_dev', 'pgl_bfgs_update_dev', 'pgl_bfgs_step_dev', 'pgl_plan_kernels', 'pgl_leading_singular_pairs',
 ]
 
 
@@ -114,6 +114,8 @@ def load():
     lib.pgl_timing_summary.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.pgl_set_stream.argtypes = [vp, vp]
     lib.pgl_sta.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int, vp]
+    if hasattr(lib, 'pgl_leading_singular_pairs'):
+        lib.pgl_leading_singular_pairs.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.pgl_ll_grad.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pgl_ll_grad_list_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
@@ -308,6 +310,17 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_sta(self.h, _ptr(stim), stim.shape[0], stim.shape[1], float(dt_stim), int(L),
                               _ptr(sel), nsel, _ptr(out)))
         return out
+
+    def leading_singular_pairs(self, A):
+        """(U (n, L), sigma (n,), V (n, D)): leading singular pair of every matrix of the batch A (n, L, D); see
+        pgl_leading_singular_pairs."""
+        A = _f64(A)
+        if A.ndim != 3:
+            raise ValueError("A must be (n, L, D)")
+        n, L, D = A.shape
+        U, sig, V = np.empty((n, L)), np.empty(n), np.empty((n, D))
+        _chk(self.lib.pgl_leading_singular_pairs(self.h, _ptr(A), n, L, D, _ptr(U), _ptr(sig), _ptr(V)))
+        return U, sig, V
 
     # -- hot path -------------------------------------------------------------
     def ll_grad(self, theta, Weff, n_lo=0, n_hi=None, want_grad=True):

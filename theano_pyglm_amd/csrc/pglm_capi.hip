@@ -3081,6 +3081,91 @@ int pgl_simulate(int N, int64_t nT, int R, int nlin, double dt, double* X, const
     return PGL_OK;
 }
 
+// Leading singular pairs of a batch of (L x D) matrices (k_lsp_*, pglm_stim.hip.h).  Host arrays; everything in between on
+// the device with the library's own kernels.
+int pgl_leading_singular_pairs(pgl_handle h, const double* A, int n, int L, int D, double* U, double* sigma, double* V)
+{
+    if (!h || !A || !U || !sigma || !V || n <= 0 || L <= 0 || D <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    const bool wide = L <= D;                              // Gram matrix of the smaller side
+    const int m = wide ? L : D, big = wide ? D : L;
+    const size_t na = (size_t)n * L * D, ng = (size_t)n * m * m;
+    DevBuf dA, dG0, dG1, dx, dy, dn;
+    auto done = [&](int rc) {
+        release(dA); release(dG0); release(dG1); release(dx); release(dy); release(dn);
+        return rc;
+    };
+    if (ensure(dA, na * 8) || ensure(dG0, ng * 8) || ensure(dG1, ng * 8) || ensure(dx, (size_t)n * m * 8) ||
+        ensure(dy, (size_t)n * big * 8) || ensure(dn, (size_t)n * 8))
+        return done(PGL_ERR_HIP);
+    if (hipMemcpyAsync(dA.p, A, na * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) return done(fail(PGL_ERR_HIP, "upload"));
+    const double* a = (const double*)dA.p;
+    const long long sa = (long long)L * D, sg = (long long)m * m;
+    auto gemm = [&](const double* Am, long long sam, long long sak, long long sAb, const double* Bm, long long sbn, long long sbk,
+                    long long sBb, double* C, long long scm, long long scn, long long sCb, int M, int N, int K) {
+        if (N >= 64) {
+            hipLaunchKernelGGL(k_gemm_mfma<4>, dim3((M + 15) / 16, (N + 63) / 64, n), dim3(512), 0, h->stream, Am, sam, sak, Bm, sbn,
+                               sbk, C, scm, scn, M, N, K, sAb, sBb, sCb);
+        } else {
+            hipLaunchKernelGGL(k_gemm_mfma<1>, dim3((M + 15) / 16, (N + 15) / 16, n), dim3(512), 0, h->stream, Am, sam, sak, Bm, sbn,
+                               sbk, C, scm, scn, M, N, K, sAb, sBb, sCb);
+        }
+    };
+    // G = A A^T (wide) or A^T A (tall); element (i, j) of the small side
+    if (wide) gemm(a, D, 1, sa, a, D, 1, sa, (double*)dG0.p, m, 1, sg, m, m, D);
+    else gemm(a, 1, D, sa, a, 1, D, sa, (double*)dG0.p, m, 1, sg, m, m, L);
+    double* g0 = (double*)dG0.p;
+    double* g1 = (double*)dG1.p;
+    hipLaunchKernelGGL(k_lsp_trace_scale, dim3(n), dim3(1024), 0, h->stream, g0, m, sg);
+    for (int s = 0; s < 16; ++s) {                         // G <- G^2 / trace(G^2)  (G symmetric: G G^T): G^(2^16) in the end
+        gemm(g0, m, 1, sg, g0, m, 1, sg, g1, m, 1, sg, m, m, m);
+        hipLaunchKernelGGL(k_lsp_trace_scale, dim3(n), dim3(1024), 0, h->stream, g1, m, sg);
+        std::swap(g0, g1);
+    }
+    double* x = (double*)dx.p;                             // (n, m): on the small side
+    double* y = (double*)dy.p;                             // (n, big)
+    hipLaunchKernelGGL(k_lsp_pick, dim3(n), dim3(1024), 0, h->stream, (const double*)g0, m, sg, x);
+    // y = A^T x (wide: D-vector) or A x (tall: L-vector); x back from y
+    auto to_big = [&]() {
+        if (wide) gemm(a, 1, D, sa, x, 0, 1, m, y, 1, 0, big, D, 1, L);       // y[d] = sum_l A[l][d] x[l]
+        else gemm(a, D, 1, sa, x, 0, 1, m, y, 1, 0, big, L, 1, D);            // y[l] = sum_d A[l][d] x[d]
+    };
+    auto to_small = [&]() {
+        if (wide) gemm(a, D, 1, sa, y, 0, 1, big, x, 1, 0, m, L, 1, D);       // x[l] = sum_d A[l][d] y[d]
+        else gemm(a, 1, D, sa, y, 0, 1, big, x, 1, 0, m, D, 1, L);            // x[d] = sum_l A[l][d] y[l]
+    };
+    for (int it = 0; it < 2; ++it) {
+        to_big();
+        hipLaunchKernelGGL(k_lsp_normalize, dim3(n), dim3(1024), 0, h->stream, y, big, (double*)nullptr);
+        to_small();
+        hipLaunchKernelGGL(k_lsp_normalize, dim3(n), dim3(1024), 0, h->stream, x, m, (double*)nullptr);
+    }
+    to_big();                                              // |A^T x| (wide) or |A x| (tall) = sigma_0
+    hipLaunchKernelGGL(k_lsp_normalize, dim3(n), dim3(1024), 0, h->stream, y, big, (double*)dn.p);
+    if (hipGetLastError() != hipSuccess) return done(fail(PGL_ERR_HIP, "leading singular pairs: launch failed"));
+    double* Uo = wide ? x : y;
+    double* Vo = wide ? y : x;
+    bool ok = hipMemcpyAsync(U, Uo, (size_t)n * L * 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+              hipMemcpyAsync(V, Vo, (size_t)n * D * 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+              hipMemcpyAsync(sigma, dn.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+              hipStreamSynchronize(h->stream) == hipSuccess;
+    if (!ok) return done(fail(PGL_ERR_HIP, "leading singular pairs: copy failed"));
+    // sign convention: the component of u_0 of largest magnitude is positive (the pair's sign is LAPACK's business in the
+    // reference; the rank-1 filter u_0 v_0^T does not depend on it)
+    for (int b = 0; b < n; ++b) {
+        double* u = U + (size_t)b * L;
+        double* v = V + (size_t)b * D;
+        int j = 0;
+        for (int i = 1; i < L; ++i)
+            if (std::fabs(u[i]) > std::fabs(u[j])) j = i;
+        if (u[j] < 0.0) {
+            for (int i = 0; i < L; ++i) u[i] = -u[i];
+            for (int i = 0; i < D; ++i) v[i] = -v[i];
+        }
+    }
+    return done(PGL_OK);
+}
+
 int pgl_state(pgl_handle h, int n, const double* theta_n, const double* Weff_col, double* lam_out,
               double* I_net_out, double* I_stim_out)
 {

@@ -592,13 +592,18 @@ __global__ __launch_bounds__(1024) void k_sepf_finish_d(const SepfParams p)
 // + v), each on a 16 (m) x 16 NT (n) tile; the eight partial tiles are added in a fixed order through LDS.  The
 // operands of the next chunk are in flight during the MFMAs of the current one (the shapes here -- a few hundred
 // tiles, K in the thousands -- are bound by the latency of their load rounds, not by the MFMA rate).
-// grid = (ceil(M / 16), ceil(N / (16 NT))).
+// grid = (ceil(M / 16), ceil(N / (16 NT)), batch).
 template <int NT>
 __global__ __launch_bounds__(512) void k_gemm_mfma(const double* __restrict__ A, long long sam, long long sak,
                                                    const double* __restrict__ Bm, long long sbn, long long sbk,
                                                    double* __restrict__ C, long long scm, long long scn,
-                                                   int M, int Nn, int Kd)
+                                                   int M, int Nn, int Kd, long long sAb = 0, long long sBb = 0,
+                                                   long long sCb = 0)
 {
+    // (a batch of problems along blockIdx.z: operand / result strides sAb, sBb, sCb)
+    A += (size_t)blockIdx.z * sAb;
+    Bm += (size_t)blockIdx.z * sBb;
+    C += (size_t)blockIdx.z * sCb;
     constexpr int NWG = 8, KC = 8;
     __shared__ double red[NWG - 1][NT][4][64];
     const int lane = threadIdx.x & 63;
@@ -874,4 +879,82 @@ __global__ void k_transpose_u8(const uint8_t* __restrict__ S, uint8_t* __restric
         const int n = n0 + nn;
         if (t < nT && n < N) ST[(size_t)n * nT + t] = tile[tt][nn];
     }
+}
+
+// ---------------------------------------------------------------------------
+// Leading singular pair (u_0, s_0, v_0) of a batch of matrices -- all that initialize_stim_with_sta keeps of
+// np.linalg.svd(STA) (smart_init.py:66-72: the best rank-1 space x time factorisation of a neuron's spike-triggered
+// average).  On the device, with this library's own kernels: the Gram matrix of the smaller side (k_gemm_mfma, batched),
+// repeated squaring with a trace normalisation (G^(2^16): every other eigen-direction is down by (l_2 / l_1)^65536), the
+// column with the largest diagonal entry as the eigenvector, then two steps of the alternating iteration on A itself.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double pgl_block_sum1024(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+// G[b] <- G[b] / trace(G[b]) (symmetric positive semi-definite: its eigenvalues then lie in [0, 1] and the largest is >= 1 / m)
+__global__ __launch_bounds__(1024) void k_lsp_trace_scale(double* __restrict__ G, const int m, const long long sb)
+{
+    __shared__ double red[16];
+    double* g = G + (size_t)blockIdx.x * sb;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) t += g[(size_t)i * m + i];
+    t = pgl_block_sum1024(t, red);
+    if (!(t > 0.0) || t - t != 0.0) return;               // the zero matrix (no spikes) stays
+    const double inv = 1.0 / t;
+    for (int i = threadIdx.x; i < m * m; i += blockDim.x) g[i] *= inv;
+}
+// x[b] <- the column of G[b] with the largest diagonal entry, normalised (e_0 for the zero matrix)
+__global__ __launch_bounds__(1024) void k_lsp_pick(const double* __restrict__ G, const int m, const long long sb,
+                                                   double* __restrict__ x)
+{
+    __shared__ double red[16];
+    __shared__ double bestv[16];
+    __shared__ int besti[16];
+    const double* g = G + (size_t)blockIdx.x * sb;
+    double bv = -1.0;
+    int bi = 0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const double d = g[(size_t)i * m + i];
+        if (d > bv) { bv = d; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bestv[threadIdx.x >> 6] = bv; besti[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    bv = bestv[0]; bi = besti[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+        if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+    double* xo = x + (size_t)blockIdx.x * m;
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const double v = g[(size_t)i * m + bi];
+        ss = fma(v, v, ss);
+    }
+    ss = pgl_block_sum1024(ss, red);
+    const double inv = (ss > 0.0) ? 1.0 / sqrt(ss) : 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) xo[i] = (ss > 0.0) ? g[(size_t)i * m + bi] * inv : (i == 0 ? 1.0 : 0.0);
+}
+// v[b] <- v[b] / |v[b]|, nrm[b] = |v[b]| (a zero vector stays)
+__global__ __launch_bounds__(1024) void k_lsp_normalize(double* __restrict__ v, const int len, double* __restrict__ nrm)
+{
+    __shared__ double red[16];
+    double* x = v + (size_t)blockIdx.x * len;
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) ss = fma(x[i], x[i], ss);
+    ss = pgl_block_sum1024(ss, red);
+    const double n = sqrt(ss);
+    if (nrm && threadIdx.x == 0) nrm[blockIdx.x] = n;
+    if (!(n > 0.0)) return;
+    const double inv = 1.0 / n;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) x[i] *= inv;
 }

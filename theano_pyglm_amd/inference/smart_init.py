@@ -35,7 +35,7 @@ def leading_singular_pair(A):
     """(u_0, sigma_0, v_0) of A -- all the reference uses of np.linalg.svd(sn) (smart_init.py:68-72).  From the leading
     eigenvector of the smaller Gram matrix, polished by two steps of the alternating iteration on A itself: a full SVD of a
     300 x 1024 STA builds a 1024 x 1024 factor (0.3 s per neuron), the thin one still takes 0.17 s -- 11 s beside a 0.2 s MAP
-    sweep at 64 neurons; this takes 17 ms on the GPU box's host (leading_singular_pairs: all neurons in 15 ms on the GPU).  The sign of the pair is LAPACK's business in the reference; here the component
+    sweep at 64 neurons; this takes 17 ms on the GPU box's host (leading_singular_pairs: all neurons at once on the GPU).  The sign of the pair is LAPACK's business in the reference; here the component
     of u_0 of largest magnitude is positive (the rank-1 filter u_0 v_0^T does not depend on it)."""
     A = np.asarray(A, dtype=float)
     tall = A.shape[0] > A.shape[1]
@@ -64,43 +64,30 @@ def leading_singular_pair(A):
     return u * sgn, float(sig), v * sgn
 
 
-def leading_singular_pairs(S, device=None):
-    """leading_singular_pair for a batch S (n, L, D): on the GPU when there is one (batched Gram matrices, one batched
-    symmetric eigensolve, two polishing steps -- 15 ms for 64 STAs of 300 x 1024 against 64 x 17 ms on the host), same
-    sign convention.  Returns (U (n, L), sigma (n,), V (n, D))."""
+def leading_singular_pairs(S, device=None, handle=None):
+    """leading_singular_pair for a batch S (n, L, D).  With a HIP device: pgl_leading_singular_pairs -- the library's own
+    kernels (batched Gram matrices of the smaller side on the f64 MFMA, repeated squaring, two alternating steps on the
+    matrices themselves; 64 STAs of 300 x 1024 in a few ms against 64 x 17 ms on the host) on `handle` (a DeviceGlm;
+    None: a bare handle on `device` for the duration of the call).  Without the library or a device: the host routine,
+    matrix by matrix.  Same sign convention.  Returns (U (n, L), sigma (n,), V (n, D))."""
     S = np.asarray(S, dtype=float)
-    try:
-        import torch
-        use_gpu = torch.cuda.is_available() and S.ndim == 3 and min(S.shape[1:]) > 1
-    except Exception:
-        use_gpu = False
+    from theano_pyglm_amd import _lib
+    use_gpu = S.ndim == 3 and min(S.shape[1:]) > 1
+    if use_gpu and handle is None:
+        try:
+            use_gpu = _lib.device_count() > 0
+        except Exception:
+            use_gpu = False
     if not use_gpu:
         out = [leading_singular_pair(a) for a in S]
         return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out])
-    dev = torch.device('cuda', torch.cuda.current_device() if device is None else device)
-    A = torch.from_numpy(S).to(dev)
-    tall = A.shape[1] > A.shape[2]
-    At = A.transpose(1, 2)
-    G = torch.bmm(At, A) if tall else torch.bmm(A, At)
-    _, Q = torch.linalg.eigh(G)
-    x = Q[:, :, -1:].contiguous()                                   # (n, small, 1)
-    for _ in range(2):
-        y = torch.bmm(A, x) if tall else torch.bmm(At, x)
-        y = y / y.norm(dim=1, keepdim=True).clamp_min(1e-300)
-        x = torch.bmm(At, y) if tall else torch.bmm(A, y)
-        x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-300)
-    if tall:
-        u, v = torch.bmm(A, x)[:, :, 0], x[:, :, 0]
-        sig = u.norm(dim=1)
-        u = u / sig.clamp_min(1e-300)[:, None]
-    else:
-        u, v = x[:, :, 0], torch.bmm(At, x)[:, :, 0]
-        sig = v.norm(dim=1)
-        v = v / sig.clamp_min(1e-300)[:, None]
-    idx = u.abs().argmax(dim=1, keepdim=True)
-    sgn = torch.sign(u.gather(1, idx))
-    sgn = torch.where(sgn == 0, torch.ones_like(sgn), sgn)
-    return (u * sgn).cpu().numpy(), sig.cpu().numpy(), (v * sgn).cpu().numpy()
+    if handle is not None:
+        return handle.leading_singular_pairs(S)
+    tmp = _lib.DeviceGlm(1, 16, 1, 1, 'exp', 0.001, 0 if device is None else int(device))
+    try:
+        return tmp.leading_singular_pairs(S)
+    finally:
+        tmp.close()
 
 
 def stim_weights_from_sta(bkgd, sn, pair=None):
@@ -140,7 +127,7 @@ def initialize_stim_with_sta(population, data, x0, Ns=None):
     s = sta(data['stim'], data, L, Ns=Ns, handle=population._find_handle(data))
     pairs = None
     if isinstance(bkgd, SpatiotemporalStimulus) and np.ndim(s) == 3 and len(Ns) > 1:
-        U, Sig, V = leading_singular_pairs(s, device=getattr(population, 'device', None))
+        U, Sig, V = leading_singular_pairs(s, device=getattr(population, 'device', None), handle=population._find_handle(data))
         pairs = [(U[i], float(Sig[i]), V[i]) for i in range(len(Ns))]
     for i, n in enumerate(Ns):
         x0['glms'][n]['bkgd'].update(stim_weights_from_sta(bkgd, s[i], None if pairs is None else pairs[i]))
