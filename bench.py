@@ -139,7 +139,7 @@ def map_wall_clock(S, N, dt):
     stats = getattr(popn, 'last_fit_stats', None) or {}
     popn.release_data()
     return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm", "value": min(walls[1:]),
-            "first_call_s": walls[0], "sweeps_s": walls,
+            "first_call_s": walls[0], "first_over_steady": walls[0] / min(walls[1:]), "sweeps_s": walls,
             "path": "coord_descent default (batched=None -> GPU lock-step optimizer)",
             "unit": "s", "log_p_initial": lp0, "log_p_final": lp1,
             "bfgs_iterations": getattr(popn, 'last_fit_stats', {}).get('iterations'),
@@ -160,6 +160,71 @@ def map_wall_clock(S, N, dt):
                              'dense': "dense (one read-modify-write pass of 2 P^2 numbers per accepted iteration)"}
                             .get(stats.get('inverse_hessian'), 'n/a'), stats.get('lag', 'n/a'),
                             's.y/y.y' if stats.get('init_scaling') else 'none (identity)')}
+
+
+def map_wall_clock_sharded(S, N, dt, device, rank, world):
+    """The secondary metric on N > 1 ranks: the same coord_descent(maxiter=1) sweep with every evaluation time-sharded
+    (each rank its own bins of all neurons, one all-reduce of the packed (ll, grad) block per trial step:
+    inference/parallel_coord_descent.py shard='time').  Called on EVERY rank; rank 0 reports."""
+    import copy
+    from theano_pyglm_amd.models.model_factory import make_model
+    from theano_pyglm_amd.population import Population
+    from theano_pyglm_amd.inference.parallel_coord_descent import parallel_coord_descent, parallel_compute_log_p
+    popn = Population(make_model('standard_glm', N=N, dt=dt), device=device)
+    popn.add_data({'S': S, 'N': N, 'dt': dt, 'T': S.shape[0] * dt, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(0))                  # same seed on every rank
+    walls = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        x = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, shard='time')
+        walls.append(time.perf_counter() - t0)
+    popn.set_time_shard(rank, world)
+    lp1, _ = parallel_compute_log_p(popn, x, shard='time')
+    popn.set_time_shard(None)
+    stats = getattr(popn, 'last_fit_stats', None) or {}
+    popn.release_data()
+    return {"metric": "MAP wall-clock, coord_descent(maxiter=1), standard_glm, time-sharded over %d ranks" % world,
+            "value": min(walls[1:]), "first_call_s": walls[0], "sweeps_s": walls, "unit": "s", "log_p_final": lp1,
+            "ll_grad_evaluations": stats.get('evaluations'), "bfgs_iterations": stats.get('iterations'),
+            "neurons_converged_gtol": stats.get('converged_gtol'),
+            "collective": "one all-reduce of the packed (ll, grad) block of the listed neurons per trial step"}
+
+
+def narrow_shard_steps(dev, theta, d_Weff, N, P, steps=30):
+    """The step of north star's own split at 8 ranks on THIS GPU: ll+grad of a 16-neuron shard against the whole feature row
+    (one post tile: k_fused8), default f64 resident blocks and -- a labelled opt-in, never the headline -- the same blocks
+    stored as f32 (PGL_OPT_FEATURE_F32 = 2: all arithmetic f64, only the stored feature rounded)."""
+    import torch
+    from theano_pyglm_amd import _lib
+    a, b = 32, 48
+    d_th = torch.from_numpy(np.ascontiguousarray(theta[a:b])).cuda()
+    d_o = torch.zeros((b - a) * (1 + P), dtype=torch.float64, device='cuda')
+    out = {}
+    ref = None
+    for name, opt in (("f64_blocks", 0), ("f32_blocks_opt_in", 2)):
+        dev.set_option(_lib.OPT_FEATURE_F32, opt)
+        for _ in range(3):
+            dev.ll_grad_dev(d_th.data_ptr(), d_Weff.data_ptr(), d_o.data_ptr(), d_o[b - a:].data_ptr(), a, b)
+        torch.cuda.synchronize()
+        dev.timing_summary(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dev.ll_grad_dev(d_th.data_ptr(), d_Weff.data_ptr(), d_o.data_ptr(), d_o[b - a:].data_ptr(), a, b)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        _, k_ms, _ = dev.timing_summary(reset=True)
+        res = d_o.cpu().numpy().copy()
+        info = dev.info(a, b)
+        out[name] = {"ms_per_step": wall, "kernel_ms": k_ms, "resident_feature_gb": info['resident_feature_bytes'] / 1e9}
+        if ref is None:
+            ref = res
+        else:
+            out[name]["max_rel_dev_from_f64_blocks"] = {
+                "ll": float(np.max(np.abs(res[:b - a] - ref[:b - a]) / np.abs(ref[:b - a]))),
+                "grad": float(np.max(np.abs(res[b - a:] - ref[b - a:])) / np.max(np.abs(ref[b - a:])))}
+    dev.set_option(_lib.OPT_FEATURE_F32, 0)
+    out["shard"] = "neurons %d..%d of %d on the whole recording" % (a, b - 1, N)
+    return out
 
 
 def mcmc_inner_ll(S, N, dt):
@@ -786,6 +851,18 @@ def main():
                 assert np.allclose(shard_neurons.pop('_ll'), ll_ref, rtol=1e-10, atol=0), \
                     "neuron-sharded population ll differs from the single-rank evaluation"
 
+    # N > 1: the MAP sweep under the same (time) sharding, on every rank, behind the timed region
+    map_sharded = None
+    if multi and world > 1 and args.shard == 'time' and not args.no_map:
+        dev.set_stream(None)
+        try:
+            map_sharded = map_wall_clock_sharded(S, N, dt, local_rank, rank, world)
+        except Exception as e:                         # (diagnostic run: report, do not lose the headline)
+            map_sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        dev.set_stream(bench_stream.cuda_stream)
+    narrow = None
+    if not multi and N == 128 and not args.f32_features and not args.no_ab:
+        narrow = narrow_shard_steps(dev, theta, d_Weff, N, P)
     if rank == 0:
         out = {
             "metric": "population ll+grad evals/sec (N neurons x T bins)",
@@ -831,7 +908,9 @@ def main():
                 "traffic": None,
                 "kernel_ms": kern_ms,
                 "kernel_ms_source": "mean of HIP-event spans around the fused kernels of every %d-th evaluation of the "
-                                    "timed region (%d samples), on the stream they are launched on" % (TIMING_EVERY, n_timed),
+                                    "timed region (%d samples), on the stream they are launched on; a sample mean: "
+                                    "kernel_ms + prep + finalize may exceed ms_per_step (all steps) by the sampling "
+                                    "noise of a few per cent" % (TIMING_EVERY, n_timed),
                 "algorithmic_flops_per_launch": info['flops'],
                 "algorithmic_bytes_per_launch": info['bytes'],
                 "streamed_bytes_per_launch": info['streamed_bytes'],
@@ -858,6 +937,10 @@ def main():
                 out["roofline"]["mfma_busy_pmc"] = mb
         if not multi and not args.no_map and not args.f32_features:
             out["secondary"] = map_wall_clock(S, N, dt)
+        if map_sharded is not None:
+            out["secondary"] = map_sharded
+        if narrow is not None:
+            out["secondary_narrow_shard"] = narrow
         if not multi and not args.no_mcmc and not args.f32_features:
             out["secondary_mcmc"] = mcmc_inner_ll(S, N, dt)
         if not multi and not args.no_stim and not args.f32_features:
