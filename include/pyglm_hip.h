@@ -287,7 +287,9 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
 /* Leading singular pair (u_0, sigma_0, v_0) of each of n (L x D) row-major matrices -- what initialize_stim_with_sta keeps of
  * np.linalg.svd(STA) (smart_init.py:66-72).  Host arrays: A (n, L, D) in; U (n, L), sigma (n), V (n, D) out; the
  * component of u_0 of largest magnitude is positive.  Device work with the library's own kernels (Gram matrix of the
- * smaller side, repeated squaring, two alternating steps on A). */
+ * smaller side, repeated squaring, two alternating steps on A).  A == NULL: the averages a preceding pgl_sta call with
+ * A_out == NULL has left on the device (same n, L, D; consumed by this call) -- the initialisation of a wide stimulus never
+ * moves its 157 MB of averages over PCIe. */
 int pgl_leading_singular_pairs(pgl_handle h, const double* A, int n, int L, int D, double* U, double* sigma, double* V);
 
 /* Population.simulate (population.py:233-389), native host implementation (no GPU needed):

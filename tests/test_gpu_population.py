@@ -906,3 +906,28 @@ def test_sta_factorisation_on_the_gpu_matches_lapack_svd():
             assert U[i][np.argmax(np.abs(U[i]))] > 0
             uh, sh, vh = leading_singular_pair(S[i])
             assert abs(sh - Sig[i]) <= 1e-12 * sh and np.max(np.abs(uh - U[i])) < tol and np.max(np.abs(vh - V[i])) < tol
+
+
+def test_sta_factors_without_leaving_the_device():
+    """initialize_stim_with_sta on a wide stimulus: the spike-triggered averages stay on the device (pgl_sta with A_out = NULL)
+    and only their leading singular pairs come back (pgl_leading_singular_pairs with A = NULL) -- the same pairs as from the
+    averages copied out; the kept buffer is consumed by the call (a second call without a new pgl_sta fails loudly)."""
+    from theano_pyglm_amd import _lib
+    rng = np.random.default_rng(5)
+    N, nT, D, L = 6, 40000, 96, 50
+    S = np.minimum(rng.poisson(30.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    stim = rng.standard_normal((nT // 100, D))
+    d = _lib.DeviceGlm(N, nT, 1, 1, 'exp', 0.001)
+    d.set_spikes(S)
+    A = d.sta(stim, 0.1, L)
+    U0, S0, V0 = d.leading_singular_pairs(A)
+    shape = d.sta(stim, 0.1, L, keep_on_device=True)
+    assert shape == A.shape
+    U1, S1, V1 = d.leading_singular_pairs(None, shape)
+    assert np.array_equal(U0, U1) and np.array_equal(S0, S1) and np.array_equal(V0, V1)
+    for i in range(N):
+        u, s, vt = np.linalg.svd(A[i], full_matrices=False)
+        assert abs(S1[i] - s[0]) <= 1e-12 * s[0]
+    with pytest.raises(_lib.PglError):
+        d.leading_singular_pairs(None, shape)
+    d.close()

@@ -299,25 +299,29 @@ class DeviceGlm(object):
         _chk(self.lib.pgl_get_stim_features(self.h, _ptr(out)))
         return out
 
-    def sta(self, stim, dt_stim, L, Ns=None):
-        """Spike-triggered average (n_sel, L, D) of the resident spikes; see pgl_sta."""
+    def sta(self, stim, dt_stim, L, Ns=None, keep_on_device=False):
+        """Spike-triggered average (n_sel, L, D) of the resident spikes; see pgl_sta.  keep_on_device: the averages stay
+        on the device for leading_singular_pairs(None, shape) and the shape (n_sel, L, D) is returned instead."""
         stim = _f64(stim)
         if stim.ndim != 2:
             raise ValueError("stim must be (Tstim, D)")
         sel = None if Ns is None else np.ascontiguousarray(np.atleast_1d(Ns), dtype=np.int32)
         nsel = self.N if sel is None else int(sel.size)
-        out = np.empty((nsel, int(L), stim.shape[1]))
+        out = None if keep_on_device else np.empty((nsel, int(L), stim.shape[1]))
         _chk(self.lib.pgl_sta(self.h, _ptr(stim), stim.shape[0], stim.shape[1], float(dt_stim), int(L),
                               _ptr(sel), nsel, _ptr(out)))
-        return out
+        return (nsel, int(L), int(stim.shape[1])) if keep_on_device else out
 
-    def leading_singular_pairs(self, A):
+    def leading_singular_pairs(self, A, shape=None):
         """(U (n, L), sigma (n,), V (n, D)): leading singular pair of every matrix of the batch A (n, L, D); see
         pgl_leading_singular_pairs."""
-        A = _f64(A)
-        if A.ndim != 3:
-            raise ValueError("A must be (n, L, D)")
-        n, L, D = A.shape
+        if A is None:                                      # the averages sta(keep_on_device=True) left on the device
+            n, L, D = shape
+        else:
+            A = _f64(A)
+            if A.ndim != 3:
+                raise ValueError("A must be (n, L, D)")
+            n, L, D = A.shape
         U, sig, V = np.empty((n, L)), np.empty(n), np.empty((n, D))
         _chk(self.lib.pgl_leading_singular_pairs(self.h, _ptr(A), n, L, D, _ptr(U), _ptr(sig), _ptr(V)))
         return U, sig, V

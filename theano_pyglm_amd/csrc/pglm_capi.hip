@@ -86,6 +86,8 @@ struct pgl_context {
     double gibbs_bias = 0;
     // batched column Gibbs (pgl_gibbs_prepare_all / _ll_cols / _update_cols)
     DevBuf GX, gtheta, gargs, gpart, gout, ghs, gfs;
+    DevBuf staA;                         // pgl_sta with A_out == NULL: the averages (sta_n, sta_L, sta_D) stay here for
+    int sta_n = 0, sta_L = 0, sta_D = 0; // pgl_leading_singular_pairs(A == NULL)
     int gx_xs = 0;                       // row stride of GX (16 * post tiles); 0 = not prepared
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
@@ -1018,7 +1020,7 @@ int pgl_destroy(pgl_handle h)
                       &h->gbpart, &h->Xbuf, &h->imgs[0].buf, &h->imgs[1].buf, &h->imgs[2].buf, &h->imgs[3].buf, &h->imgs[4].buf, &h->imgs[5].buf, &h->imgs[6].buf, &h->imgs[7].buf, &h->IimpT, &h->Inet, &h->Istim, &h->tmpA, &h->tmpB, &h->tmpC,
                       &h->wsmall, &h->part, &h->outK, &h->lam, &h->wcol, &h->thetan, &h->GX, &h->gtheta,
                       &h->gargs, &h->gpart, &h->gout, &h->ghs, &h->gfs, &h->zf, &h->zfT, &h->sbt, &h->Yf, &h->Qb, &h->Qf,
-                      &h->spart, &h->sepC, &h->sepA, &h->sepAT, &h->sepD, &h->YfT, &h->Hb, &h->wpart, &h->QvT};
+                      &h->spart, &h->sepC, &h->sepA, &h->sepAT, &h->sepD, &h->YfT, &h->Hb, &h->wpart, &h->QvT, &h->staA};
     for (DevBuf* b : bufs) release(*b);
     for (int s = 0; s < pgl_context::NEV; ++s)
         for (int i = 0; i < 4; ++i)
@@ -1575,7 +1577,7 @@ static int sepf_backward(pgl_handle h, SepfParams& sp, double* d_grad, bool fuse
 int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_stim, int L,
             const int* neurons, int n_sel, double* A_out)
 {
-    if (!h || !stim || !A_out) return fail(PGL_ERR_ARG, "null argument");
+    if (!h || !stim) return fail(PGL_ERR_ARG, "null argument");
     if (!h->have_spikes) return fail(PGL_ERR_STATE, "pgl_set_spikes_* has not been called");
     if (Tstim <= 0 || D <= 0 || L <= 0 || !(dt_stim > 0)) return fail(PGL_ERR_ARG, "bad stimulus description");
     const int nSel = neurons ? n_sel : h->N;
@@ -1595,6 +1597,14 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
     HIPCHK(hipSetDevice(h->device));
     DevBuf dstim, distim, deoff, dpart, dA;
     auto cleanup = [&]() { release(dstim); release(distim); release(deoff); release(dpart); release(dA); };
+    // A_out == NULL: the averages stay on the device for pgl_leading_singular_pairs (157 MB for 64 neurons x 300 lags x 1024
+    // pixels would otherwise cross PCIe twice)
+    auto keep = [&]() {
+        release(h->staA);
+        h->staA = dA;
+        dA = DevBuf();
+        h->sta_n = nSel; h->sta_L = L; h->sta_D = D;
+    };
     // frame-rate form (k_sta_weights + one thin GEMM): dt_stim an integer multiple of dt, an even number of frames (the
     // GEMM's 16-byte loads), a weight matrix of at most 2 GB; dev option 94 = 7: the bin-rate form
     const double ratio = dt_stim / h->dt;
@@ -1635,10 +1645,11 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
                                (double*)dA.p, (long long)D, 1LL, Mrows, D, (int)Tstim);
             e = hipGetLastError();
         }
-        if (e == hipSuccess)
+        if (e == hipSuccess && A_out)
             e = hipMemcpyAsync(A_out, dA.p, (size_t)nSel * LD * 8, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         release(dW); release(dscale);
+        if (e == hipSuccess && !A_out) keep();
         cleanup();
         if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_sta: ") + hipGetErrorString(e));
         return PGL_OK;
@@ -1663,9 +1674,10 @@ int pgl_sta(pgl_handle h, const double* stim, int64_t Tstim, int D, double dt_st
                            h->dt / dt_stim, (double*)dA.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess)
+    if (e == hipSuccess && A_out)
         e = hipMemcpyAsync(A_out, dA.p, (size_t)nSel * LD * 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && !A_out) keep();
     cleanup();
     if (e != hipSuccess) return fail(PGL_ERR_HIP, std::string("pgl_sta: ") + hipGetErrorString(e));
     return PGL_OK;
@@ -3085,7 +3097,9 @@ int pgl_simulate(int N, int64_t nT, int R, int nlin, double dt, double* X, const
 // the device with the library's own kernels.
 int pgl_leading_singular_pairs(pgl_handle h, const double* A, int n, int L, int D, double* U, double* sigma, double* V)
 {
-    if (!h || !A || !U || !sigma || !V || n <= 0 || L <= 0 || D <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if (!h || !U || !sigma || !V || n <= 0 || L <= 0 || D <= 0) return fail(PGL_ERR_ARG, "bad argument");
+    if (!A && (!h->staA.p || h->sta_n != n || h->sta_L != L || h->sta_D != D))
+        return fail(PGL_ERR_STATE, "A == NULL: no spike-triggered averages of this shape on the device (pgl_sta with A_out == NULL)");
     HIPCHK(hipSetDevice(h->device));
     const bool wide = L <= D;                              // Gram matrix of the smaller side
     const int m = wide ? L : D, big = wide ? D : L;
@@ -3095,10 +3109,17 @@ int pgl_leading_singular_pairs(pgl_handle h, const double* A, int n, int L, int 
         release(dA); release(dG0); release(dG1); release(dx); release(dy); release(dn);
         return rc;
     };
-    if (ensure(dA, na * 8) || ensure(dG0, ng * 8) || ensure(dG1, ng * 8) || ensure(dx, (size_t)n * m * 8) ||
+    if (A) {
+        if (ensure(dA, na * 8)) return done(PGL_ERR_HIP);
+        if (hipMemcpyAsync(dA.p, A, na * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) return done(fail(PGL_ERR_HIP, "upload"));
+    } else {                                               // the averages pgl_sta left on the device; consumed by this call
+        dA = h->staA;
+        h->staA = DevBuf();
+        h->sta_n = h->sta_L = h->sta_D = 0;
+    }
+    if (ensure(dG0, ng * 8) || ensure(dG1, ng * 8) || ensure(dx, (size_t)n * m * 8) ||
         ensure(dy, (size_t)n * big * 8) || ensure(dn, (size_t)n * 8))
         return done(PGL_ERR_HIP);
-    if (hipMemcpyAsync(dA.p, A, na * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) return done(fail(PGL_ERR_HIP, "upload"));
     const double* a = (const double*)dA.p;
     const long long sa = (long long)L * D, sg = (long long)m * m;
     auto gemm = [&](const double* Am, long long sam, long long sak, long long sAb, const double* Bm, long long sbn, long long sbk,

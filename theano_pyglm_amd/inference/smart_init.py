@@ -95,9 +95,10 @@ def stim_weights_from_sta(bkgd, sn, pair=None):
     Spatiotemporal: best rank-1 factor pair f_t f_x^T of the STA (leading singular pair, each scaled
     by sqrt(sigma_0)), projected onto the temporal / spatial bases.  Basis: every stimulus dimension
     projected onto the temporal basis, stacked d-major."""
-    sn = np.asarray(sn, dtype=float)
-    if sn.ndim == 1:
-        sn = sn.reshape(-1, 1)
+    if sn is not None:
+        sn = np.asarray(sn, dtype=float)
+        if sn.ndim == 1:
+            sn = sn.reshape(-1, 1)
     if isinstance(bkgd, SpatiotemporalStimulus):
         u, sig, v = leading_singular_pair(sn) if pair is None else pair
         f_t = u * np.sqrt(sig)
@@ -124,10 +125,18 @@ def initialize_stim_with_sta(population, data, x0, Ns=None):
         Ns = np.arange(population.N)
     if isinstance(Ns, (int, np.integer)):
         Ns = [int(Ns)]
-    s = sta(data['stim'], data, L, Ns=Ns, handle=population._find_handle(data))
+    handle = population._find_handle(data)
+    if isinstance(bkgd, SpatiotemporalStimulus) and np.ndim(data['stim']) == 2 and len(Ns) > 1 and handle is not None:
+        # averages and their rank-1 factors stay on the device: only the factors (n x (L + D) numbers) come back
+        shape = sta(data['stim'], data, L, Ns=Ns, handle=handle, keep_on_device=True)
+        U, Sig, V = handle.leading_singular_pairs(None, shape)
+        for i, n in enumerate(Ns):
+            x0['glms'][n]['bkgd'].update(stim_weights_from_sta(bkgd, None, (U[i], float(Sig[i]), V[i])))
+        return
+    s = sta(data['stim'], data, L, Ns=Ns, handle=handle)
     pairs = None
     if isinstance(bkgd, SpatiotemporalStimulus) and np.ndim(s) == 3 and len(Ns) > 1:
-        U, Sig, V = leading_singular_pairs(s, device=getattr(population, 'device', None), handle=population._find_handle(data))
+        U, Sig, V = leading_singular_pairs(s, device=getattr(population, 'device', None), handle=handle)
         pairs = [(U[i], float(Sig[i]), V[i]) for i in range(len(Ns))]
     for i, n in enumerate(Ns):
         x0['glms'][n]['bkgd'].update(stim_weights_from_sta(bkgd, s[i], None if pairs is None else pairs[i]))

@@ -5,7 +5,7 @@ import numpy as np
 from theano_pyglm_amd import _lib
 
 
-def sta(stim, data, L, Ns=None, handle=None):
+def sta(stim, data, L, Ns=None, handle=None, keep_on_device=False):
     """A[i,l,:] = sum_t S[t,Ns[i]] * istim[t-l,:] / sum_t S[t,Ns[i]]  (sta.py:43-80).
 
     stim : (Tstim, D) stimulus at sampling interval data['dt_stim']
@@ -13,6 +13,8 @@ def sta(stim, data, L, Ns=None, handle=None):
            already added to a Population (Population._handle(data)); without it the spikes are
            uploaded for this call
     L    : number of lags in bins of data['dt'];  Ns: neuron indices (default all, int allowed)
+    keep_on_device (needs `handle`): the averages stay on the device for handle.leading_singular_pairs(None, shape);
+           returns their shape
     """
     stim = np.asarray(stim, dtype=float)
     if stim.ndim != 2:
@@ -29,7 +31,7 @@ def sta(stim, data, L, Ns=None, handle=None):
         h = _lib.DeviceGlm(N, nT, 1, 1, 'exp', float(data['dt']))
         h.set_spikes(S)
     try:
-        return h.sta(stim, float(data['dt_stim']), int(L), Ns=Ns)
+        return h.sta(stim, float(data['dt_stim']), int(L), Ns=Ns, keep_on_device=keep_on_device and not own)
     finally:
         if own:
             h.close()

@@ -20,6 +20,8 @@ args = ap.parse_args()
 
 import __graft_entry__ as ge
 ge.build_hip()
+import torch                              # (as in bench.py: imported and initialised before the sweep is timed)
+torch.zeros(8, device='cuda').sum().item()
 from theano_pyglm_amd.models import templates
 from theano_pyglm_amd.models.model_factory import make_model
 from theano_pyglm_amd.population import Population
