@@ -841,6 +841,40 @@ def test_map_lockstep_one_kernel_iteration_equals_split_form():
         pp.release_data()
 
 
+def test_map_lockstep_falls_back_to_scatter_when_a_list_launch_is_refused(monkeypatch):
+    """A list length whose launch plan the device path does not serve (the packing probes the whole shard and a one-neuron
+    list only) must not end a fit: from the refused launch on the trial rows are scattered into the current point and the
+    whole shard is evaluated.  Forced here by refusing the third list launch; same fits to rounding."""
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    N, nT = 24, 20000
+    rng = np.random.default_rng(78)
+    S = np.minimum(rng.poisson(20.0 * 0.001, size=(nT, N)), 10).astype(np.uint8)
+    popn = Population(make_model('standard_glm', N=N, dt=0.001))
+    popn.add_data({'S': S, 'N': N, 'dt': 0.001, 'T': nT * 0.001, 'stim': None, 'dt_stim': 0.1})
+    x0 = popn.sample(np.random.RandomState(17))
+    xa, xb = copy.deepcopy(x0), copy.deepcopy(x0)
+    fa, ita, eva = fit_glms_batched_torch(popn, xa)
+    calls = {'n': 0}
+    orig = _lib.DeviceGlm.ll_grad_list_dev
+
+    def refusing(self, *a, **k):
+        calls['n'] += 1
+        if calls['n'] >= 3:
+            raise _lib.PglError("libpyglm_hip error -4: no plan for a list of this length (test)")
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(_lib.DeviceGlm, 'll_grad_list_dev', refusing)
+    fb, itb, evb = fit_glms_batched_torch(popn, xb)
+    assert calls['n'] == 3                                     # refused once, never asked again
+    assert np.allclose(fa, fb, rtol=1e-9, atol=0) and abs(ita - itb) <= 1
+    for n in range(N):
+        # (both stop at max|g| <= 1e-5: the optima agree to what that tolerance pins down)
+        assert np.allclose(popn.glm.theta_row(xa['glms'][n]), popn.glm.theta_row(xb['glms'][n]), rtol=1e-4, atol=1e-5)
+    st = popn.last_fit_stats      # (a neuron may end on a line-search warning a hair above gtol, as in scipy)
+    assert st['converged_gtol'] + st['stalled'] == N and st['converged_gtol'] >= N - 2
+    popn.release_data()
+
+
 def test_map_lockstep_matches_sequential_c2():
     """C2 (N=32, T=300 s): every neuron's lock-step optimum equals the sequential scipy fit."""
     st = _map_compare(32, 300000, range(32), 1234 + 2)

@@ -75,6 +75,22 @@ def _worker(rank, world, port, data0, out):
     xt = parallel_coord_descent(popn, x0=copy.deepcopy(x0), maxiter=1, batched='torch', shard='time')
     lpt = popn.compute_log_p(xt)                     # full recording again (the shard is lifted on return)
     rows_t, _, _ = _pack_state(popn, xt)
+    # ... and with a memory budget that differs between the ranks (room for 4 neurons' inverse Hessians on rank 0, for 2
+    # on rank 1): the group size is the minimum over the ranks, so both run the same three groups of two neurons with
+    # identically sized all-reduces (a rank-local split would hang or sum garbage)
+    from theano_pyglm_amd.inference.batched_bfgs import fit_glms_batched_torch
+    xg = copy.deepcopy(x0)
+    P = popn.glm.P
+    popn.set_time_shard(rank, world)
+    try:
+        fit_glms_batched_torch(popn, xg, reduce=PL.allreduce_sum_t, hessian='dense',
+                               hessian_bytes=8.0 * P * (P + (P & 1)) * (4.5 if rank == 0 else 2.5))
+        groups = popn.last_fit_stats.get('groups')
+    finally:
+        popn.set_time_shard(None)
+    rows_g, _, _ = _pack_state(popn, xg)
+    assert groups == 3, groups
+    assert np.allclose(rows_g, rows_t, rtol=1e-4, atol=1e-5)
     # sharded Gibbs on the sparse_weighted_model
     m2 = make_model('sparse_weighted_model', N=N, dt=0.001)
     stabilize_sparsity(m2)

@@ -54,6 +54,8 @@ def _worker(rank, world, port, N, out):
         return lls, gs
 
     ll_t, g_t = PL.population_ll_grad_time_sharded(local_time_eval, p.nT)
+    # the neuron-group size of a time-sharded fit: every rank proposes what its free memory allows, all take the minimum
+    assert PL.allreduce_min_int(100 + 7 * ((rank * 5) % world)) == 100
     out.put((rank, total, ll_all, calls, rows, ll_t, g_t, tcalls))
     dist.destroy_process_group()
 
