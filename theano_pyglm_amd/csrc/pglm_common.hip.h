@@ -102,8 +102,8 @@ struct FusedParams {
     int rsf;                             // F row stride in elements
     int RP;                              // padded basis-table length (>= R+32, RP % 32 == 8)
     double* __restrict__ Gpart;          // [nChunks][nPT][KT][4][64]
-    double* __restrict__ llpart;         // [nChunks][nPT][64]
-    double* __restrict__ gbpart;         // [nChunks][nPT][64]
+    double* __restrict__ llpart;         // [nPT * 16 neurons][nChunks][KSPLIT] (pgl_store_ll)
+    double* __restrict__ gbpart;         // same layout
     // feature-column slice (general path for N > 128 or more than 640 columns): this launch
     // covers presynaptic neurons [np0, np0+N) and stimulus columns [ds0, ds0+Dstim); N / Dstim /
     // Kimp above are then the slice's, Nall / DsAll the strides of S, the window tables and fstim
@@ -143,7 +143,29 @@ struct FusedParams {
     double* __restrict__ sepD;
     long long sepB0;                     // frame base of the evaluated range's first tile
     int sepSL;                           // slots per base
+    // post-block-major grid (k_fused5 on the column slices of a wide population whose last post block is light): workgroup b
+    // takes post block b / nChunks, so that every CU first runs a full block, then a light one (1 = on)
+    int pb_major;
 };
+
+// A wave's ll / d ll / d bias partials (accumulator layout: lane = 16 r + column) leave the kernel summed over the four lane
+// groups and NEURON-major: [neuron][chunk][K-slice wave] -- the reduction over chunks (pgl_reduce_ll, one block per neuron)
+// then reads one contiguous run.  (In the accumulator layout a neuron owns 8 bytes of every 128-byte line: each load
+// instruction of the reduction touched 64 lines and the block sat on its CU's L1 for 19 us at C1 / C2 -- two thirds of
+// k_finalize.)
+__device__ __forceinline__ void pgl_store_ll(const FusedParams& p, const int chunk, const int pt, const int sub,
+                                             const int nsub, const int lane, double ll, double gb)
+{
+    ll += __shfl_xor(ll, 16, 64);
+    gb += __shfl_xor(gb, 16, 64);
+    ll += __shfl_xor(ll, 32, 64);
+    gb += __shfl_xor(gb, 32, 64);
+    if (lane < 16) {
+        const size_t o = (((size_t)pt * 16 + lane) * p.nChunks + chunk) * nsub + sub;
+        p.llpart[o] = ll;
+        p.gbpart[o] = gb;
+    }
+}
 
 // geometry shared by k_fused7 (writer) and k_sepf_finish_d (reader): the first tile whose frame base is b, for the
 // evaluated tiles [tile0, ...), and the chunk that holds it

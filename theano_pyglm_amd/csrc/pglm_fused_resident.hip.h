@@ -217,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nPB = (p.nPT + NW - 1) / NW;
-    const int pb = blockIdx.x % nPB;
-    const int chunk = blockIdx.x / nPB;
+    const int pb = p.pb_major ? (int)blockIdx.x / p.nChunks : (int)blockIdx.x % nPB;
+    const int chunk = p.pb_major ? (int)blockIdx.x % p.nChunks : (int)blockIdx.x / nPB;
     const int pt = pb * NW + wave;
     const bool active = pt < p.nPT;
     // role of the wave: 0 its own tile in full (or none), 1 its own tile with a helper, 2 helper of tile wpt (slot hslot of
@@ -548,9 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         }
         PGL_PROF_STORE(1);
         if (active && !FWO) {
-            const size_t slot = (size_t)chunk * p.nPT + pt;
-            p.llpart[slot * 64 + lane] = ll_acc;
-            p.gbpart[slot * 64 + lane] = gb_acc;
+            pgl_store_ll(p, chunk, pt, 0, 1, lane, ll_acc, gb_acc);
         }
         if (active && p.want_grad && !FWO) {
             double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, 0, p.nChunks, chunk, lane);
@@ -969,9 +967,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused6(const FusedParams p)
     PGL_PROF_STORE(1);
 
     if (active) {
-        const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
-        p.llpart[slot * 64 + lane] = ll_acc;
-        p.gbpart[slot * 64 + lane] = gb_acc;
+        pgl_store_ll(p, chunk, pt, ksl, KSPLIT, lane, ll_acc, gb_acc);
         if (p.want_grad) {
             double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
             const size_t gcs = (size_t)p.nChunks * 64;
@@ -1274,9 +1270,7 @@ __global__ __launch_bounds__(512, 1) void k_fused8(const FusedParams p)
         for (int tile = tile_beg, li = 0; tile < tile_end; ++tile, ++li) tile_step(std::integral_constant<int, 0>{}, tile, li);
     }
 
-    const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
-    p.llpart[slot * 64 + lane] = ll_acc;
-    p.gbpart[slot * 64 + lane] = gb_acc;
+    pgl_store_ll(p, chunk, pt, ksl, KSPLIT, lane, ll_acc, gb_acc);
     if (p.want_grad) {
         double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
         const size_t gcs = (size_t)p.nChunks * 64;
@@ -1693,9 +1687,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_fused7(const FusedParams p)
     PGL_PROF_STORE(1);
 
     if (active) {
-        const size_t slot = (size_t)chunk * p.nPT + pt;
-        p.llpart[slot * 64 + lane] = ll_acc;
-        p.gbpart[slot * 64 + lane] = gb_acc;
+        pgl_store_ll(p, chunk, pt, 0, 1, lane, ll_acc, gb_acc);
         if (p.want_grad) {
             double* gp = pgl_gpart(p.Gpart, pt, KT, 0, p.nChunks, chunk, lane);
             const size_t gcs = (size_t)p.nChunks * 64;

@@ -440,9 +440,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_fused2(const FusedParams p)
     }
 
     if (active) {
-        const size_t slot = ((size_t)chunk * p.nPT + pt) * KSPLIT + ksl;
-        p.llpart[slot * 64 + lane] = ll_acc;
-        p.gbpart[slot * 64 + lane] = gb_acc;
+        pgl_store_ll(p, chunk, pt, ksl, KSPLIT, lane, ll_acc, gb_acc);
         if (p.want_grad) {
             double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, ksl * KTW, p.nChunks, chunk, lane);
             const size_t gcs = (size_t)p.nChunks * 64;
@@ -752,9 +750,7 @@ __global__ __launch_bounds__(512, 2) void k_fused3(const FusedParams p)
     }
 
     if (active) {
-        const size_t slot = (size_t)chunk * p.nPT + pt;
-        p.llpart[slot * 64 + lane] = ll_acc;
-        p.gbpart[slot * 64 + lane] = gb_acc;
+        pgl_store_ll(p, chunk, pt, 0, 1, lane, ll_acc, gb_acc);
     }
     if (active && p.want_grad) {
         double* gp = pgl_gpart(p.Gpart, pt, KT_ALL, 0, p.nChunks, chunk, lane);

@@ -41,10 +41,9 @@ __global__ void k_prep_w(const double* __restrict__ theta, const double* __restr
 // finalize: deterministic reduction of the per-chunk partials, Weff chain rule,
 // scatter into the (npost, P) gradient layout
 // ---------------------------------------------------------------------------
-// ll_n and d ll_n / d bias of neuron n: all threads of the block stride over the (chunk, k-slice wave, lane group)
-// partials with four independent sums each, fixed-order butterfly + fixed-order combination of the waves --
-// deterministic for a given launch geometry.  (One wave walking the partials alone is a serial chain of
-// nChunks * nsub / 16 dependent global loads: 150 us for the 1 250 chunks of a 4-neuron population.)
+// ll_n and d ll_n / d bias of neuron n: its nChunks * nsub partials are one contiguous run (pgl_store_ll); 256 threads
+// stride over it with four independent sums each, fixed-order butterfly + fixed-order combination of the waves --
+// deterministic for a given launch geometry.
 __device__ __forceinline__ void pgl_reduce_ll(const double* __restrict__ llpart, const double* __restrict__ gbpart,
                                               double* __restrict__ ll_out, double* __restrict__ grad_out,
                                               const int n, const int P, const int nPT, const int nChunks,
@@ -53,19 +52,17 @@ __device__ __forceinline__ void pgl_reduce_ll(const double* __restrict__ llpart,
     // always the first 256 threads of the block, whatever its size: the ll of an ll-only call (k_finalize_ll) and of
     // an ll+grad call (trailing blocks of k_finalize) are then the same sums in the same order, bit for bit
     const int nthr = 256, t = (int)threadIdx.x, lane = t & 63, w = t >> 6, nw = 4;
-    const int pt = n >> 4, col = n & 15;
-    const int per = 4 * nsub;
-    const int total = nChunks * per;
+    const int total = nChunks * nsub;
+    const double* __restrict__ lp = llpart + (size_t)n * total;
+    const double* __restrict__ gp = gbpart + (size_t)n * total;
     double sl[4] = {0.0, 0.0, 0.0, 0.0}, sg[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i0 = t; i0 < total && t < nthr; i0 += 4 * nthr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = i0 + j * nthr;
             if (i < total) {
-                const int c = i / per, g = i - c * per;
-                const size_t idx = ((size_t)c * nPT + pt) * nsub * 64 + (size_t)g * 16 + col;
-                sl[j] += llpart[idx];
-                sg[j] += gbpart[idx];
+                sl[j] += lp[i];
+                sg[j] += gp[i];
             }
         }
     }

@@ -2,7 +2,7 @@
 kernel the dispatcher picks (make_plan) and the forced alternatives, fused-kernel and whole-evaluation time, fraction
 of the f64 MFMA peak.  Writes a markdown table (profiles/r05_shape_sweep.md via tools/r5_profiles.sh).
 
-    python tools/shape_sweep.py [T seconds = 300] [--alts] [--no-helpers] [N ...]
+    python tools/shape_sweep.py [T seconds = 300] [--alts] [--no-helpers] [--chunk-major] [N ...]
 """
 import sys
 import numpy as np
@@ -16,6 +16,7 @@ alts = '--alts' in sys.argv
 ptw = [int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--ptw=')]
 slc = [int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--slice=')]
 nohlp = '--no-helpers' in sys.argv                                  # dev option 92: two-pass kernel without helper waves (A/B)
+cmajor = '--chunk-major' in sys.argv                              # dev option 91: wide populations on the chunk-major grid (A/B)
 T = float(args[0]) if args else 300.0
 Ns = [int(a) for a in args[1:]] or [16, 32, 48, 64, 80, 96, 128, 160, 256]
 nT = int(T * 1000)
@@ -31,6 +32,8 @@ for N in Ns:
             dev.set_option(_lib.OPT_KERNEL, opt)
             if nohlp:
                 dev.set_option(92, 1)
+            if cmajor:
+                dev.set_option(91, 1)
             if slc:
                 dev.set_option(93, slc[0])                      # dev: feature columns per slice of the 3-phase path
             if ptw:
