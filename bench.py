@@ -518,7 +518,8 @@ def _self_launch_once(n, script, argv, attempts_left):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv), env=env,
+        cmd = [sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv)
+        procs.append(subprocess.Popen(cmd, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     # rank 0's stdout is drained by a thread; the parent watches the ranks: one that fails takes the others down (its
     # own children, by PID) instead of leaving them in a collective until the communicator times out
@@ -547,7 +548,8 @@ def _self_launch_once(n, script, argv, attempts_left):
         print(rec[0], flush=True)
     bad = [c for i, c in enumerate(codes) if c != 0 and i not in killed]      # the ranks that failed by themselves
     if bad or killed:
-        sys.stderr.write("bench.py: rank exit codes %s%s\n" % (codes, (" (ended by the parent: ranks %s)" % sorted(killed)) if killed else ""))
+        ended = (" (ended by the parent: ranks %s)" % sorted(killed)) if killed else ""
+        sys.stderr.write("bench.py: rank exit codes %s%s\n" % (codes, ended))
         if RENDEZVOUS_EXIT in bad and attempts_left > 1:
             sys.stderr.write("bench.py: rendezvous on port %d failed after %.0f s; launching again on a new port\n"
                              % (port, time.time() - t_start))

@@ -85,6 +85,28 @@ __device__ __forceinline__ double pgl_blk_max(double v, double* red)
     __syncthreads();
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
+// three sums (or two sums and a maximum) behind ONE pair of barriers: the same butterflies and the same combination of
+// the four waves' values as three calls of the above -- the same numbers, a third of the barriers
+__device__ __forceinline__ void pgl_blk_sum3(double& a, double& b, double& c, double* red, const bool cmax = false)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+        const double co = __shfl_xor(c, o, 64);
+        c = cmax ? fmax(c, co) : c + co;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
+        const int w = threadIdx.x >> 6;
+        red[w] = a;
+        red[4 + w] = b;
+        red[8 + w] = c;
+    }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    c = cmax ? fmax(fmax(red[8], red[9]), fmax(red[10], red[11])) : (red[8] + red[9]) + (red[10] + red[11]);
+}
 // first column of a thread's stride-256 walk over a row of P numbers (threads beyond the first 256: none)
 __device__ __forceinline__ int pgl_row_c0(const int tid, const int P) { return tid < 256 ? tid : P; }
 
@@ -92,7 +114,7 @@ __device__ __forceinline__ int pgl_row_c0(const int tid, const int P) { return t
 // first trial step min(1, 1.01 / |g|) (its old_old_fval = f + |g| / 2), rows with max|g| <= gtol never start
 __global__ __launch_bounds__(256) void k_bfgs_init(const BfgsView v, const double gtol)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     const int r = blockIdx.x, tid = threadIdx.x, P = v.P;
     const size_t o = (size_t)r * P;
     double gg = 0.0, gmax = 0.0;
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256) void k_bfgs_objective(const int P, const doubl
                                                         double* __restrict__ ll, double* __restrict__ grad,
                                                         const BfgsPrior q)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     const int j = blockIdx.x;
     pgl_bfgs_objective_row(P, Xt + (size_t)j * P, grad + (size_t)j * P, ll + j, q, red, (int)threadIdx.x);
 }
@@ -481,9 +503,7 @@ __device__ __forceinline__ void pgl_bfgs_update_row(const BfgsView& v, const int
                 vg0 = fma(v.s[o + c], v.g[o + c], vg0);
                 vg2 = fma(Hy, v.g[o + c], vg2);
             }
-            yHy = pgl_blk_sum(yHy, red);
-            vg0 = pgl_blk_sum(vg0, red);
-            vg2 = pgl_blk_sum(vg2, red);
+            pgl_blk_sum3(yHy, vg0, vg2, red);
             const double c0 = (1.0 + rho * yHy) * rho;
             for (int c = pgl_row_c0(tid, P); c < P; c += 256) {
                 const double tc = lazy ? hs * v.g[o + c] : v.t[o + c];
@@ -525,9 +545,7 @@ __device__ __forceinline__ void pgl_bfgs_update_row(const BfgsView& v, const int
         gg = fma(gc, gc, gg);
         gmax = fmax(gmax, fabs(gc));
     }
-    sl = pgl_blk_sum(sl, red);
-    gg = pgl_blk_sum(gg, red);
-    gmax = pgl_blk_max(gmax, red);
+    pgl_blk_sum3(sl, gg, gmax, red, true);
     const bool newls = a || again;
     const bool reset = newls && (again || !(sl < 0.0));      // restart / not a descent direction: H = I
     if (newls)
@@ -678,7 +696,7 @@ struct BfgsStepArgs {
 template <int NT>
 __global__ __launch_bounds__(NT) void k_bfgs_step(const BfgsView v, const BfgsStepArgs a)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     __shared__ int dec[3];
     __shared__ double part[(NT >= 512) ? NT / 64 : 1][64];
     const int j = blockIdx.x, r = a.rows ? a.rows[j] : j, tid = threadIdx.x, P = v.P;

@@ -1,6 +1,6 @@
 """Phase timeline of the resident-tile kernels for short feature rows, k_fused6 / k_fused7 (dev tool).
 Needs a -DPGL_PROF build (tools/build_variant.sh prof -DPGL_PROF):
-    PYGLM_HIP_LIB=$PWD/theano_pyglm_amd/libpyglm_hip_prof.so python tools/phase_profile_small.py C2|C5|C1 [n_hi] [PGL_OPT_KERNEL]
+    PYGLM_HIP_LIB=$PWD/theano_pyglm_amd/libpyglm_hip_prof.so python tools/phase_profile_small.py C2|C5|C1|N<size> [n_hi] [PGL_OPT_KERNEL]
 Prints the mean shader cycles per step (one 16-bin tile, or MT tiles for k_fused6 with MT = 2) a wave spends
 between the phase marks."""
 import ctypes as C
@@ -15,6 +15,8 @@ if cfg == 'C2':
     N, T, ib, kind, Ds, ws = 32, 300.0, H.std_ibasis(), 'explinear', 0, 0.5
 elif cfg == 'C1':
     N, T, ib, kind, Ds, ws = 4, 60.0, H.std_ibasis(), 'explinear', 0, 0.5
+elif cfg.startswith('N'):                                     # N16, N48, ...: standard_glm of that size, T = 300 s
+    N, T, ib, kind, Ds, ws = int(cfg[1:]), 300.0, H.std_ibasis(), 'explinear', 0, 0.5
 elif cfg == 'C3':
     N, T, ib, kind, Ds, ws = 128, 600.0, H.std_ibasis(), 'explinear', 0, 0.5
 else:

@@ -58,7 +58,8 @@ tail -24 $R/r06_map_C2_timeline.csv
 fi
 if has sweep; then
 echo "== shape sweep"
-python3 tools/shape_sweep.py 300 16 32 48 64 80 96 128 160 200 256 384 512 2>&1 | grep "^|" | tee $R/r06_shape_sweep.md
+python3 tools/shape_sweep.py 300 16 32 48 64 80 96 128 144 160 192 200 256 320 384 512 2>&1 | grep "^|" | tee $R/r06_shape_sweep.md
+(echo "# wide populations with a light last post block on the chunk-major grid (dev option 91 = 1)"; python3 tools/shape_sweep.py 300 --chunk-major 144 160 192 320 2>&1 | grep "^|") | tee $R/r06_shape_sweep_chunk_major.md
 (echo "# the same launches without helper waves (dev option 92 = 1): blocks of five / six post tiles"; python3 tools/shape_sweep.py 300 --no-helpers 80 96 2>&1 | grep "^|") | tee $R/r06_shape_sweep_no_helpers.md
 fi
 if has shards; then
