@@ -847,6 +847,29 @@ def test_narrow_post_blocks_of_a_wide_population_one_image_buffer():
     d.close()
 
 
+def test_evaluations_are_reproducible_bit_for_bit():
+    """No atomics, fixed summation orders: the same evaluation repeated on one handle, and on a second handle built from the
+    same data, returns the same bits -- for every kernel family the dispatcher picks (K-split and no-K-split resident
+    tiles, the two-pass kernel with and without helper waves, a narrow shard's block rings, column slices of a wide
+    population on the post-block-major grid, whose workgroups the dispatcher hands out in an order that varies)."""
+    from theano_pyglm_amd import _lib
+    for N, nT, lo, hi in ((32, 12000, 0, 32), (48, 6000, 0, 48), (80, 9000, 0, 80), (128, 9000, 0, 128), (128, 9000, 32, 48),
+                          (160, 9000, 0, 160)):
+        p = H.Problem(N, nT, H.std_ibasis(), seed=7 * N + hi, w_scale=0.5)
+        d = p.device()
+        ll, g = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+        for rep in range(3):
+            ll2, g2 = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+            assert np.array_equal(ll, ll2) and np.array_equal(g, g2), (N, lo, hi, rep)
+        d2 = p.device()
+        ll3, g3 = d2.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+        assert np.array_equal(ll, ll3) and np.array_equal(g, g3), (N, lo, hi)
+        ll4, _ = d2.ll_grad(p.theta[lo:hi], p.Weff, lo, hi, want_grad=False)
+        assert np.array_equal(ll, ll4)
+        d.close()
+        d2.close()
+
+
 def test_wide_population_on_resident_tiles():
     """Populations of more than 128 neurons (more than 640 feature columns) on the resident-tile two-pass kernels: equal-width
     column slices, forward-only passes of the first slices adding their currents in the slab (k_fused5<.., 1, 2 / 3>), pass 1 of
