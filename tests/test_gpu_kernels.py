@@ -884,7 +884,7 @@ def test_wide_population_on_resident_tiles():
         d = p.device()
         assert d.info()['kernel_version'] == 5 and d.info()['resident_feature_bytes'] > 0
         names = _lib.plan_kernels(N, B=p.B, R=p.ibasis.shape[0], Dstim=Ds, nT=nT)
-        assert all(n.startswith('k_fused5<') for n in names) and any(n.endswith('2, 0, 1, 0>') for n in names), names
+        assert all(n.startswith('k_fused5<') for n in names) and any(n.endswith(('2, 0, 1, 0>', '2, 0, 1, 1>')) for n in names), names
         ll, g = d.ll_grad(p.theta, p.Weff)
         d2 = p.device()
         d2.set_option(_lib.OPT_KERNEL, 2)

@@ -233,7 +233,7 @@ static int fused6_wg_per_cu(const Plan& pl);
 static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, Plan& pl,
                      bool single_slice = true, bool force7 = false, bool wide = false)
 {
-    const bool hlp_ok = single_slice && !force7 && !wide;      // (the slab-input and column-slice forms have no helper variant)
+    const bool hlp_ok = (single_slice || wide) && !force7;      // (the slab-input form of a separable stimulus has no helper variant)
     if (n_lo < 0 || n_hi > h->N || n_lo >= n_hi) return fail(PGL_ERR_ARG, "bad neuron range");
     pl.npost = n_hi - n_lo;
     pl.nPT = (pl.npost + 15) / 16;
@@ -428,11 +428,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         wgPerCU = (pl.sb6 == 2) ? 1 : fused6_wg_per_cu(pl);
     }
     int target = h->opt_nchunks > 0 ? h->opt_nchunks : std::max(1, wgPerCU * h->numCU / pl.nPB);
-    // a wide population whose last post block holds one to four tiles (N = 144, 160, 192, 320 ..): with the post blocks of a
+    // a wide population whose last post block holds one to six tiles (N = 144, 160, 192, 200, 320 ..): with the post blocks of a
     // chunk side by side, half the CUs (a third, ..) carry the light blocks and idle behind them (N = 160: 0.45 of the
     // peak).  One chunk per CU and post block, post-block-major: the dispatcher hands every CU a full block first and a
     // light one behind it -- balanced whatever the cost ratio (dev option 91 = 1: the chunk-major grid)
-    pl.pb_major = (wide && pl.version == 5 && pl.nPB > 1 && pl.nPT % 8 >= 1 && pl.nPT % 8 <= 4 && h->opt_nchunks == 0 &&
+    pl.pb_major = (wide && pl.version == 5 && pl.nPB > 1 && pl.nPT % 8 >= 1 && pl.nPT % 8 <= 6 && h->opt_nchunks == 0 &&
                    h->opt_pbmajor != 1) ? 1 : 0;
     if (pl.pb_major) target = h->numCU;
     target = std::min(target, pl.nTiles);
@@ -453,8 +453,13 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
         // the last block holds five or six post tiles: its idle waves help (plain two-pass form, rows from 10 k-tiles on;
         // PGL_OPT_KERNEL 4 / dev option 92 = 1: never)
         const int nb = pl.nPT % 8;
-        pl.hlp = (hlp_ok && (nb == 5 || nb == 6) && pl.ktl >= 5 && h->opt_hlp != 1) ? 1 : 0;
-        if (pl.hlp) pl.lds += 2 * 256 * 8;                                                         // + the helpers' partial currents
+        // (measured, r06_shape_sweep*.md / r06_shard_steps.txt: five or six tiles +7 .. 12 %; a light block of one or two tiles
+        //  at the end of a wide population +4 .. 5 %; three tiles of a single slice (a 48-neuron range of C3) +5 %, but -2 % as the
+        //  last block of a wide population, whose full blocks pay for the helper form; four tiles: the helpers share their
+        //  tile's SIMD, +-0)
+        const bool nb_ok = nb == 5 || nb == 6 || (wide ? (nb == 1 || nb == 2) : nb == 3);
+        pl.hlp = (hlp_ok && nb_ok && pl.ktl >= 5 && h->opt_hlp != 1) ? 1 : 0;
+        if (pl.hlp) pl.lds += 4 * 256 * 8;                                                         // + the helpers' partial currents
         if (pl.lds > 160 * 1024) return fail(PGL_ERR_UNSUPPORTED, "LDS budget exceeded");
         return PGL_OK;
     }
@@ -668,35 +673,35 @@ static hipError_t launch_fused5_xin(const Plan& pl, const FusedParams& fp, hipSt
 // the slice's partial currents written to the slab; 1: forward only, added to the slab; 2: the last slice -- pass 1 from the
 // slab (epilogue, residuals out, G of its L columns); 3: pass 2 on the H part; 4: pass 2 on the L part (the gradient of the
 // L columns of a slice whose pass 1 was forward only)
-template <int KTL, int KTH>
+template <int KTL, int KTH, int HLP = 0>
 static hipError_t launch_fused5_wide_t(const Plan& pl, const FusedParams& fp, hipStream_t s, int mode)
 {
     const size_t lds2h = (size_t)2 * pgl_img_bytes(KTH) + 256, lds2l = (size_t)2 * pgl_img_bytes(KTL) + 256;
     if (g_dry) {
-        if (mode <= 1) dry_record("k_fused5", {KTL, KTH, 1, mode == 0 ? 2 : 3, 0, 0});
-        else if (mode == 2) dry_record("k_fused5", {KTL, KTH, 1, 1, 0, 0});
-        else dry_record("k_fused5", {KTL, KTH, 2, 0, mode == 4 ? 1 : 0, 0});
+        if (mode <= 1) dry_record("k_fused5", {KTL, KTH, 1, mode == 0 ? 2 : 3, 0, HLP});
+        else if (mode == 2) dry_record("k_fused5", {KTL, KTH, 1, 1, 0, HLP});
+        else dry_record("k_fused5", {KTL, KTH, 2, 0, mode == 4 ? 1 : 0, HLP});
         return hipSuccess;
     }
     hipError_t e = hipSuccess;
     if (mode == 0) {
-        auto k = k_fused5<KTL, KTH, 1, 2, 0>;
+        auto k = k_fused5<KTL, KTH, 1, 2, 0, HLP>;
         if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
     } else if (mode == 1) {
-        auto k = k_fused5<KTL, KTH, 1, 3, 0>;
+        auto k = k_fused5<KTL, KTH, 1, 3, 0, HLP>;
         if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
     } else if (mode == 2) {
-        auto k = k_fused5<KTL, KTH, 1, 1, 0>;
+        auto k = k_fused5<KTL, KTH, 1, 1, 0, HLP>;
         if ((e = ensure_dyn_lds(k, pl.lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), pl.lds, s, fp);
     } else if (mode == 3) {
-        auto k = k_fused5<KTL, KTH, 2, 0, 0>;
+        auto k = k_fused5<KTL, KTH, 2, 0, 0, HLP>;
         if ((e = ensure_dyn_lds(k, lds2h)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), lds2h, s, fp);
     } else {
-        auto k = k_fused5<KTL, KTH, 2, 0, 1>;
+        auto k = k_fused5<KTL, KTH, 2, 0, 1, HLP>;
         if ((e = ensure_dyn_lds(k, lds2l)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(pl.blocks), dim3(512), lds2l, s, fp);
     }
@@ -704,6 +709,17 @@ static hipError_t launch_fused5_wide_t(const Plan& pl, const FusedParams& fp, hi
 }
 static hipError_t launch_fused5_wide(const Plan& pl, const FusedParams& fp, hipStream_t s, int mode)
 {
+    if (pl.hlp) {                                // the last post block holds one to six tiles: its idle waves help (make_plan)
+        switch (pl.ktl << 8 | pl.kth) {
+        case 5 << 8 | 5: return launch_fused5_wide_t<5, 5, 1>(pl, fp, s, mode);
+        case 7 << 8 | 7: return launch_fused5_wide_t<7, 7, 1>(pl, fp, s, mode);
+        case 9 << 8 | 11: return launch_fused5_wide_t<9, 11, 1>(pl, fp, s, mode);
+        case 12 << 8 | 14: return launch_fused5_wide_t<12, 14, 1>(pl, fp, s, mode);
+        case 14 << 8 | 18: return launch_fused5_wide_t<14, 18, 1>(pl, fp, s, mode);
+        case PGL_SPLIT_L << 8 | (40 - PGL_SPLIT_L): return launch_fused5_wide_t<PGL_SPLIT_L, 40 - PGL_SPLIT_L, 1>(pl, fp, s, mode);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.ktl << 8 | pl.kth) {
     case 5 << 8 | 5: return launch_fused5_wide_t<5, 5>(pl, fp, s, mode);
     case 7 << 8 | 7: return launch_fused5_wide_t<7, 7>(pl, fp, s, mode);

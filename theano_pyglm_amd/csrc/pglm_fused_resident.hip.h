@@ -185,7 +185,7 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 // ---------------------------------------------------------------------------
 // XIN = 1 (pass 1): the currents start from the slab p.Xbuf[tile - tile0][post tile][r][lane] -- the stimulus current of a
 // separable stimulus (k_sepf_fwd) -- which pass 1 then overwrites with the residuals as always
-// HLP = 1: blocks of FIVE or SIX post tiles (N = 65 .. 96 and the last block of 13 or 14 tiles) leave three or two of the
+// HLP = 1: blocks of ONE to SIX post tiles leave waves without a tile of their own.  Five or six (N = 65 .. 96) leave three or two of the
 // eight waves without a tile of their own, and two SIMDs with two tiles each: the idle waves take over part of the work of
 // the tiles of a doubly loaded SIMD -- in pass 1 the second half of a tile's forward k-steps (the partial currents reach
 // the tile's own wave through LDS, in front of the barrier that closes the forward phase anyway), in pass 2 the second half
@@ -195,7 +195,7 @@ __device__ __forceinline__ void pgl_dma_round(const unsigned char* __restrict__ 
 template <int KTL, int KTH, int PASS, int XIN = 0, int PART = 0, int HLP = 0>
 __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 {
-    static_assert(!HLP || (XIN == 0 && PART == 0 && KTL >= 2 && KTH >= 2), "helper waves: plain two-pass form only");
+    static_assert(!HLP || (KTL >= 2 && KTH >= 2), "helper waves: at least two k-tiles per column part");
     constexpr int TT = 16, NW = 8;
     constexpr int KT_ALL = KTL + KTH;
     constexpr int KS_ALL = 4 * KT_ALL;
@@ -234,6 +234,18 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
             role = (wave <= 1) ? 1 : ((wave >= 6) ? 2 : 0);
             wpt = pb * NW + ((wave >= 6) ? wave - 6 : wave);
             hslot = (wave == 1 || wave == 7) ? 1 : 0;
+        } else if (nb <= 4) {
+            // a light block (one to four tiles: 33 .. 64 neurons against a long row, the last block of a wide population):
+            // every tile has a helper, on a SIMD without a tile of its own where there is one
+            //   4 tiles: waves 4 .. 7 help tiles 0 .. 3;  3: waves 3, 7, 5 help tiles 0, 1, 2;  2: waves 2, 3;  1: wave 1
+            int ht = -1;
+            if (nb == 4) ht = (wave >= 4) ? wave - 4 : -1;
+            else if (nb == 3) ht = (wave == 3) ? 0 : ((wave == 7) ? 1 : ((wave == 5) ? 2 : -1));
+            else if (nb == 2) ht = (wave == 2 || wave == 3) ? wave - 2 : -1;
+            else ht = (wave == 1) ? 0 : -1;
+            role = (wave < nb) ? 1 : ((ht >= 0) ? 2 : 0);
+            wpt = pb * NW + ((ht >= 0) ? ht : wave);
+            hslot = (ht >= 0) ? ht : ((wave < nb) ? wave : 0);
         }
         role = __builtin_amdgcn_readfirstlane(role);
         wpt = __builtin_amdgcn_readfirstlane(wpt);
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
         const double bias_l = valid_n ? p.bias[nloc] : (p.nlin == 1 ? 30.0 : 0.0);
         const double* __restrict__ wrow = p.Wfrag + (size_t)(works ? wpt : 0) * KS_ALL * 64;
         double* const wscratch = reinterpret_cast<double*>(smem + 2 * IMGL + IMGH + 256) + wave * 192;   // spike compaction
-        // HLP: partial currents of the two helpers, [2][4][64], behind the spike scratch
+        // HLP: partial currents of the (up to four) helpers, [4][4][64], behind the spike scratch
         double* const Xh = reinterpret_cast<double*>(smem + 2 * IMGL + IMGH + 256) + NW * 192 + hslot * 256 + lane;
         // prologue: L and H of the first tile
         if (tile_beg < tile_end) {
@@ -456,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void k_fused5(const FusedParams p)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         double x = acc0[r] + acc1[r];
+                        if constexpr (HLP != 0) x += xh[r];
                         if constexpr (XRD) x += xin[r];
                         rs[r * 64] = x;
                     }
