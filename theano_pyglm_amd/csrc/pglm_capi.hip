@@ -450,8 +450,7 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     size_t off = ((size_t)16 * pl.rsf * esz + 15) & ~(size_t)15;
     if (pl.version == 5) {
         pl.lds = (size_t)2 * pgl_img_bytes(pl.ktl) + pgl_img_bytes(pl.kth) + 256 + 8 * 192 * 8;   // + per-wave spike scratch
-        // the last block holds five or six post tiles: its idle waves help (plain two-pass form, rows from 10 k-tiles on;
-        // PGL_OPT_KERNEL 4 / dev option 92 = 1: never)
+        // the last block leaves waves without a post tile: they help (rows from 10 k-tiles on; dev option 92 = 1: never)
         const int nb = pl.nPT % 8;
         // (measured, r06_shape_sweep*.md / r06_shard_steps.txt: five or six tiles +7 .. 12 %; a light block of one or two tiles
         //  at the end of a wide population +4 .. 5 %; three tiles of a single slice (a 48-neuron range of C3) +5 %, but -2 % as the
