@@ -19,13 +19,21 @@ class ConstantBias(Component):
 
     @staticmethod
     def I_bias(vars):
-        return float(np.ravel(vars['bias'])[0])
+        b = vars['bias']
+        try:
+            return float(b[0])
+        except (TypeError, IndexError):
+            return float(np.ravel(b)[0])
 
     def _z(self, vars):
         return (self.I_bias(vars) - self.mu_bias) / self.sig_bias
 
     def log_p(self, vars):
         return -0.5 * self._z(vars) ** 2
+
+    def log_p_all(self, vars_list):
+        z = (np.array([self.I_bias(v) for v in vars_list]) - self.mu_bias) / self.sig_bias
+        return float(-0.5 * np.sum(z ** 2))
 
     def grad_log_p(self, vars):
         return {'bias': np.array([-self._z(vars) / self.sig_bias])}

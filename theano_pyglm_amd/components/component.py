@@ -30,5 +30,13 @@ class Component(object):
     def log_p(self, vars):
         return 0.0
 
+    def log_p_all(self, vars_list):
+        """Sum of log_p over the neurons' copies of this component's variables (Population.compute_log_prior evaluates the
+        N per-neuron priors of population.py:47-69 in one go; components whose prior is a plain array expression override it)."""
+        lp = 0.0
+        for v in vars_list:
+            lp += self.log_p(v)
+        return lp
+
     def grad_log_p(self, vars):
         return {}

@@ -74,6 +74,13 @@ class LinearBasisImpulses(_ImpulseBase):
     def log_p(self, vars):
         return self.prior.log_p(self.flat_weights(vars).reshape(self.N, self.B))
 
+    def log_p_all(self, vars_list):
+        # both priors (priors.py:139 / 202) are sums over the (presynaptic neuron, basis) groups: all neurons' groups at once
+        if len(vars_list) == 0:
+            return 0.0
+        W = np.stack([self.flat_weights(v) for v in vars_list])
+        return float(self.prior.log_p(W.reshape(len(vars_list) * self.N, self.B)))
+
     def grad_log_p(self, vars):
         g = self.prior.grad_log_p(self.flat_weights(vars).reshape(self.N, self.B))
         return {'w_ir': np.asarray(g).reshape(-1)}

@@ -50,7 +50,7 @@ class GroupLasso(Component):
 
     def log_p(self, value):
         z = (np.asarray(value) - self.mu) / self.sigma
-        return -1.0 * self.lam * np.sum(np.sqrt(np.sum(z ** 2, axis=1)))
+        return -1.0 * self.lam * np.sum(np.sqrt(np.einsum('ij,ij->i', z, z)))
 
     def grad_log_p(self, value):
         """A zero group yields 0/0 = NaN like T.grad of the sqrt in the reference; callers

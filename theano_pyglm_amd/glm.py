@@ -68,6 +68,12 @@ class Glm(Component):
         return (self.bias_model.log_p(xn['bias']) + self.bkgd_model.log_p(xn['bkgd']) +
                 self.imp_model.log_p(xn['imp']) + self.nlin_model.log_p(xn.get('nlin', {})))
 
+    def log_prior_all(self, glms):
+        """sum_n log_prior(glms[n]) with every component evaluated over all neurons at once (rounding order differs from the
+        per-neuron sum by a few ulp)."""
+        return (self.bias_model.log_p_all([g['bias'] for g in glms]) + self.bkgd_model.log_p_all([g['bkgd'] for g in glms]) +
+                self.imp_model.log_p_all([g['imp'] for g in glms]) + self.nlin_model.log_p_all([g.get('nlin', {}) for g in glms]))
+
     def grad_log_prior(self, xn):
         return {'n': {}, 'bias': self.bias_model.grad_log_p(xn['bias']),
                 'bkgd': self.bkgd_model.grad_log_p(xn['bkgd']),
@@ -86,6 +92,17 @@ class Glm(Component):
         return np.concatenate(([self.bias_model.I_bias(xn['bias'])],
                                self.bkgd_model.flat_weights(xn['bkgd']),
                                self.imp_model.flat_weights(xn['imp'])))
+
+    def theta_rows(self, glms):
+        """theta_row of every listed neuron as one (n, P) matrix, filled by column blocks."""
+        D = self.Dstim
+        th = np.empty((len(glms), self.P))
+        for i, g in enumerate(glms):
+            th[i, 0] = self.bias_model.I_bias(g['bias'])
+            if D:
+                th[i, 1:1 + D] = self.bkgd_model.flat_weights(g['bkgd'])
+            th[i, 1 + D:] = self.imp_model.flat_weights(g['imp'])
+        return th
 
     def chain_grad(self, xn, g_theta):
         """Flat-weight gradient of ll (from the device) -> gradient w.r.t. the model's own

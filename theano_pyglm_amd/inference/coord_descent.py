@@ -53,7 +53,7 @@ def _neuron_lp_grad(population, x, want_grad):
 def prep_first_order_glm_inference(population):
     """coord_descent.py:15-82: returns (glm_syms, nlp, grad_nlp)."""
     glm_syms = population.glm_syms()
-    x0 = population.sample()
+    x0 = population.shape_vars()          # (the reference draws a sample here, for the shapes only: coord_descent.py:24-26)
     nvars = population.extract_vars(x0, 0)
     _, glm_shapes = packdict(get_vars(glm_syms, nvars['glm']))
 
@@ -78,7 +78,7 @@ def prep_first_order_network_inference(population):
     from theano_pyglm_amd.utils.syms import differentiable
     network = population.network
     net_syms = differentiable(population.get_variables()['net'])
-    x0 = population.sample()
+    x0 = population.shape_vars()          # (shapes only: coord_descent.py:93-95)
     _, shapes = packdict(get_vars(net_syms, x0['net']))
 
     def nlp(x_vec, x):

@@ -22,7 +22,7 @@ from theano_pyglm_amd.components.latent import LatentVariables
 from theano_pyglm_amd.components.network import Network
 from theano_pyglm_amd.glm import Glm
 from theano_pyglm_amd.utils.packvec import packdict, get_vars
-from theano_pyglm_amd.utils.syms import from_shapes, differentiable, check_bound
+from theano_pyglm_amd.utils.syms import from_shapes, differentiable, check_bound, compile_bound, compile_paths, check_paths
 
 
 class Population(object):
@@ -59,6 +59,24 @@ class Population(object):
         v['glms'] = []
         for n in range(self.N):
             xn = self.glm.sample(v, rng=rng)
+            xn['n'] = n
+            v['glms'].append(xn)
+        return v
+
+    def shape_vars(self):
+        """A value dictionary laid out like sample() with zeros of every symbol's shape -- for callers that need the
+        packing shapes only (the reference draws a sample for that, coord_descent.py:24-26, 93-95; here the shapes come from
+        the symbol table: 2 x 2.5 ms of Python per sweep at N = 128, and no random numbers consumed)."""
+        def zeros(syms):
+            out = {}
+            for k, v in syms.items():
+                out[k] = zeros(v) if isinstance(v, dict) else np.zeros(v.shape, dtype=v.dtype)
+            return out
+        syms = self.get_variables()
+        v = {'latent': {}, 'net': zeros(syms['net']), 'glms': []}
+        z = zeros(dict((k, s) for k, s in syms['glm'].items() if k != 'n'))
+        for n in range(self.N):
+            xn = dict(z)                                      # (the neurons share the zero arrays: shapes are all that is read)
             xn['n'] = n
             v['glms'].append(xn)
         return v
@@ -183,7 +201,7 @@ class Population(object):
     # -- parameters -> device layout ----------------------------------------------
     def theta_matrix(self, vars, n_lo=0, n_hi=None):
         n_hi = self.N if n_hi is None else n_hi
-        return np.array([self.glm.theta_row(vars['glms'][n]) for n in range(n_lo, n_hi)])
+        return self.glm.theta_rows([vars['glms'][n] for n in range(n_lo, n_hi)])
 
     def W_eff(self, vars):
         return self.network.W_eff(vars['net'])
@@ -195,22 +213,27 @@ class Population(object):
         cache = getattr(self, '_bound_syms', None)
         if cache is None:
             syms = self.get_variables()
-            cache = ({'net': syms['net']}, dict((k, v) for k, v in syms['glm'].items() if k != 'n'))
+            net_tree = compile_bound({'net': syms['net']})
+            glm_tree = compile_bound(dict((k, v) for k, v in syms['glm'].items() if k != 'n'))
+            cache = (net_tree, compile_paths(net_tree), glm_tree, compile_paths(glm_tree))
             self._bound_syms = cache
-        net_syms, glm_syms = cache
-        check_bound(net_syms, vars)
+        net_tree, net_paths, glm_tree, glm_paths = cache
+        check_paths(net_paths, net_tree, vars)
+        glms = vars['glms']
         for m in (range(self.N) if n is None else (n,)):
-            check_bound(glm_syms, vars['glms'][m])
+            check_paths(glm_paths, glm_tree, glms[m])
 
     # -- log probability ---------------------------------------------------------------
     def compute_log_prior(self, vars):
         """population.py:47-69: latent + network + sum_n glm.log_prior."""
+        self._check_vars(vars)
+        return self._log_prior(vars)
+
+    def _log_prior(self, vars):
         lp = 0.0
         lp += self.latent.log_p(vars.get('latent', {}))
         lp += self.network.log_p(vars['net'])
-        self._check_vars(vars)
-        for n in range(self.N):
-            lp += self.glm.log_prior(vars['glms'][n])
+        lp += self.glm.log_prior_all([vars['glms'][n] for n in range(self.N)])
         return lp
 
     def compute_ll_vector(self, vars, n_lo=0, n_hi=None):
@@ -229,12 +252,14 @@ class Population(object):
         return float(np.sum(self.compute_ll_vector(vars)))
 
     def compute_log_p(self, vars):
-        """population.py:34-45 (lkhd_scale is not applied here, like the reference)."""
+        """population.py:34-45 (lkhd_scale is not applied here, like the reference).  The variables are checked once for
+        the prior and all data sequences."""
+        self._check_vars(vars)
         lp = 0.0
-        lp += self.compute_log_prior(vars)
+        lp += self._log_prior(vars)
         for data in self.data_sequences:
             self.set_data(data)
-            lp += self.compute_ll(vars)
+            lp += float(np.sum(self.compute_ll_vector(vars)))
         return lp
 
     # -- gradients (the reference: T.grad in coord_descent.py:27-30) --------------------
