@@ -114,6 +114,41 @@ def test_log_prior_matches_oracle():
     assert np.isclose(q.compute_log_prior(y), ref)
 
 
+def test_population_fast_paths_equal_the_per_neuron_forms():
+    """compute_log_prior evaluates every component over all neurons at once, theta_matrix fills the rows by column blocks,
+    the binding check walks precompiled key paths, shape_vars replaces the sample the reference draws for its packing
+    shapes (coord_descent.py:24-26, 93-95): same values as the per-neuron forms, same error for an unbound variable."""
+    import copy
+    from theano_pyglm_amd.inference.coord_descent import get_vars
+    from theano_pyglm_amd.utils.syms import differentiable
+    for name, N in (('standard_glm', 9), ('spatiotemporal_glm', 5), ('sparse_weighted_model', 6)):
+        popn = Population(make_model(name, N=N, dt=0.001))
+        x = popn.sample(np.random.RandomState(N))
+        ref = popn.latent.log_p(x.get('latent', {})) + popn.network.log_p(x['net'])
+        for n in range(N):
+            ref += popn.glm.log_prior(x['glms'][n])
+        assert np.isclose(popn.compute_log_prior(x), ref, rtol=1e-13, atol=0)
+        rows = np.array([popn.glm.theta_row(x['glms'][n]) for n in range(N)])
+        assert np.array_equal(popn.theta_matrix(x, 0, N), rows) and np.array_equal(popn.theta_matrix(x, 2, 4), rows[2:4])
+        z = popn.shape_vars()
+        gs, ns = popn.glm_syms(), differentiable(popn.get_variables()['net'])
+        assert PV.packdict(get_vars(gs, popn.extract_vars(z, 0)['glm']))[1] == PV.packdict(get_vars(gs, popn.extract_vars(x, 0)['glm']))[1]
+        assert PV.packdict(get_vars(ns, z['net']))[1] == PV.packdict(get_vars(ns, x['net']))[1]
+        popn.compute_log_prior(z)                                  # a fully bound dictionary
+        for path in (('glms', N - 1, 'bias', 'bias'), ('glms', 0, 'imp'), ('net',), ('glms', 1, 'nlin')):
+            y = copy.deepcopy(x)
+            v = y
+            for k in path[:-1]:
+                v = v[k]
+            del v[path[-1]]
+            with pytest.raises(Exception, match="Key %s not found in either vals or defaults!" % path[-1]):
+                popn.compute_log_prior(y)
+        y = copy.deepcopy(x)
+        y['glms'][2]['imp'] = None
+        with pytest.raises(Exception, match="Key imp not found"):
+            popn.compute_log_prior(y)
+
+
 def test_flat_weights_and_chain_rules():
     rng = np.random.RandomState(2)
     q = Population(stabilize_sparsity(make_model('sparse_weighted_model', N=3, dt=0.001)))
