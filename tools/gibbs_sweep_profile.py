@@ -75,3 +75,7 @@ for rep in range(2):
           "ARS evals %d, edges %d" % (rep, t_sw, acc['wide'], acc['n_narrow'], acc['narrow'], acc['update'],
                                       t_sw - acc['wide'] - acc['narrow'] - acc['update'], upd.n_ars_evals,
                                       int(np.asarray(x['net']['graph']['A']).sum())))
+if '--cprofile' in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); upd.update_all(x); pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(28)
