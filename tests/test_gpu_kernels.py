@@ -483,6 +483,40 @@ def test_two_pass_kernel_helper_waves():
         d.close()
 
 
+def test_helper_waves_in_light_blocks():
+    """Helpers also serve a block of three post tiles of a single slice (a 33 .. 48-neuron range or list against a row of more
+    than 20 k-tiles) and the last block of one or two tiles of a wide population (every form of the kernel: forward-only
+    column slices, pass 1 from the slab, pass 2 on the L and H parts).  Against the oracle and against the same launches
+    without helpers (dev option 92): every tile of such a block is helped -- equal to rounding, not bit for bit."""
+    from theano_pyglm_amd import _lib
+    p = H.Problem(100, 3000, H.std_ibasis(), seed=77, w_scale=0.4)            # 32 k-tiles per row
+    d = p.device()
+    for lo, hi in ((10, 50), (60, 100), (3, 36)):
+        names = _lib.plan_kernels(100, B=p.B, R=p.R, nT=p.nT, n_lo=lo, count=hi - lo)
+        assert all(n.startswith('k_fused5<') and n.endswith(', 1>') for n in names), names
+        ll, g = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+        llo, go = p.oracle_ll_grad(lo, hi)
+        assert np.allclose(ll, llo, rtol=LL_RTOL) and H.rel_err(g, go) < G_RTOL
+        d.set_option(92, 1)
+        lln, gn = d.ll_grad(p.theta[lo:hi], p.Weff, lo, hi)
+        d.set_option(92, 0)
+        assert np.allclose(ll, lln, rtol=1e-12) and H.rel_err(g, gn) < 1e-12 and not np.array_equal(g, gn)
+    d.close()
+    for N, nT in ((130, 2500), (160, 6000)):                                  # wide: 8 + 1 and 8 + 2 post tiles
+        p = H.Problem(N, nT, H.std_ibasis(), seed=N + 1, w_scale=0.4)
+        names = _lib.plan_kernels(N, B=p.B, R=p.R, nT=nT)
+        assert all(n.startswith('k_fused5<') and n.endswith(', 1>') for n in names), names
+        d = p.device()
+        ll, g = d.ll_grad(p.theta, p.Weff)
+        llo, go = p.oracle_ll_grad(N - 20, N)
+        assert np.allclose(ll[N - 20:], llo, rtol=LL_RTOL) and H.rel_err(g[N - 20:], go) < G_RTOL
+        d.set_option(92, 1)
+        lln, gn = d.ll_grad(p.theta, p.Weff)
+        assert np.array_equal(ll[:128], lln[:128]) and np.array_equal(g[:128], gn[:128])         # the full block: no helpers
+        assert np.allclose(ll, lln, rtol=1e-12) and H.rel_err(g, gn) < 1e-12 and not np.array_equal(g[128:], gn[128:])
+        d.close()
+
+
 def test_forced_kernels_on_tiny_shapes():
     """Forcing the two-pass kernels on tiny problems (one k-tile per half, a single time tile, one
     neuron) must either run correctly or fall back to the K-split kernel -- never misbehave."""
