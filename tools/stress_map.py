@@ -1,7 +1,7 @@
 """C5 stress variant (spatiotemporal_glm N=64, T=300 s, D_stim=1024, identity spatial basis; P = 1220 per neuron):
 one MAP sweep through the lock-step optimizer, optionally against sequential scipy fits of a few neurons (dev tool).
 
-    python tools/stress_map.py [--maxiter 225] [--scipy 0,21,42,63] [--reps 2] [--no-sta] [--N 64] [--D 1024]
+    python tools/stress_map.py [--maxiter 225] [--scipy 0,21,42,63] [--reps 2] [--no-sta] [--N 64] [--D 1024] [--merge doubles]
 """
 import argparse, copy, json, sys, time
 import numpy as np
@@ -15,6 +15,7 @@ ap.add_argument('--N', type=int, default=64)
 ap.add_argument('--T', type=float, default=300.0)
 ap.add_argument('--D', type=int, default=1024)
 ap.add_argument('--no-sta', action='store_true')
+ap.add_argument('--merge', type=int, default=-1, help='PGL_OPT_BFGS_MERGE: doubles of update history up to which an iteration is one kernel')
 ap.add_argument('--opts', default='{}', help='JSON dict of keyword options for fit_glms_batched_torch')
 args = ap.parse_args()
 
@@ -45,6 +46,9 @@ for g in x0['glms']:
 if not args.no_sta:
     initialize_with_data(popn, popn.data_sequences[-1], x0)
 lp0 = popn.compute_log_p(x0)
+if args.merge >= 0:
+    for d in popn.data_sequences:
+        popn._handle(d).set_option(7, args.merge)
 opts = json.loads(args.opts)
 for rep in range(args.reps):
     xb = copy.deepcopy(x0)
