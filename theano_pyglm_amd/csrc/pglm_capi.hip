@@ -411,6 +411,10 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
             pl.version = 7;
             pl.nw7 = nw7;
             pl.wg7 = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds7, (size_t)(8 / nw7)));
+            // one-wave workgroups: five to seven per CU put two waves on some SIMDs and one on the others -- the kernel ends
+            // with the doubly loaded SIMDs while the others idle (N = 16: exits spread over 28 .. 67 us); one wave per SIMD
+            // and longer chunks: 0.0876 -> 0.0828 ms per evaluation (tools/shape_sweep.py, chunk-count scan of round 6)
+            if (nw7 == 1 && pl.wg7 > 4 && pl.wg7 < 8) pl.wg7 = 4;
             pl.PTW = nw7; pl.KSPLIT = 1; pl.KTW = kt7; pl.KT = kt7; pl.wpb = nw7;
             pl.nPB = (pl.nPT + nw7 - 1) / nw7;
             pl.mt = 0;
