@@ -443,8 +443,11 @@ static int make_plan(const pgl_context* h, int n_lo, int n_hi, const Slice& sl, 
     if (h->opt_nchunks == 0 && wgPerCU > 1) {
         // short recordings: a chunk keeps >= 8 tiles as long as every CU still gets a workgroup (per-chunk
         // prologue, partial write-out and the reduction over chunks are paid per chunk)
-        const int floor_t = std::min(std::max(1, h->numCU / pl.nPB), pl.nTiles);
-        target = std::min(target, std::max(floor_t, pl.nTiles / 8));
+        // (one-wave workgroups -- a single post tile on k_fused7 -- have a light prologue and fill a SIMD each: chunks from
+        //  four tiles on, every SIMD a wave; N = 16, T = 60 s: 0.047 -> 0.042 ms per evaluation, T = 20 s: 0.035 -> 0.033)
+        const bool one_wave = pl.version == 7 && pl.nw7 == 1;
+        const int floor_t = std::min(std::max(1, (one_wave ? 4 : 1) * h->numCU / pl.nPB), pl.nTiles);
+        target = std::min(target, std::max(floor_t, pl.nTiles / (one_wave ? 4 : 8)));
     }
     pl.tilesPerChunk = (pl.nTiles + target - 1) / target;
     pl.nChunks = (pl.nTiles + pl.tilesPerChunk - 1) / pl.tilesPerChunk;
